@@ -1,1 +1,16 @@
-"""placeholder - filled in below"""
+"""chainer_differentiable_mpc_amd - MI355X-native differentiable-MPC inner solver.
+
+Drop-in for the hot path of pfnet-research/chainer-differentiable-mpc: the batched LQR Riccati
+backward/forward sweep, its analytic KKT gradient and the projected-Newton box QP run as
+hand-written gfx950 HIP kernels behind the reference's own call signatures
+(`LqrRecursion`, `DiffLqr`, `PNQP`, `MPCstep`, `LQR_active`, ...).  "Variable" in the reference
+becomes `torch.Tensor` here.  Kernels are bound through a ctypes C-ABI (include/dmpc.h);
+there is no CPU fallback.
+"""
+from . import synthetic  # noqa: F401
+from ._lib import DmpcError, load as load_library  # noqa: F401
+from .util import (LinDx, QuadCost, batch_lu_factor, batch_lu_solve, bdot, bger, bmv, bquad,  # noqa: F401
+                   clamp, expand_batch, expand_time_batch, get_cost, get_traj)
+from .lqr_recursion import LqrRecursion  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,116 @@
+"""ctypes binding of libdmpc_hip.so (the C-ABI in include/dmpc.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every solver call below is
+one C function taking raw device pointers.  There is NO CPU fallback: if the shared library is
+missing or no GPU is visible the product path raises.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libdmpc_hip.so"
+LIB_PATH = os.environ.get("DMPC_LIB", os.path.join(_HERE, LIB_NAME))
+
+E_BADARG, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
+INFO_SINGULAR, INFO_NONFINITE, INFO_QP_ITERCAP, INFO_LS_ITERCAP = 1, 2, 4, 8
+
+_c_f = ctypes.c_void_p      # const float* / float* (device)
+_c_i = ctypes.c_int
+_c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/dmpc.h one to one
+SIGNATURES = {
+    "dmpc_version": (_c_i, []),
+    "dmpc_lqr_kernel_family": (_c_i, [_c_i, _c_i]),
+    "dmpc_lqr_workspace_bytes": (_c_sz, [_c_i] * 4),
+    "dmpc_lqr_solve": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_lqr_backward_sweep": (_c_i, [_c_i] * 4 + [_c_f] * 9),
+    "dmpc_lqr_forward_sweep": (_c_i, [_c_i] * 4 + [_c_f] * 10),
+    "dmpc_lqr_kkt_workspace_bytes": (_c_sz, [_c_i] * 4),
+    "dmpc_lqr_kkt_grad": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_batch_lu_factor": (_c_i, [_c_i, _c_i] + [_c_f] * 5),
+    "dmpc_batch_lu_solve": (_c_i, [_c_i, _c_i, _c_i] + [_c_f] * 5),
+    "dmpc_pnqp": (_c_i, [_c_i, _c_i] + [_c_f] * 5 + [_c_i] + [_c_f] * 7),
+    "dmpc_mpc_step_workspace_bytes": (_c_sz, [_c_i] * 4),
+    "dmpc_mpc_step_forward": (_c_i, [_c_i] * 4 + [_c_f] * 12 + [_c_i, ctypes.c_float, _c_i, _c_i]
+                              + [_c_f] * 10 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_mpc_step_backward": (_c_i, [_c_i] * 4 + [_c_f] * 9 + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DmpcError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen the HIP library (no GPU needed for this step) and attach signatures."""
+    global _lib
+    with _lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise DmpcError(
+                "%s not found at %s - build it with `python %s` (hipcc, gfx950). "
+                "There is no CPU fallback." % (LIB_NAME, p, os.path.join(_HERE, "csrc", "build.py")))
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise DmpcError("no MI355X/HIP device visible: the differentiable-MPC kernels run on the GPU only "
+                        "(there is no CPU fallback; the numpy oracle under oracle/ is test infrastructure)")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_ERR = {E_BADARG: "bad argument (NULL pointer, non-positive size or a base pointer that is not 16-byte aligned)",
+        E_UNSUPPORTED: "dimensions not covered by the HIP kernels",
+        E_WORKSPACE: "workspace missing or too small"}
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise DmpcError("%s: %s (code %d)" % (what, _ERR.get(rc, "argument error"), rc))
+    raise DmpcError("%s: HIP error %d" % (what, rc))
+
+
+def f32c(t, device=None):
+    """contiguous float32 device tensor, 16-byte aligned (clones when a view is misaligned)"""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    if device is not None and t.device != device:
+        t = t.to(device)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.data_ptr() % 16 != 0:
+        t = t.clone()
+    return t

@@ -1,0 +1,126 @@
+// lqr_api.hip - C-ABI entry points of the LQR solve family (include/dmpc.h section A).
+// Replaces LqrRecursion.backward/forward/solve_recursion (lqr/lqr_recursion.py:69-209) and
+// LQR_active (mpc/active_constrained_lqr.py:67-202) of the reference.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmpc.h"
+#include "api_util.hpp"
+#include "lqr_generic.hpp"
+#include "lqr_kernels.hpp"
+
+namespace dmpc {
+
+// LDS a 256-thread workgroup may spend on gains before we spill them to HBM.
+constexpr size_t kGainLdsBudget = 64 * 1024;
+
+template <int NX, int NU, int L>
+static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
+  constexpr int GPB = 256 / L;
+  const dim3 grid((a.B + GPB - 1) / GPB), block(256);
+  const bool masked = a.mask != nullptr;
+  const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
+#define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
+  hipLaunchKernelGGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
+  if (mode == kSolve) {
+    const bool in_lds = lds_gain <= kGainLdsBudget;
+    if (in_lds) {
+      if (masked) DMPC_LAUNCH(true, kSolve, true, lds_gain);
+      else DMPC_LAUNCH(false, kSolve, true, lds_gain);
+    } else {
+      LqrArgs s = a;  // long horizon: gains go through HBM (caller's Ks/ks, else the workspace)
+      if (s.Ks == nullptr) { s.Ks = s.wsK; s.ks = s.wsk; }
+      if (s.Ks == nullptr) return DMPC_E_WORKSPACE;
+      if (masked) hipLaunchKernelGGL((lqr_kernel<NX, NU, L, true, kSolve, false>), grid, block, 0, stream, s);
+      else hipLaunchKernelGGL((lqr_kernel<NX, NU, L, false, kSolve, false>), grid, block, 0, stream, s);
+    }
+  } else if (mode == kBackwardOnly) {
+    if (masked) DMPC_LAUNCH(true, kBackwardOnly, false, 0);
+    else DMPC_LAUNCH(false, kBackwardOnly, false, 0);
+  } else {
+    if (masked) DMPC_LAUNCH(true, kForwardOnly, false, 0);
+    else DMPC_LAUNCH(false, kForwardOnly, false, 0);
+  }
+#undef DMPC_LAUNCH
+  return (int)hipGetLastError();
+}
+
+// The shapes with a register-resident specialisation.  Anything else (ns + 1 <= 64) goes to the
+// runtime-dimension LDS kernel in lqr_generic.hpp.
+#define DMPC_LQR_SHAPES(X) \
+  X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
+  X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
+
+static int lqr_family(int nx, int nu) {
+#define X(NX_, NU_, L_) \
+  if (nx == NX_ && nu == NU_) return L_ == 16 ? 1 : 2;
+  DMPC_LQR_SHAPES(X)
+#undef X
+  if (nx >= 1 && nu >= 1 && nx + nu + 1 <= kGenericMaxCols) return 3;
+  return DMPC_E_UNSUPPORTED;
+}
+
+static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t stream) {
+#define X(NX_, NU_, L_) \
+  if (nx == NX_ && nu == NU_) return launch_lqr<NX_, NU_, L_>(mode, a, stream);
+  DMPC_LQR_SHAPES(X)
+#undef X
+  if (lqr_family(nx, nu) == 3) return launch_lqr_generic(mode, nx, nu, a, stream);
+  return DMPC_E_UNSUPPORTED;
+}
+
+}  // namespace dmpc
+
+using namespace dmpc;
+
+extern "C" {
+
+int dmpc_version(void) { return DMPC_VERSION; }
+
+int dmpc_lqr_kernel_family(int nx, int nu) { return lqr_family(nx, nu); }
+
+size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
+  // gains [T,B,nu,nx] + [T,B,nu]; only touched when they do not fit in LDS (long horizons) or
+  // by the generic kernel
+  return (size_t)T * B * nu * (nx + 1) * sizeof(float);
+}
+
+int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                   const float *f, const float *x_init, const uint8_t *u_zero_mask, float *Ks_out,
+                   float *ks_out, float *x_out, float *u_out, void *ws, size_t ws_bytes, int32_t *info,
+                   dmpc_stream_t stream) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!C || !c || !x_init || !x_out || !u_out || (T > 1 && !F)) return DMPC_E_BADARG;
+  if ((Ks_out == nullptr) != (ks_out == nullptr)) return DMPC_E_BADARG;
+  if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;
+  LqrArgs a{T, B, C, c, F, f, x_init, u_zero_mask, Ks_out, ks_out, nullptr, nullptr, x_out, u_out, info};
+  if (ws != nullptr) {
+    if (ws_bytes < dmpc_lqr_workspace_bytes(T, B, nx, nu)) return DMPC_E_WORKSPACE;
+    a.wsK = static_cast<float *>(ws);
+    a.wsk = a.wsK + (size_t)T * B * nu * nx;
+  }
+  return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
+}
+
+int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                            const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
+                            int32_t *info, dmpc_stream_t stream) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!C || !c || !Ks_out || !ks_out || (T > 1 && !F)) return DMPC_E_BADARG;
+  if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;
+  LqrArgs a{T, B, C, c, F, f, nullptr, u_zero_mask, Ks_out, ks_out, nullptr, nullptr, nullptr, nullptr, info};
+  return dispatch_lqr(kBackwardOnly, nx, nu, a, static_cast<hipStream_t>(stream));
+}
+
+int dmpc_lqr_forward_sweep(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *F,
+                           const float *f, const float *x_init, const uint8_t *u_zero_mask, float *x_out,
+                           float *u_out, int32_t *info, dmpc_stream_t stream) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!Ks || !ks || !x_init || !x_out || !u_out || (T > 1 && !F)) return DMPC_E_BADARG;
+  if (!aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;
+  LqrArgs a{T, B, nullptr, nullptr, F, f, x_init, u_zero_mask, const_cast<float *>(Ks),
+            const_cast<float *>(ks), nullptr, nullptr, x_out, u_out, info};
+  return dispatch_lqr(kForwardOnly, nx, nu, a, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

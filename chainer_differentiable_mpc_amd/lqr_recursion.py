@@ -1,0 +1,178 @@
+"""`LqrRecursion` - same constructor and methods as lqr/lqr_recursion.py:18-209 of the reference,
+computed by the fused gfx950 kernel behind `dmpc_lqr_solve` (include/dmpc.h).
+
+Inputs may be torch tensors (any device / float dtype) or numpy arrays; arithmetic is float32 on
+the GPU; outputs are torch tensors with the dtype and device of `C`.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_tensor(v):
+    if v is None or isinstance(v, torch.Tensor):
+        return v
+    return torch.as_tensor(np.asarray(v))
+
+
+def _device_of(*ts):
+    for t in ts:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    _lib.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def raise_info(info, what):
+    """Turn the kernels' per-trajectory flags into the reference's behaviour where it has one:
+    MPCstep asserts on NaN/Inf (mpc_step.py:133-135,161-162,211-223).  Synchronises (reads `info`)."""
+    if info is None or info.numel() == 0:
+        return 0
+    flags = int(np.bitwise_or.reduce(info.cpu().numpy()))
+    if flags & _lib.INFO_NONFINITE:
+        n_bad = int(((info & _lib.INFO_NONFINITE) != 0).sum().item())
+        raise AssertionError("%s: NaN/Inf in the solution of %d trajectories" % (what, n_bad))
+    return flags
+
+
+class LqrRecursion:
+    """LQR Recursion solver (time-varying, batched).  lqr/lqr_recursion.py:18."""
+
+    def __init__(self, x_init, C, c, large_f, f, T, n_state, n_ctrl, u_zero_Index=None):
+        self.x_init = _as_tensor(x_init)
+        self.C = _as_tensor(C)
+        self.c = _as_tensor(c)
+        self.F = _as_tensor(large_f)
+        self.f = _as_tensor(f)
+        self.T = int(T)
+        self.n_batch = self.C.shape[1]
+        self.n_state = int(n_state)
+        self.n_ctrl = int(n_ctrl)
+        self.n_sc = self.n_state + self.n_ctrl
+        self.u_zero_Index = _as_tensor(u_zero_Index)
+        # the reference's contracts (lqr_recursion.py:51-66); F is deliberately unchecked there
+        # beyond what indexing needs: both [T-1,...] and [T,...] are accepted, F[t], t < T-1 is read
+        assert list(self.x_init.shape) == [self.n_batch, self.n_state]
+        assert list(self.C.shape) == [self.T, self.n_batch, self.n_sc, self.n_sc], "C dim mismatch"
+        assert list(self.c.shape) == [self.T, self.n_batch, self.n_sc], \
+            str(tuple(self.c.shape)) + " c dim mismatch: expected " + str([self.T, self.n_batch, self.n_sc])
+        if self.T > 1:
+            assert self.F.shape[0] in (self.T - 1, self.T) and \
+                list(self.F.shape[1:]) == [self.n_batch, self.n_state, self.n_sc], "F dim mismatch"
+        if self.f is not None:
+            assert list(self.f.shape) == [self.T - 1, self.n_batch, self.n_state], " f dim mismatch"
+        if self.u_zero_Index is not None:
+            assert list(self.u_zero_Index.shape) == [self.T, self.n_batch, self.n_ctrl]
+        self._out_dtype = self.C.dtype if self.C.dtype.is_floating_point else torch.float32
+        self._out_device = self.C.device
+        self._dev = _device_of(self.C, self.c, self.F, self.x_init)
+        self.info = None
+
+    # -- marshalling -------------------------------------------------------------------------
+    def _dev_inputs(self):
+        d = self._dev
+        mask = None
+        if self.u_zero_Index is not None:
+            mask = self.u_zero_Index.to(device=d).to(torch.uint8).contiguous()
+        return (_lib.f32c(self.C, d), _lib.f32c(self.c, d), _lib.f32c(self.F, d), _lib.f32c(self.f, d),
+                _lib.f32c(self.x_init, d), mask)
+
+    def _out(self, t):
+        return t.to(device=self._out_device, dtype=self._out_dtype)
+
+    def _new_info(self):
+        self.info = torch.zeros(self.n_batch, dtype=torch.int32, device=self._dev)
+        return self.info
+
+    # -- reference API -----------------------------------------------------------------------
+    def backward(self):
+        """Riccati backward recursion -> (Ks, ks): lists of T per-step gains [B,nu,nx], [B,nu]
+        in forward time order (lqr_recursion.py:69-158)."""
+        lib = _lib.load()
+        _lib.require_gpu()
+        C, c, F, f, _, mask = self._dev_inputs()
+        T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
+        Ks = torch.empty((T, B, nu, nx), dtype=torch.float32, device=self._dev)
+        ks = torch.empty((T, B, nu), dtype=torch.float32, device=self._dev)
+        info = self._new_info()
+        with torch.cuda.device(self._dev):
+            _lib.check(lib.dmpc_lqr_backward_sweep(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F),
+                                                   _lib.ptr(f), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks),
+                                                   _lib.ptr(info), _lib.stream_ptr(self._dev)),
+                       "dmpc_lqr_backward_sweep")
+        Ks, ks = self._out(Ks), self._out(ks)
+        return [Ks[t] for t in range(T)], [ks[t] for t in range(T)]
+
+    def forward(self, Ks, ks):
+        """closed-loop rollout with the given gains -> (x [T,B,nx], u [T,B,nu]) (lqr_recursion.py:160-200)"""
+        assert len(Ks) == self.T, "Ks length error"
+        lib = _lib.load()
+        _lib.require_gpu()
+        _, _, F, f, x0, mask = self._dev_inputs()
+        T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
+        Kd = _lib.f32c(torch.stack(list(Ks), dim=0) if not isinstance(Ks, torch.Tensor) else Ks, self._dev)
+        kd = _lib.f32c(torch.stack(list(ks), dim=0) if not isinstance(ks, torch.Tensor) else ks, self._dev)
+        assert list(Kd.shape) == [T, B, nu, nx], "Kt dim mismatch"
+        assert list(kd.shape) == [T, B, nu], "kt dim mismatch"
+        x = torch.empty((T, B, nx), dtype=torch.float32, device=self._dev)
+        u = torch.empty((T, B, nu), dtype=torch.float32, device=self._dev)
+        info = self._new_info()
+        with torch.cuda.device(self._dev):
+            _lib.check(lib.dmpc_lqr_forward_sweep(T, B, nx, nu, _lib.ptr(Kd), _lib.ptr(kd), _lib.ptr(F),
+                                                  _lib.ptr(f), _lib.ptr(x0), _lib.ptr(mask), _lib.ptr(x),
+                                                  _lib.ptr(u), _lib.ptr(info), _lib.stream_ptr(self._dev)),
+                       "dmpc_lqr_forward_sweep")
+        return self._out(x), self._out(u)
+
+    def solve_recursion(self):
+        """backward + forward in ONE fused launch -> (x, u) (lqr_recursion.py:202-209)"""
+        x, u, _, _ = solve_device(*self._dev_inputs(), self.T, self.n_state, self.n_ctrl,
+                                  info=self._new_info())
+        return self._out(x), self._out(u)
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """grow-only per-device scratch (the C library allocates nothing itself)"""
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False, info=None, out=None):
+    """Raw fused solve on float32 device tensors (no copies): the unit the benchmark times.
+    Returns (x, u, Ks|None, ks|None)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = C.device
+    B = C.shape[1]
+    nx, nu = n_state, n_ctrl
+    if out is None:
+        x = torch.empty((T, B, nx), dtype=torch.float32, device=dev)
+        u = torch.empty((T, B, nu), dtype=torch.float32, device=dev)
+    else:
+        x, u = out
+    Ks = ks = None
+    if want_gains:
+        Ks = torch.empty((T, B, nu, nx), dtype=torch.float32, device=dev)
+        ks = torch.empty((T, B, nu), dtype=torch.float32, device=dev)
+    ws = None
+    ws_bytes = 0
+    # gains stay in LDS unless the horizon is long or the shape runs on the generic kernel
+    need = lib.dmpc_lqr_workspace_bytes(T, B, nx, nu)
+    per_traj_lds = T * nu * (nx + 1) * 4
+    if not want_gains and (per_traj_lds * 16 > 60 * 1024 or lib.dmpc_lqr_kernel_family(nx, nu) != 1):
+        ws = _workspace(need, dev)
+        ws_bytes = need
+    with torch.cuda.device(dev):
+        rc = lib.dmpc_lqr_solve(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f),
+                                _lib.ptr(x_init), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(x),
+                                _lib.ptr(u), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(dev))
+    _lib.check(rc, "dmpc_lqr_solve")
+    return x, u, Ks, ks

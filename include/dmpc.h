@@ -1,0 +1,133 @@
+/*
+ * dmpc.h - C-ABI of the MI355X-native differentiable-MPC inner solver (libdmpc_hip.so).
+ *
+ * Drop-in boundary for the hot path of pfnet-research/chainer-differentiable-mpc
+ * (the reference is pure Python; these entry points are what a ctypes binding placed in
+ * the reference's own modules would call - see INTEGRATION.md).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer to a C-contiguous, time-major float32 array
+ *     (shapes as in the reference: C [T,B,ns,ns], c [T,B,ns], F [T-1 or T,B,nx,ns]
+ *     - only F[t], t < T-1 is read -, f [T-1,B,nx] or NULL, x_init [B,nx],
+ *     x [T,B,nx], u [T,B,nu], Ks [T,B,nu,nx], ks [T,B,nu]); ns = nx + nu;
+ *   - the caller owns every buffer; the library allocates nothing, inputs are read-only;
+ *   - work is enqueued on `stream` (a hipStream_t, may be NULL) and NOT synchronised;
+ *   - return value: 0 ok, >0 a hipError_t, <0 an argument error (DMPC_E_*);
+ *   - `info` (optional, int32 [B]) receives a per-trajectory bit mask (DMPC_INFO_*).
+ *   - entry points are thread-compatible (no global mutable state).
+ */
+#ifndef DMPC_H_
+#define DMPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMPC_VERSION 100 /* 0.1.0 */
+
+#define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
+#define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */
+#define DMPC_E_WORKSPACE (-3)   /* workspace too small */
+
+#define DMPC_INFO_SINGULAR 1   /* exact zero pivot met in a Quu / H factorisation */
+#define DMPC_INFO_NONFINITE 2  /* NaN/Inf in the outputs of this trajectory */
+#define DMPC_INFO_QP_ITERCAP 4 /* projected-Newton QP hit n_iter (reference: warnings.warn, pnqp.py:192) */
+#define DMPC_INFO_LS_ITERCAP 8 /* MPC-step line search hit the safety cap (reference loop is unbounded, mpc_step.py:196) */
+
+typedef void *dmpc_stream_t; /* hipStream_t */
+
+int dmpc_version(void);
+
+/* Which kernel family a shape dispatches to: 1 = DPP row kernel (16 lanes / trajectory),
+ * 2 = wave kernel (64 lanes / trajectory), 3 = generic LDS kernel, <0 unsupported. */
+int dmpc_lqr_kernel_family(int nx, int nu);
+
+/* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active
+ *         (mpc/active_constrained_lqr.py:67-202 when `u_zero_mask` != NULL) ------------ */
+
+/* Bytes of device workspace needed by dmpc_lqr_solve (gains that do not fit in LDS). */
+size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu);
+
+/* solve_recursion(): backward Riccati sweep + forward rollout in ONE launch.
+ *   f            NULL = no affine dynamics term (lqr_recursion.py:90-92)
+ *   u_zero_mask  NULL, or uint8 [T,B,nu]: clamped controls (LQR_active semantics)
+ *   Ks_out/ks_out NULL, or gains in forward time order (lqr_recursion.py:156-158)  */
+int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                   const float *f, const float *x_init, const uint8_t *u_zero_mask, float *Ks_out,
+                   float *ks_out, float *x_out, float *u_out, void *ws, size_t ws_bytes, int32_t *info,
+                   dmpc_stream_t stream);
+
+/* backward(): gains only (lqr_recursion.py:69-158). */
+int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                            const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
+                            int32_t *info, dmpc_stream_t stream);
+
+/* forward(Ks, ks): closed-loop rollout (lqr_recursion.py:160-200). */
+int dmpc_lqr_forward_sweep(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *F,
+                           const float *f, const float *x_init, const uint8_t *u_zero_mask, float *x_out,
+                           float *u_out, int32_t *info, dmpc_stream_t stream);
+
+/* ---- B. DiffLqr.backward (lqr/differentiable_lqr.py:78-142): analytic KKT gradient ----
+ *   inputs: retained (C, c, F), solution (x, u), upstream (grad_x [T,B,nx], grad_u [T,B,nu]).
+ *   outputs: d_x_init [B,nx], dC [T,B,ns,ns], dc [T,B,ns], dF [T-1,B,nx,ns], df [T-1,B,nx]
+ *            (any of dC/dF/df may be NULL to skip it).
+ *   strict_math = 0 reproduces the reference bit-faithfully in structure: dC = 0.5*dtau(x)tau +
+ *   tau(x)dtau (:128) and df = d_lambda[0:T-1] (:133); 1 gives the symmetric dC and d_lambda[1:T]. */
+size_t dmpc_lqr_kkt_workspace_bytes(int T, int B, int nx, int nu);
+int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                      const float *x, const float *u, const float *grad_x, const float *grad_u,
+                      int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df,
+                      void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
+
+/* ---- D. batched LU (util.py:462-482 torch.lu, util.py:505-528 torch.lu_solve in float32) */
+/* A [B,n,n] -> LU [B,n,n], piv [B,n] int32 1-based (LAPACK getrf). */
+int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, int32_t *info,
+                         dmpc_stream_t stream);
+/* b [B,n,k] (k = 1 for the reference's 2-D right-hand sides) -> x [B,n,k]. */
+int dmpc_batch_lu_solve(int B, int n, int k, const float *LU, const int32_t *piv, const float *b, float *x,
+                        dmpc_stream_t stream);
+
+/* ---- C. PNQP (mpc/pnqp.py:37-201): min 1/2 x'Hx + q'x, lower <= x <= upper ------------
+ *   x_init NULL = cold start (-H^-1 q clamped).  Per-row termination (= the reference called
+ *   with a batch of one per row; its batch-global coupling is described in DESIGN.md).
+ *   outputs: x [B,n]; fac [B,n,n] = LU of the last free-set Hessian (n == 1: H_f [B,1,1]);
+ *   piv [B,n] int32 1-based; index_f [B,n] float {0,1}; n_iter_out [B] int32 (the reference's `i`). */
+int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
+              const float *x_init, int n_iter, float *x, float *fac, int32_t *piv, float *index_f,
+              int32_t *n_iter_out, int32_t *info, dmpc_stream_t stream);
+
+/* ---- E. MPCstep (mpc/mpc_step.py:70-460), LinDx true dynamics + QuadCost true cost --------
+ * forward(): Taylor re-centre (need_expand), backward_rec with one PNQP per timestep, forward_rec
+ * (clamped rollout + per-trajectory line search on the true cost).
+ *   controls/u_lower/u_upper [T,B,nu], states [T,B,nx] (current iterate);
+ *   C_hat/c_hat/F_hat/f_hat the quadratic/linear model; C_true/c_true/F_true/f_true the true
+ *   QuadCost / LinDx (may alias the model);  f_hat, f_true may be NULL.
+ *   outputs: x_out [T,B,nx], u_out [T,B,nu], Ks_out/ks_out (NULL ok), costs [B], old_costs [B]
+ *   (NULL ok), alphas [B], objs [T,B] (NULL ok), n_qp_iter [B] int32 = sum_t (1 + i_t),
+ *   n_ls_iter [B] int32.                                                                      */
+size_t dmpc_mpc_step_workspace_bytes(int T, int B, int nx, int nu);
+int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
+                          const float *F_hat, const float *f_hat, const float *controls, const float *states,
+                          const float *u_lower, const float *u_upper, const float *C_true, const float *c_true,
+                          const float *F_true, const float *f_true, int need_expand, float ls_decay,
+                          int max_ls_iter, int n_qp_iter_max, float *x_out, float *u_out, float *Ks_out,
+                          float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
+                          int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes, int32_t *info,
+                          dmpc_stream_t stream);
+
+/* backward(): active-set LQR on (-d_tau) + co-state sweeps + outer products (mpc_step.py:330-460).
+ *   outputs carry the reference's signs: dC = -1/2(dtau'(x)tau + tau(x)dtau'), dc = -dtau',
+ *   dF = -(dlam(x)tau + lam(x)dtau'), df = -dlam[1:] (NULL to skip), dx_init = -dlam[0].  */
+int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
+                           const float *F_hat, const float *x, const float *u, const float *u_lower,
+                           const float *u_upper, const float *grad_x, const float *grad_u, float *d_x_init,
+                           float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes,
+                           int32_t *info, dmpc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMPC_H_ */

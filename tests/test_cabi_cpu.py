@@ -1,0 +1,79 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/dmpc.h declares
+(no compute calls - there is no GPU here), and the host layer refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import chainer_differentiable_mpc_amd as dm
+from chainer_differentiable_mpc_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "dmpc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmpc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), "libdmpc_hip.so lacks %s" % s
+        assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
+    assert sorted(_lib.SIGNATURES) == syms
+    assert lib.dmpc_version() == 100
+
+
+def test_dispatch_table_and_workspace_queries():
+    lib = _lib.load()
+    assert lib.dmpc_lqr_kernel_family(8, 2) == 1        # DPP row kernel
+    assert lib.dmpc_lqr_kernel_family(3, 1) == 1
+    assert lib.dmpc_lqr_kernel_family(32, 8) == 2       # wave kernel
+    assert lib.dmpc_lqr_kernel_family(5, 3) == 3        # runtime-dimension kernel
+    assert lib.dmpc_lqr_kernel_family(60, 10) == _lib.E_UNSUPPORTED
+    assert lib.dmpc_lqr_workspace_bytes(50, 4096, 8, 2) == 50 * 4096 * 2 * 9 * 4
+    assert lib.dmpc_lqr_workspace_bytes(0, 1, 1, 1) == 0
+
+
+def test_argument_errors_are_reported_before_any_launch():
+    lib = _lib.load()
+    assert lib.dmpc_lqr_solve(0, 1, 1, 1, *([None] * 10), None, 0, None, None) == _lib.E_BADARG
+    assert lib.dmpc_lqr_solve(5, 1, 3, 1, *([None] * 10), None, 0, None, None) == _lib.E_BADARG
+    assert lib.dmpc_batch_lu_factor(0, 2, None, None, None, None, None) == _lib.E_BADARG
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    p = dm.synthetic.make_lqr_problem(1, 3, 2, 1)
+    with pytest.raises(dm.DmpcError):
+        dm.LqrRecursion(p["x_init"], p["C"], p["c"], p["F"], p["f"], 3, 2, 1).solve_recursion()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(dm.DmpcError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "chainer_differentiable_mpc_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+def test_synthetic_generator_is_deterministic_and_fp32_representable():
+    a = dm.synthetic.make_lqr_problem(2, 3, 4, 2, seed=7)
+    b = dm.synthetic.make_lqr_problem(2, 3, 4, 2, seed=7)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+        assert np.array_equal(a[k], a[k].astype(np.float32).astype(np.float64))
+    assert dm.synthetic.lqr_algorithmic_bytes_per_timestep(8, 2) == 832
+    assert dm.synthetic.lqr_algorithmic_bytes_per_timestep(32, 8) == 11968
+    assert dm.synthetic.kkt_algorithmic_bytes_per_timestep(8, 2) == 1624
