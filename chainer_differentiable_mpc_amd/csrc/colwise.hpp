@@ -130,6 +130,30 @@ __device__ __forceinline__ void lu_solve_inplace(const float (&LU)[N][N], const 
   }
 }
 
+// Sum of v over the lanes of a group, result in every lane of the group.
+template <int L>
+__device__ __forceinline__ float group_sum(float v);
+
+template <>
+__device__ __forceinline__ float group_sum<16>(float v) {
+  // rotate-and-add inside the 16-lane DPP row: row_ror:8,4,2,1 (dpp_ctrl 0x120 + n)
+#define DMPC_ROR_ADD(N) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, true))
+  DMPC_ROR_ADD(8);
+  DMPC_ROR_ADD(4);
+  DMPC_ROR_ADD(2);
+  DMPC_ROR_ADD(1);
+#undef DMPC_ROR_ADD
+  return v;
+}
+
+template <>
+__device__ __forceinline__ float group_sum<64>(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
 __device__ __forceinline__ bool is_finite(float v) { return fabsf(v) <= 3.402823466e+38f; }
 
 }  // namespace dmpc

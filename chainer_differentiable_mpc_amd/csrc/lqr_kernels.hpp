@@ -13,6 +13,8 @@
 // nx + nu broadcast-FMAs and no reduction.
 #pragma once
 #include "colwise.hpp"
+#include "dpp_blocks_gen.hpp"
+#include "riccati_blocks.hpp"
 
 namespace dmpc {
 
@@ -49,6 +51,14 @@ __device__ __forceinline__ void load_contig(const float *__restrict__ p, float (
   }
 }
 
+// Register ring depths: how many timesteps of inputs are in flight per lane group.  With one
+// wavefront per SIMD nothing else hides HBM/L2 latency, so the sweeps prefetch explicitly; the depth
+// is bounded by a VGPR budget (the wave kernel for large states keeps a single slot).
+constexpr int ring_depth(int regs_per_slot, int budget, int max_depth) {
+  int d = budget / regs_per_slot;
+  return d < 1 ? 1 : (d > max_depth ? max_depth : d);
+}
+
 // NX, NU: state / control dims.  L: lanes per trajectory (16 or 64).  MASKED: LQR_active.
 // MODE: fused solve, gains only, or rollout only.  K_LDS: gains handed to the forward sweep
 // through LDS (else through args.Ks/args.ks in HBM).
@@ -59,6 +69,7 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
   constexpr int GPB = 256 / L;  // trajectories per 256-thread workgroup
   constexpr int KROW = NX + 1;  // [K_m | k_m]
   using G = Group<L>;
+  using Blk = RiccatiBlocks<NX, NU, L>;
 
   const int lane = threadIdx.x % L;
   const int grp = threadIdx.x / L;
@@ -67,49 +78,61 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
   if (!live) b = a.B - 1;  // keep the whole wave in lock step; only stores are suppressed
   const int T = a.T;
   const size_t B = (size_t)a.B;
+  const bool has_f = a.f != nullptr;
 
   extern __shared__ float lds[];
   float *kl = lds + (size_t)grp * T * NU * KROW;  // this trajectory's gains [T][NU][KROW]
 
-  const bool col_mat = lane < NS;   // lane owns a matrix column
-  const bool col_aff = lane == NS;  // lane owns the affine column
-  const int kidx = col_aff ? NX : lane;  // position inside a [K_m | k_m] row
+  const bool col_aff = lane == NS;               // lane owns the affine column
+  const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the matrix re-read its last column (never used)
+  const bool k_lane = lane < NX || col_aff;      // lanes that hold a gain entry
+  const int kidx = lane < NX ? lane : NX;        // position inside a [K_m | k_m] row (k at NX)
   int info_bits = 0;
 
   if constexpr (MODE != kForwardOnly) {
     // ------------------------------------------------------------ backward Riccati sweep
+    constexpr int D = ring_depth(2 * (NS + NX), 144, 4);
+    // Ring slots.  The matrix columns are loaded by every lane with the same instructions; the affine
+    // column (lane NS only) lands in registers of its own and is merged when the slot is consumed -
+    // merging at load time would put a wait for the load right behind it.
+    float Qr[D][NS], Fr[D][NX];  // [C_t], [F_t] columns
+    float cr[D][NS], fr[D][NX];  // c_t, f_t (valid in lane NS)
+    auto issue_loads = [&](int t, float (&Qn)[NS], float (&Fn)[NX], float (&cn)[NS], float (&fn)[NX]) {
+      const size_t tb = (size_t)t * B + b;
+      const float *Cp = a.C + tb * NS * NS + lane_c;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) Qn[i] = Cp[i * NS];
+      if (t < T - 1) {
+        const float *Fp = a.F + tb * NX * NS + lane_c;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Fn[k] = Fp[k * NS];
+      }
+      if (col_aff) {
+        load_contig<NS>(a.c + tb * NS, cn);
+        if (has_f && t < T - 1) load_contig<NX>(a.f + tb * NX, fn);
+      }
+    };
+
     float V[NX];  // [V | v] columns; lanes NX..NS-1 carry junk that is never broadcast
 #pragma unroll
     for (int i = 0; i < NX; ++i) V[i] = 0.f;
 
-    for (int t = T - 1; t >= 0; --t) {
+    auto step = [&](int t, const float (&Qn)[NS], const float (&Fn)[NX], const float (&cn)[NS],
+                    const float (&fn)[NX]) {
       const size_t tb = (size_t)t * B + b;
-      float Q[NS];  // [C_t | c_t] column, then Q~
-      {
-        const float *Cp = a.C + tb * NS * NS + lane;
+      float Q[NS];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) Q[i] = col_mat ? Cp[i * NS] : 0.f;
-        if (col_aff) load_contig<NS>(a.c + tb * NS, Q);
-      }
+      for (int i = 0; i < NS; ++i) Q[i] = col_aff ? cn[i] : Qn[i];
       if (t < T - 1) {
-        float Fc[NX];  // [F_t | f_t] column
-        const float *Fp = a.F + tb * NX * NS + lane;
+        float Fc[NX];
 #pragma unroll
-        for (int k = 0; k < NX; ++k) Fc[k] = col_mat ? Fp[k * NS] : 0.f;
-        if (col_aff && a.f != nullptr) load_contig<NX>(a.f + tb * NX, Fc);
+        for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? (has_f ? fn[k] : 0.f) : Fn[k];
         // W~ = V F~ (+ v in the affine column)     lqr_recursion.py:89,96: (F^T V) F, (F^T V) f + F^T v
         float W[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) W[i] = col_aff ? V[i] : 0.f;
-        static_for<0, NX>([&](auto k) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) W[i] = fmaf(G::template bcast<k.value>(V[i]), Fc[k.value], W[i]);
-        });
-        // Q~ += F^T W~
-        static_for<0, NS>([&](auto i) {
-#pragma unroll
-          for (int k = 0; k < NX; ++k) Q[i.value] = fmaf(G::template bcast<i.value>(Fc[k]), W[k], Q[i.value]);
-        });
+        Blk::vf(W, V, Fc);
+        Blk::ftw(Q, Fc, W);  // Q~ += F^T W~
       }
       // every lane gets the full Quu                                lqr_recursion.py:102
       float Quu[NU][NU];
@@ -121,13 +144,13 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
       float Kt[NU];
 #pragma unroll
       for (int m = 0; m < NU; ++m) Kt[m] = Q[NX + m];
+      float A[NU][NU];
       if constexpr (MASKED) {
         // active_constrained_lqr.py:110-137: zero q_u / Qux rows of clamped controls, zero Quu
         // outside free x free, 1e-8 on the clamped diagonal.
         bool act[NU];
 #pragma unroll
         for (int m = 0; m < NU; ++m) act[m] = a.mask[tb * NU + m] != 0;
-        float A[NU][NU];
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
           Kt[m] = act[m] ? 0.f : Kt[m];
@@ -138,35 +161,24 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
             A[m][l] = v;
           }
         }
-        if constexpr (NU == 1) {
-          Kt[0] = -((1.0f / A[0][0]) * Kt[0]);  // :131-133
-          if (A[0][0] == 0.f) info_bits |= 1;
-        } else {
-          int piv[NU];
-          if (lu_factor_inplace<NU>(A, piv)) info_bits |= 1;
-          lu_solve_inplace<NU>(A, piv, Kt);
-#pragma unroll
-          for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
-        }
       } else {
-        if constexpr (NU == 1) {
-          Kt[0] = -((1.0f / Quu[0][0]) * Kt[0]);  // lqr_recursion.py:112-115
-          if (Quu[0][0] == 0.f) info_bits |= 1;
-        } else {
-          float A[NU][NU];
 #pragma unroll
-          for (int m = 0; m < NU; ++m)
+        for (int m = 0; m < NU; ++m)
 #pragma unroll
-            for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
-          int piv[NU];
-          if (lu_factor_inplace<NU>(A, piv)) info_bits |= 1;  // reference: F.batch_inv (LU + inverse), :116-120
-          lu_solve_inplace<NU>(A, piv, Kt);
+          for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
+      }
+      if constexpr (NU == 1) {
+        Kt[0] = -((1.0f / A[0][0]) * Kt[0]);  // lqr_recursion.py:112-115, active_constrained_lqr.py:131-133
+        if (A[0][0] == 0.f) info_bits |= 1;
+      } else {
+        int piv[NU];
+        if (lu_factor_inplace<NU>(A, piv)) info_bits |= 1;  // reference: F.batch_inv (:116-120) / torch.lu
+        lu_solve_inplace<NU>(A, piv, Kt);
 #pragma unroll
-          for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
-        }
+        for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
       }
       // hand the gains to the forward sweep / the caller
-      if (lane < NX || col_aff) {
+      if (k_lane) {
         if constexpr (K_LDS) {
 #pragma unroll
           for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + kidx] = Kt[m];
@@ -190,77 +202,118 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) V[i] = Q[i];
-        static_for<0, NU>([&](auto m) {
-#pragma unroll
-          for (int i = 0; i < NX; ++i) V[i] = fmaf(G::template bcast<NX + m.value>(Q[i]), Kt[m.value], V[i]);
-        });
-        static_for<0, NX>([&](auto i) {
-#pragma unroll
-          for (int m = 0; m < NU; ++m) V[i.value] = fmaf(G::template bcast<i.value>(Kt[m]), R[m], V[i.value]);
-        });
+        Blk::vupd(V, Q, Kt, R);
       }
+    };
+
+    // prologue: fill the ring with the last D timesteps
+    static_for<0, D>([&](auto j) {
+      const int t = T - 1 - j.value;
+      if (t >= 0) issue_loads(t, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);
+    });
+    int t0 = T - 1;
+    for (; t0 - (D - 1) >= 0; t0 -= D) {  // full groups of D steps
+      static_for<0, D>([&](auto j) {
+        const int t = t0 - j.value;
+        step(t, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);
+        if (t - D >= 0) issue_loads(t - D, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);  // refill
+      });
     }
+    static_for<0, D>([&](auto j) {  // the last T % D steps
+      const int t = t0 - j.value;
+      if (t >= 0) step(t, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);
+    });
   }
 
   if constexpr (MODE != kBackwardOnly) {
     // ------------------------------------------------------------ forward rollout
-    if constexpr (MODE == kSolve) {
-      if constexpr (K_LDS) __syncthreads();  // gains written column-wise, read row-wise
-      else __threadfence_block();
-    }
-    const bool row_x = lane < NX;            // lane i: row i of [F_t | f_t]  -> x_{t+1}[i]
-    const bool row_u = lane >= NX && lane < NS;  // lane nx+m: row m of [K_t | k_t] -> u_t[m]
-    const int m_own = row_u ? lane - NX : 0;
-    float xu = row_x ? a.x_init[(size_t)b * NX + lane] : 0.f;  // lane j<nx: x[j]; lane nx+m: u[m]
-    bool bad = false;
-    for (int t = 0; t < T; ++t) {
+    // Lane i < NX owns ROW i of [F_t | f_t] (contiguous in HBM) and x[i]; the gains stay in the column
+    // layout of the backward sweep (lane j holds K[.][j], lane NS holds k), so u_t[m] is a group sum and
+    // no transposition, barrier or second address space is needed:
+    //     u[m]  = sum_lanes Kcol[m] * xv            (xv: x[j] in lanes < NX, 1 in lane NS, else 0)
+    //     x'[i] = f[i] + sum_j F[i][j] x[j] + sum_m F[i][NX+m] u[m]
+    if constexpr (MODE == kSolve && !K_LDS) __threadfence_block();
+    constexpr int D = ring_depth(NS + 1 + NU, 112, 8);
+    const bool row_x = lane < NX;
+    const int lane_x = row_x ? lane : NX - 1;  // other lanes re-read the last row (never used)
+    float Fr[D][NS], fr[D], Kr[D][NU];
+    bool cl[D][NU];
+    auto issue_row = [&](int t, float (&Fn)[NS], float &fn, float (&Kn)[NU], bool (&cn)[NU]) {
       const size_t tb = (size_t)t * B + b;
-      float M[NS + 1];  // row of [F|f] (lanes < nx) or of [K|k] (lanes nx..ns-1); M[NS] = affine term
-#pragma unroll
-      for (int j = 0; j <= NS; ++j) M[j] = 0.f;
-      if (row_x && t < T - 1) {
-        float Fr[NS];
-        load_contig<NS>(a.F + (tb * NX + lane) * NS, Fr);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) M[j] = Fr[j];
-        if (a.f != nullptr) M[NS] = a.f[tb * NX + lane];
+      if (t < T - 1) {
+        load_contig<NS>(a.F + (tb * NX + lane_x) * NS, Fn);
+        if (has_f) fn = a.f[tb * NX + lane_x];
       }
-      bool clamp_u = false;
-      if (row_u) {
-        if constexpr (MODE == kSolve && K_LDS) {
+      if constexpr (MODE == kSolve && K_LDS) {
 #pragma unroll
-          for (int j = 0; j < NX; ++j) M[j] = kl[(t * NU + m_own) * KROW + j];
-          M[NS] = kl[(t * NU + m_own) * KROW + NX];
-        } else {
+        for (int m = 0; m < NU; ++m) Kn[m] = kl[(t * NU + m) * KROW + kidx];
+      } else {
+        // gains from HBM: lanes < NX read Ks[t][b][m][lane], lane NS reads ks[t][b][m]
 #pragma unroll
-          for (int j = 0; j < NX; ++j) M[j] = a.Ks[(tb * NU + m_own) * NX + j];
-          M[NS] = a.ks[tb * NU + m_own];
+        for (int m = 0; m < NU; ++m) {
+          const float *p = col_aff ? (a.ks + tb * NU + m) : (a.Ks + (tb * NU + m) * NX + kidx % NX);
+          Kn[m] = *p;
         }
-        if constexpr (MASKED) clamp_u = a.mask[tb * NU + m_own] != 0;
       }
-      // lanes nx+m: u = k + K x          lanes i<nx: partial x' = f + Fx x     lqr_recursion.py:177,189
-      float acc = M[NS];
-      static_for<0, NX>([&](auto j) { acc = fmaf(G::template bcast<j.value>(xu), M[j.value], acc); });
-      if (row_u) {
-        if constexpr (MASKED) acc = clamp_u ? 0.f : acc;  // :179-183
-        xu = acc;
+      if constexpr (MASKED) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) cn[m] = a.mask[tb * NU + m] != 0;
       }
-      bad = bad || !is_finite(xu);
-      if (live) {  // x_t from lanes < nx, u_t from lanes nx..ns-1
-        if (row_x) a.x[tb * NX + lane] = xu;
-        else if (row_u) a.u[tb * NU + m_own] = xu;
+    };
+    float xv = row_x ? a.x_init[(size_t)b * NX + lane] : (col_aff ? 1.f : 0.f);
+    bool bad = false;
+    auto fstep = [&](int t, const float (&Fn)[NS], const float fn, const float (&Kn)[NU], const bool (&cn)[NU]) {
+      const size_t tb = (size_t)t * B + b;
+      float u[NU];
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        u[m] = group_sum<L>(k_lane ? Kn[m] * xv : 0.f);  // lqr_recursion.py:177
+        if constexpr (MASKED) u[m] = cn[m] ? 0.f : u[m];   // :179-183
+        bad = bad || !is_finite(u[m]);
       }
-      // x' += Fu u
-      static_for<0, NU>([&](auto m) {
-        acc = fmaf(G::template bcast<NX + m.value>(xu), M[NX + m.value], acc);
+      bad = bad || !is_finite(xv);
+      if (live) {
+        if (row_x) a.x[tb * NX + lane] = xv;
+        if (lane < NU) {
+          float uo = u[0];
+#pragma unroll
+          for (int m = 1; m < NU; ++m) uo = (lane == m) ? u[m] : uo;
+          a.u[tb * NU + lane] = uo;
+        }
+      }
+      if (t < T - 1) {
+        float acc = has_f ? fn : 0.f;
+        {
+          float M[NS + 1];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) M[j] = Fn[j];
+          M[NS] = 0.f;
+          Blk::dot_x(acc, xv, M);  // :189, state part
+        }
+#pragma unroll
+        for (int m = 0; m < NU; ++m) acc = fmaf(Fn[NX + m], u[m], acc);  // control part (u is in every lane)
+        if (row_x) xv = acc;
+      }
+    };
+    static_for<0, D>([&](auto j) {
+      if (j.value < T) issue_row(j.value, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
+    });
+    int t0 = 0;
+    for (; t0 + D <= T; t0 += D) {
+      static_for<0, D>([&](auto j) {
+        const int t = t0 + j.value;
+        fstep(t, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
+        if (t + D < T) issue_row(t + D, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
       });
-      if (row_x) xu = acc;
     }
+    static_for<0, D>([&](auto j) {
+      const int t = t0 + j.value;
+      if (t < T) fstep(t, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
+    });
     if (bad) info_bits |= 2;
   }
 
   if (a.info != nullptr) {
-    // OR the group's bits into info[b]
     if (live && info_bits != 0) atomicOr(&a.info[b], info_bits);
   }
 }
