@@ -46,9 +46,13 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 
 // The shapes with a register-resident specialisation.  Anything else (ns + 1 <= 64) goes to the
 // runtime-dimension LDS kernel in lqr_generic.hpp.
+#ifdef DMPC_EXPERIMENT_ONLY_8_2  // quick single-shape builds for kernel experiments (scripts/variants.sh)
+#define DMPC_LQR_SHAPES(X) X(8, 2, 16)
+#else
 #define DMPC_LQR_SHAPES(X) \
   X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
+#endif
 
 static int lqr_family(int nx, int nu) {
 #define X(NX_, NU_, L_) \

@@ -91,26 +91,39 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
 
   if constexpr (MODE != kForwardOnly) {
     // ------------------------------------------------------------ backward Riccati sweep
-    constexpr int D = ring_depth(2 * (NS + NX), 144, 4);
-    // Ring slots.  The matrix columns are loaded by every lane with the same instructions; the affine
-    // column (lane NS only) lands in registers of its own and is merged when the slot is consumed -
-    // merging at load time would put a wait for the load right behind it.
-    float Qr[D][NS], Fr[D][NX];  // [C_t], [F_t] columns
-    float cr[D][NS], fr[D][NX];  // c_t, f_t (valid in lane NS)
+    // Two banks of G ring slots, ping-ponged: the loads of the NEXT G timesteps are issued before the
+    // current G are computed.  (hipcc drains vmcnt to 0 at the loop header, so whatever is issued last
+    // in the loop body gets no latency cover - issuing a whole bank first gives every load G steps.)
+#ifndef DMPC_BWD_BUDGET
+#define DMPC_BWD_BUDGET 72
+#define DMPC_BWD_MAXG 2
+#endif
+    constexpr int G = ring_depth(2 * (NS + NX), DMPC_BWD_BUDGET, DMPC_BWD_MAXG);
+    // The matrix columns are loaded by every lane with the same instructions.  The affine column is
+    // loaded by every lane too (all read the same c_t / f_t words - no extra HBM traffic) into
+    // registers of its own and merged into lane NS when the slot is consumed: merging at load time,
+    // or loading under `if (lane == NS)`, puts a wait for the load right behind it.
+    float Qr[2][G][NS], Fr[2][G][NX];  // [C_t], [F_t] columns
+    float cr[2][G][NS], fr[2][G][NX];  // c_t, f_t
+    // Branch-free on purpose: hipcc can only emit a counted `s_waitcnt vmcnt(N)` for the bank being
+    // consumed if the number of loads issued behind it is the same on every path.  Out-of-range
+    // timesteps are clamped (the duplicate loads are never consumed), F_{T-1} does not exist and is
+    // replaced by F_{T-2}, and a missing f reads c instead (both discarded by the merge in step()).
+    const float *Fsafe = T > 1 ? a.F : a.C;
+    const float *fsafe = has_f ? a.f : a.c;
     auto issue_loads = [&](int t, float (&Qn)[NS], float (&Fn)[NX], float (&cn)[NS], float (&fn)[NX]) {
+      t = t < 0 ? 0 : t;
       const size_t tb = (size_t)t * B + b;
+      const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+      const size_t tbF = (size_t)tF * B + b;
       const float *Cp = a.C + tb * NS * NS + lane_c;
 #pragma unroll
       for (int i = 0; i < NS; ++i) Qn[i] = Cp[i * NS];
-      if (t < T - 1) {
-        const float *Fp = a.F + tb * NX * NS + lane_c;
+      load_contig<NS>(a.c + tb * NS, cn);
+      const float *Fp = Fsafe + tbF * NX * NS + lane_c;
 #pragma unroll
-        for (int k = 0; k < NX; ++k) Fn[k] = Fp[k * NS];
-      }
-      if (col_aff) {
-        load_contig<NS>(a.c + tb * NS, cn);
-        if (has_f && t < T - 1) load_contig<NX>(a.f + tb * NX, fn);
-      }
+      for (int k = 0; k < NX; ++k) Fn[k] = Fp[k * NS];
+      load_contig<NX>(fsafe + tbF * NX, fn);
     };
 
     float V[NX];  // [V | v] columns; lanes NX..NS-1 carry junk that is never broadcast
@@ -206,23 +219,23 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
       }
     };
 
-    // prologue: fill the ring with the last D timesteps
-    static_for<0, D>([&](auto j) {
-      const int t = T - 1 - j.value;
-      if (t >= 0) issue_loads(t, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);
+    // prologue: bank 0 <- the last G timesteps
+    static_for<0, G>([&](auto j) {
+      issue_loads(T - 1 - j.value, Qr[0][j.value], Fr[0][j.value], cr[0][j.value], fr[0][j.value]);
     });
-    int t0 = T - 1;
-    for (; t0 - (D - 1) >= 0; t0 -= D) {  // full groups of D steps
-      static_for<0, D>([&](auto j) {
-        const int t = t0 - j.value;
-        step(t, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);
-        if (t - D >= 0) issue_loads(t - D, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);  // refill
+    for (int t0 = T - 1; t0 >= 0; t0 -= 2 * G) {
+      static_for<0, 2>([&](auto h) {  // half h computes bank h while bank 1-h is being filled
+        constexpr int cur = h.value, nxt = 1 - h.value;
+        const int tb0 = t0 - h.value * G;
+        static_for<0, G>([&](auto j) {
+          issue_loads(tb0 - G - j.value, Qr[nxt][j.value], Fr[nxt][j.value], cr[nxt][j.value], fr[nxt][j.value]);
+        });
+        static_for<0, G>([&](auto j) {
+          const int t = tb0 - j.value;
+          if (t >= 0) step(t, Qr[cur][j.value], Fr[cur][j.value], cr[cur][j.value], fr[cur][j.value]);
+        });
       });
     }
-    static_for<0, D>([&](auto j) {  // the last T % D steps
-      const int t = t0 - j.value;
-      if (t >= 0) step(t, Qr[j.value], Fr[j.value], cr[j.value], fr[j.value]);
-    });
   }
 
   if constexpr (MODE != kBackwardOnly) {
@@ -233,17 +246,24 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
     //     u[m]  = sum_lanes Kcol[m] * xv            (xv: x[j] in lanes < NX, 1 in lane NS, else 0)
     //     x'[i] = f[i] + sum_j F[i][j] x[j] + sum_m F[i][NX+m] u[m]
     if constexpr (MODE == kSolve && !K_LDS) __threadfence_block();
-    constexpr int D = ring_depth(NS + 1 + NU, 112, 8);
+#ifndef DMPC_FWD_BUDGET
+#define DMPC_FWD_BUDGET 56
+#define DMPC_FWD_MAXG 4
+#endif
+    constexpr int G = ring_depth(NS + 1 + NU, DMPC_FWD_BUDGET, DMPC_FWD_MAXG);  // ping-pong banks as in the backward sweep
     const bool row_x = lane < NX;
     const int lane_x = row_x ? lane : NX - 1;  // other lanes re-read the last row (never used)
-    float Fr[D][NS], fr[D], Kr[D][NU];
-    bool cl[D][NU];
+    float Fr[2][G][NS], fr[2][G], Kr[2][G][NU];
+    bool cl[2][G][NU];
+    const float *Fsafe = T > 1 ? a.F : a.x_init;  // T == 1: nothing is read through it that is used
+    const float *fsafe = has_f ? a.f : a.x_init;
     auto issue_row = [&](int t, float (&Fn)[NS], float &fn, float (&Kn)[NU], bool (&cn)[NU]) {
+      t = t < T ? t : T - 1;  // branch-free, see the backward sweep
       const size_t tb = (size_t)t * B + b;
-      if (t < T - 1) {
-        load_contig<NS>(a.F + (tb * NX + lane_x) * NS, Fn);
-        if (has_f) fn = a.f[tb * NX + lane_x];
-      }
+      const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+      const size_t tbF = (size_t)tF * B + b;
+      if (T > 1) load_contig<NS>(Fsafe + (tbF * NX + lane_x) * NS, Fn);
+      fn = fsafe[has_f ? tbF * NX + lane_x : 0];
       if constexpr (MODE == kSolve && K_LDS) {
 #pragma unroll
         for (int m = 0; m < NU; ++m) Kn[m] = kl[(t * NU + m) * KROW + kidx];
@@ -295,21 +315,22 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
         if (row_x) xv = acc;
       }
     };
-    static_for<0, D>([&](auto j) {
-      if (j.value < T) issue_row(j.value, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
+    static_for<0, G>([&](auto j) {
+      issue_row(j.value, Fr[0][j.value], fr[0][j.value], Kr[0][j.value], cl[0][j.value]);
     });
-    int t0 = 0;
-    for (; t0 + D <= T; t0 += D) {
-      static_for<0, D>([&](auto j) {
-        const int t = t0 + j.value;
-        fstep(t, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
-        if (t + D < T) issue_row(t + D, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
+    for (int t0 = 0; t0 < T; t0 += 2 * G) {
+      static_for<0, 2>([&](auto h) {
+        constexpr int cur = h.value, nxt = 1 - h.value;
+        const int tb0 = t0 + h.value * G;
+        static_for<0, G>([&](auto j) {
+          issue_row(tb0 + G + j.value, Fr[nxt][j.value], fr[nxt][j.value], Kr[nxt][j.value], cl[nxt][j.value]);
+        });
+        static_for<0, G>([&](auto j) {
+          const int t = tb0 + j.value;
+          if (t < T) fstep(t, Fr[cur][j.value], fr[cur][j.value], Kr[cur][j.value], cl[cur][j.value]);
+        });
       });
     }
-    static_for<0, D>([&](auto j) {
-      const int t = t0 + j.value;
-      if (t < T) fstep(t, Fr[j.value], fr[j.value], Kr[j.value], cl[j.value]);
-    });
     if (bad) info_bits |= 2;
   }
 
