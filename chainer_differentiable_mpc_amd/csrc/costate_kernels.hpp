@@ -1,0 +1,196 @@
+// costate_kernels.hpp - co-state (lambda, d_lambda) backward sweeps and the outer products of the
+// analytic KKT gradient, one lane group per trajectory.
+//
+// Follows DiffLqr.backward, lqr/differentiable_lqr.py:85-104 (lambda), :114-126 (d_lambda), :128-134
+// (dC, dc, dF, df, d_x_init), and MPCstep.backward, mpc/mpc_step.py:383-446, which is the same
+// computation with the opposite output sign, a symmetric dC and df = -d_lambda[1:].
+//
+// Layout per group of L lanes (colwise.hpp):
+//   lane j < NS : tau_t[j], dtau_t[j]                 (element per lane)
+//   lane i < NX : row i of C_t (contiguous in HBM), c_t[i], column i of F_t[:, :NX], lambda[i], dlambda[i]
+//   lambda_t[i]  = c_t[i] + sum_j C_t[i][j] tau_t[j] + sum_k F_t[k][i] lambda_{t+1}[k]
+//   dC_t row i (lane i < NS), dF_t row k (lane k < NX) are built with broadcast-multiplies and stored as
+//   contiguous rows.
+#pragma once
+#include "colwise.hpp"
+#include "lqr_kernels.hpp"
+
+namespace dmpc {
+
+struct CostateArgs {
+  int T, B;
+  const float *C, *c, *F;
+  const float *x, *u;    // tau   [T,B,nx], [T,B,nu]
+  const float *dx, *du;  // dtau' [T,B,nx], [T,B,nu]  (solution of the second LQR solve)
+  const float *r;        // affine term of the d_lambda recursion, rows of length ns: [T,B,ns]; only [:nx] is read
+  float r_sign;          // d_lambda_t = r_sign * r_t[:nx] + ...      (+1 DiffLqr :115,124; -1 MPCstep :417,420)
+  float out_sign;        // +1 DiffLqr, -1 MPCstep
+  int dC_mode;           // 0: 0.5*dtau(x)tau + tau(x)dtau (differentiable_lqr.py:128); 1: 0.5*(dtau(x)tau + tau(x)dtau)
+  int df_shift;          // 0: df[t] = d_lambda[t] (differentiable_lqr.py:133); 1: df[t] = d_lambda[t+1]
+  float *dx0, *dC, *dc, *dF, *df;  // outputs (dC, dF, df may be nullptr)
+};
+
+template <int N>
+__device__ __forceinline__ void store_contig(float *__restrict__ p, const float (&src)[N]) {
+  if constexpr (N % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i)
+      reinterpret_cast<float4 *>(p)[i] = make_float4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+  } else if constexpr (N % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) reinterpret_cast<float2 *>(p)[i] = make_float2(src[2 * i], src[2 * i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i] = src[i];
+  }
+}
+
+template <int NX, int NU, int L>
+__global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
+  constexpr int NS = NX + NU;
+  static_assert(NS <= L, "tau must fit the lane group");
+  constexpr int GPB = 256 / L;
+  using G = Group<L>;
+
+  const int lane = threadIdx.x % L;
+  const int grp = threadIdx.x / L;
+  int b = blockIdx.x * GPB + grp;
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+
+  const bool is_x = lane < NX;
+  const bool is_tau = lane < NS;
+  const int lane_x = is_x ? lane : NX - 1;    // clamped: rows/columns re-read by the idle lanes, never used
+  const int lane_t = is_tau ? lane : NS - 1;
+  const float wa = 0.5f, wb = a.dC_mode == 0 ? 1.0f : 0.5f;
+
+  float lam = 0.f, dlam = 0.f;  // lambda_{t+1}[lane], d_lambda_{t+1}[lane]  (lanes < NX)
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t tb = (size_t)t * B + b;
+    // tau_t, dtau_t: element per lane
+    const float tau = lane_t < NX ? a.x[tb * NX + lane_t] : a.u[tb * NU + (lane_t - NX)];
+    const float dtau = lane_t < NX ? a.dx[tb * NX + lane_t] : a.du[tb * NU + (lane_t - NX)];
+    float Crow[NS];
+    load_contig<NS>(a.C + (tb * NS + lane_x) * NS, Crow);
+    const float ci = a.c[tb * NS + lane_x];
+    const float ri = a.r[tb * NS + lane_x];
+
+    // ---- dF_t and df (they use lambda_{t+1}, d_lambda_{t+1})             differentiable_lqr.py:130-133
+    if (t < T - 1) {
+      if (a.dF != nullptr) {
+        float row[NS];
+        static_for<0, NS>([&](auto j) {
+          row[j.value] = a.out_sign * fmaf(dlam, G::template bcast<j.value>(tau), lam * G::template bcast<j.value>(dtau));
+        });
+        if (live && is_x) store_contig<NS>(a.dF + (tb * NX + lane) * NS, row);
+      }
+      if (a.df != nullptr && a.df_shift == 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+    }
+    // ---- dC_t, dc_t                                                          :128-129
+    if (a.dC != nullptr) {
+      float row[NS];
+      static_for<0, NS>([&](auto j) {
+        row[j.value] = a.out_sign * fmaf(wa * dtau, G::template bcast<j.value>(tau),
+                                         (wb * tau) * G::template bcast<j.value>(dtau));
+      });
+      if (live && is_tau) store_contig<NS>(a.dC + (tb * NS + lane) * NS, row);
+    }
+    if (a.dc != nullptr && live && is_tau) a.dc[tb * NS + lane] = a.out_sign * dtau;
+
+    // ---- lambda_t, d_lambda_t                                                 :92,102 / :115,124
+    float nl = ci, ndl = a.r_sign * ri;
+    static_for<0, NS>([&](auto j) {
+      nl = fmaf(Crow[j.value], G::template bcast<j.value>(tau), nl);
+      ndl = fmaf(Crow[j.value], G::template bcast<j.value>(dtau), ndl);
+    });
+    if (t < T - 1) {
+      const float *Fp = a.F + tb * NX * NS + lane_x;  // column lane_x of F_t[:, :NX]
+      float Fcol[NX];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Fcol[k] = Fp[k * NS];
+      static_for<0, NX>([&](auto k) {
+        nl = fmaf(Fcol[k.value], G::template bcast<k.value>(lam), nl);
+        ndl = fmaf(Fcol[k.value], G::template bcast<k.value>(dlam), ndl);
+      });
+    }
+    lam = nl;
+    dlam = ndl;
+    if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+  }
+  if (a.dx0 != nullptr && live && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
+}
+
+// Shape dispatch (defined in kkt_api.hip; also used by the MPC-step backward entry point).
+int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream);
+
+// Runtime-dimension version: one wavefront per trajectory, vectors in LDS (completeness path).
+struct CostateDims {
+  int nx, nu;
+};
+
+__global__ __launch_bounds__(64) void costate_generic_kernel(const CostateArgs a, const CostateDims d) {
+  const int nx = d.nx, nu = d.nu, ns = nx + nu;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  extern __shared__ float lds[];
+  float *tau = lds, *dtau = tau + ns, *lam = dtau + ns, *dlam = lam + nx, *nlam = dlam + nx, *ndlam = nlam + nx;
+  const float wa = 0.5f, wb = a.dC_mode == 0 ? 1.0f : 0.5f;
+  for (int i = lane; i < nx; i += 64) { lam[i] = 0.f; dlam[i] = 0.f; }
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t tb = (size_t)t * B + b;
+    for (int j = lane; j < ns; j += 64) {
+      tau[j] = j < nx ? a.x[tb * nx + j] : a.u[tb * nu + (j - nx)];
+      dtau[j] = j < nx ? a.dx[tb * nx + j] : a.du[tb * nu + (j - nx)];
+    }
+    __syncthreads();
+    if (t < T - 1) {
+      if (a.dF != nullptr)
+        for (int e = lane; e < nx * ns; e += 64) {
+          const int k = e / ns, j = e % ns;
+          a.dF[tb * nx * ns + e] = a.out_sign * fmaf(dlam[k], tau[j], lam[k] * dtau[j]);
+        }
+      if (a.df != nullptr && a.df_shift == 1)
+        for (int i = lane; i < nx; i += 64) a.df[tb * nx + i] = a.out_sign * dlam[i];
+    }
+    if (a.dC != nullptr)
+      for (int e = lane; e < ns * ns; e += 64) {
+        const int i = e / ns, j = e % ns;
+        a.dC[tb * ns * ns + e] = a.out_sign * fmaf(wa * dtau[i], tau[j], (wb * tau[i]) * dtau[j]);
+      }
+    if (a.dc != nullptr)
+      for (int j = lane; j < ns; j += 64) a.dc[tb * ns + j] = a.out_sign * dtau[j];
+    for (int i = lane; i < nx; i += 64) {
+      float nl = a.c[tb * ns + i], ndl = a.r_sign * a.r[tb * ns + i];
+      const float *Cr = a.C + (tb * ns + i) * ns;
+      for (int j = 0; j < ns; ++j) {
+        nl = fmaf(Cr[j], tau[j], nl);
+        ndl = fmaf(Cr[j], dtau[j], ndl);
+      }
+      if (t < T - 1) {
+        const float *Fp = a.F + tb * nx * ns + i;
+        for (int k = 0; k < nx; ++k) {
+          nl = fmaf(Fp[k * ns], lam[k], nl);
+          ndl = fmaf(Fp[k * ns], dlam[k], ndl);
+        }
+      }
+      nlam[i] = nl;
+      ndlam[i] = ndl;
+    }
+    __syncthreads();
+    for (int i = lane; i < nx; i += 64) {
+      lam[i] = nlam[i];
+      dlam[i] = ndlam[i];
+      if (a.df != nullptr && a.df_shift == 0 && t < T - 1) a.df[tb * nx + i] = a.out_sign * dlam[i];
+    }
+    __syncthreads();
+  }
+  if (a.dx0 != nullptr)
+    for (int i = lane; i < nx; i += 64) a.dx0[(size_t)b * nx + i] = a.out_sign * dlam[i];
+}
+
+}  // namespace dmpc

@@ -1,0 +1,110 @@
+// kkt_api.hip - analytic KKT gradient of the LQR solution (include/dmpc.h section B).
+// Replaces DiffLqr.backward, lqr/differentiable_lqr.py:78-142:
+//   (1) d_tau  <- LqrRecursion(0, C, [grad_x;grad_u], F, 0).solve_recursion()        (:106-114)
+//   (2) lambda, d_lambda backward sweeps + outer products                             (:85-104, :115-134)
+// Step (1) is the fused solve kernel of lqr_api.hip, step (2) is costate_kernel.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmpc.h"
+#include "api_util.hpp"
+#include "costate_kernels.hpp"
+
+namespace dmpc {
+
+// drl[t][b][:] = [grad_x[t][b][:], grad_u[t][b][:]] ; x0[b][:] = 0
+__global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, int nu, const float *__restrict__ gx,
+                                                         const float *__restrict__ gu, float *__restrict__ drl,
+                                                         float *__restrict__ x0, size_t n_x0) {
+  const int ns = nx + nu;
+  const size_t total = n_rows * ns;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = e / ns;
+    const int j = (int)(e % ns);
+    drl[e] = j < nx ? gx[row * nx + j] : gu[row * nu + (j - nx)];
+  }
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_x0; e += (size_t)gridDim.x * blockDim.x)
+    x0[e] = 0.f;
+}
+
+#define DMPC_COSTATE_SHAPES(X) \
+  X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
+  X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
+
+int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
+#define X(NX_, NU_, L_)                                                                                     \
+  if (nx == NX_ && nu == NU_) {                                                                             \
+    constexpr int GPB = 256 / L_;                                                                           \
+    hipLaunchKernelGGL((costate_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, a); \
+    return (int)hipGetLastError();                                                                          \
+  }
+  DMPC_COSTATE_SHAPES(X)
+#undef X
+  if (nx + nu + 1 > 64) return DMPC_E_UNSUPPORTED;
+  const size_t shmem = (size_t)(2 * (nx + nu) + 4 * nx) * sizeof(float);
+  hipLaunchKernelGGL(costate_generic_kernel, dim3(a.B), dim3(64), shmem, stream, a, CostateDims{nx, nu});
+  return (int)hipGetLastError();
+}
+
+struct KktWs {
+  size_t drl, x0, dx, du, lqr, total;
+};
+static KktWs kkt_layout(int T, int B, int nx, int nu) {
+  const size_t ns = nx + nu;
+  KktWs w;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    const size_t o = off;
+    off += round_up(floats * sizeof(float), 256);
+    return o;
+  };
+  w.drl = take((size_t)T * B * ns);
+  w.x0 = take((size_t)B * nx);
+  w.dx = take((size_t)T * B * nx);
+  w.du = take((size_t)T * B * nu);
+  w.lqr = off;
+  off += round_up(dmpc_lqr_workspace_bytes(T, B, nx, nu), 256);
+  w.total = off;
+  return w;
+}
+
+}  // namespace dmpc
+
+using namespace dmpc;
+
+extern "C" {
+
+size_t dmpc_lqr_kkt_workspace_bytes(int T, int B, int nx, int nu) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
+  return kkt_layout(T, B, nx, nu).total;
+}
+
+int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                      const float *x, const float *u, const float *grad_x, const float *grad_u,
+                      int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws,
+                      size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!C || !c || !F || !x || !u || !grad_x || !grad_u || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
+  if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(dC) || !aligned16(dF)) return DMPC_E_BADARG;
+  const KktWs w = kkt_layout(T, B, nx, nu);
+  if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char *base = static_cast<char *>(ws);
+  float *drl = reinterpret_cast<float *>(base + w.drl);
+  float *x0 = reinterpret_cast<float *>(base + w.x0);
+  float *dx = reinterpret_cast<float *>(base + w.dx);
+  float *du = reinterpret_cast<float *>(base + w.du);
+  const size_t rows = (size_t)T * B;
+  const int blocks = (int)((rows * (nx + nu) + 255) / 256 > 4096 ? 4096 : (rows * (nx + nu) + 255) / 256);
+  hipLaunchKernelGGL(concat_tau_kernel, dim3(blocks), dim3(256), 0, stream, rows, nx, nu, grad_x, grad_u, drl, x0,
+                     (size_t)B * nx);
+  // (1) second LQR solve: x_init = 0, c = drl, f = 0 (a NULL f is the same recursion, lqr_recursion.py:90-96)
+  int rc = dmpc_lqr_solve(T, B, nx, nu, C, drl, F, nullptr, x0, nullptr, nullptr, nullptr, dx, du, base + w.lqr,
+                          w.total - w.lqr, info, stream_);
+  if (rc != 0) return rc;
+  // (2) co-state sweeps and outer products
+  CostateArgs a{T, B, C, c, F, x, u, dx, du, drl, 1.0f, 1.0f, strict_math ? 1 : 0, strict_math ? 1 : 0,
+                d_x_init, dC, dc, dF, df};
+  return launch_costate(nx, nu, a, stream);
+}
+
+}  // extern "C"

@@ -4,12 +4,6 @@
 
 extern "C" {
 
-size_t dmpc_lqr_kkt_workspace_bytes(int, int, int, int) { return 0; }
-int dmpc_lqr_kkt_grad(int, int, int, int, const float *, const float *, const float *, const float *,
-                      const float *, const float *, const float *, int, float *, float *, float *, float *,
-                      float *, void *, size_t, int32_t *, dmpc_stream_t) {
-  return DMPC_E_UNSUPPORTED;
-}
 int dmpc_pnqp(int, int, const float *, const float *, const float *, const float *, const float *, int,
               float *, float *, int32_t *, float *, int32_t *, int32_t *, dmpc_stream_t) {
   return DMPC_E_UNSUPPORTED;

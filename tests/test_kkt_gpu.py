@@ -1,0 +1,123 @@
+"""GPU parity: analytic KKT gradient (DiffLqr.backward, lqr/differentiable_lqr.py:78-142) through the
+C-ABI against the golden vectors recorded from the reference and against the numpy oracle.  Row B."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from chainer_differentiable_mpc_amd import DiffLqr, LqrNet, synthetic
+from chainer_differentiable_mpc_amd.differentiable_lqr import kkt_grad_device
+from chainer_differentiable_mpc_amd.lqr_recursion import solve_device
+from oracle import kkt as okkt
+from oracle import lqr as olqr
+from tests.helpers import GOLDEN, TOL_COSTATE, TOL_PRIMAL, assert_close, npy, to_dev
+
+pytestmark = pytest.mark.gpu
+
+LQR_FILES = sorted(glob.glob(os.path.join(GOLDEN, "lqr_*.npz")))
+KEYS = ("d_x_init", "dC", "dc", "dF", "df")
+TOLS = dict(d_x_init=TOL_COSTATE, dC=TOL_PRIMAL, dc=TOL_PRIMAL, dF=TOL_COSTATE, df=TOL_COSTATE)
+
+
+@pytest.mark.parametrize("path", LQR_FILES, ids=[os.path.basename(p) for p in LQR_FILES])
+def test_kkt_gradient_matches_reference_golden(path):
+    g = np.load(path)
+    B, T, nx, nu = int(g["B"]), int(g["T"]), int(g["nx"]), int(g["nu"])
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=int(g["seed"]), with_f=bool(g["with_f"]))
+    d = to_dev(p)
+    node = DiffLqr(T, B, nx, nu)
+    x, u = node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert_close(npy(x), g["x"], TOL_PRIMAL, "x")
+    gx = torch.as_tensor(g["grad_x"], dtype=torch.float32).cuda()
+    gu = torch.as_tensor(g["grad_u"], dtype=torch.float32).cuda()
+    out = node.backward((0, 1, 2, 3, 4), (gx, gu))
+    for got, key in zip(out, KEYS):
+        assert_close(npy(got), g[key], TOLS[key], key)
+
+
+@pytest.mark.parametrize("shape", [(4, 6, 8, 2), (3, 5, 5, 3), (2, 4, 32, 8)])
+def test_strict_math_variant_against_oracle(shape):
+    B, T, nx, nu = shape
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=12)
+    rng = np.random.RandomState(13)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu, strict_math=True)
+    d = to_dev(p)
+    node = DiffLqr(T, B, nx, nu, strict_math=True)
+    node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for got, want, key in zip(out, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)
+    # the symmetric dC really is symmetric, the faithful one is not
+    dC = npy(out[1])
+    assert np.abs(dC - np.swapaxes(dC, 2, 3)).max() <= 1e-6 * max(1.0, np.abs(dC).max())
+
+
+def test_autograd_through_lqrnet_reproduces_the_notebook_anchor():
+    """examples/LQRnet.ipynb:184 - loss 0.661925 at iteration 0, dynamics mse 4.774785 after the first
+    RMSprop step - with forward AND backward on the HIP path, driven by torch.autograd."""
+    from tests.lqrnet_anchor import problem
+    q = problem()
+    T, nx, nu, B = q["T"], q["nx"], q["nu"], q["B"]
+    dt = torch.float64
+    F_e = torch.as_tensor(np.concatenate((q["A_e"], q["B_e"]), axis=1), dtype=dt).cuda()
+    C = torch.as_tensor(q["C"], dtype=dt).cuda()
+    c = torch.as_tensor(q["c"], dtype=dt).cuda()
+    x0 = torch.as_tensor(q["x_init"], dtype=dt).cuda()
+    net = LqrNet(T, B, nx, nu, seed=2).cuda()
+    np.testing.assert_allclose(net.A.detach().cpu().numpy(), q["A"])      # same draws as the reference
+    expert = DiffLqr(T, B, nx, nu)
+    x_true, u_true = expert.forward((x0, C, c, F_e.expand(T - 1, B, nx, nx + nu), None))
+    x_pred, u_pred = net((x0, C, c, None))
+    loss = ((u_true - u_pred) ** 2).mean() + ((x_true - x_pred) ** 2).mean()
+    assert abs(float(loss) - 0.661925) < 5e-6
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-2, alpha=0.99, eps=1e-8)   # chainer.optimizers.RMSprop defaults
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    A_e = torch.as_tensor(q["A_e"], dtype=dt).cuda()
+    B_e = torch.as_tensor(q["B_e"], dtype=dt).cuda()
+    mse = ((net.A - A_e) ** 2).mean() + ((net.B - B_e) ** 2).mean()
+    assert abs(float(mse) - 4.774785) < 5e-5
+
+
+def test_gradients_flow_to_every_input_and_none_f():
+    B, T, nx, nu = 5, 6, 4, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=31, with_f=True)
+    d = {k: v.clone().requires_grad_(True) for k, v in to_dev(p).items()}
+    node = DiffLqr(T, B, nx, nu)
+    x, u = node.apply((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    w = torch.linspace(-1, 1, x.numel(), device="cuda").reshape(x.shape)
+    ((w * x).sum() + u.sum()).backward()
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, npy(w), np.ones((T, B, nu)), T, nx, nu)
+    for name, want, key in zip(("x_init", "C", "c", "F", "f"), ref, KEYS):
+        assert_close(npy(d[name].grad), want, TOLS[key], name)
+
+
+def test_headline_shape_sampled_oracle_and_linearity():
+    """BASELINE.json configs[2] at full size: oracle on a sample + linearity in the upstream gradient"""
+    B, T, nx, nu = 4096, 50, 8, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=0)
+    d = to_dev(p)
+    x, u, _, _ = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)
+    gx = torch.ones((T, B, nx), device="cuda")
+    gu = torch.ones((T, B, nu), device="cuda")
+    out1 = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu)
+    out1 = [o.clone() for o in out1]
+    out3 = kkt_grad_device(d["C"], d["c"], d["F"], x, u, 3 * gx, 3 * gu, T, nx, nu)
+    for a, b3, key in zip(out1, out3, KEYS):
+        assert torch.isfinite(a).all(), key
+        scale = max(1.0, float(a.abs().max()))
+        assert float((3 * a - b3).abs().max()) <= 2e-4 * 3 * scale, key
+    idx = np.random.RandomState(2).choice(B, 24, replace=False)
+    xr, ur = olqr.lqr_solve(p["x_init"][idx], p["C"][:, idx], p["c"][:, idx], p["F"][:, idx], p["f"][:, idx], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"][idx], p["C"][:, idx], p["c"][:, idx], p["F"][:, idx], xr, ur,
+                                np.ones((T, len(idx), nx)), np.ones((T, len(idx), nu)), T, nx, nu)
+    sel = [npy(out1[0])[idx], npy(out1[1])[:, idx], npy(out1[2])[:, idx], npy(out1[3])[:, idx], npy(out1[4])[:, idx]]
+    for got, want, key in zip(sel, ref, KEYS):
+        assert_close(got, want, TOLS[key], key)
