@@ -13,5 +13,8 @@ from .util import (LinDx, QuadCost, batch_lu_factor, batch_lu_solve, bdot, bger,
                    clamp, expand_batch, expand_time_batch, get_cost, get_traj)
 from .lqr_recursion import LqrRecursion  # noqa: F401
 from .differentiable_lqr import DiffLqr, LqrNet, LqrNet_cost_dx  # noqa: F401
+from .pnqp import PNQP  # noqa: F401
+from .active_constrained_lqr import LQR_active  # noqa: F401
+from .mpc_step import MPCstep, LqrBackOut, LqrForOut  # noqa: F401
 
 __version__ = "0.1.0"

@@ -36,7 +36,9 @@ SIGNATURES = {
     "dmpc_pnqp": (_c_i, [_c_i, _c_i] + [_c_f] * 5 + [_c_i] + [_c_f] * 7),
     "dmpc_mpc_step_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_mpc_step_forward": (_c_i, [_c_i] * 4 + [_c_f] * 12 + [_c_i, ctypes.c_float, _c_i, _c_i]
-                              + [_c_f] * 10 + [_c_f, _c_sz, _c_f, _c_f]),
+                              + [_c_f] * 11 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_mpc_backward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5),
+    "dmpc_mpc_forward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [ctypes.c_float, _c_i] + [_c_f] * 10),
     "dmpc_mpc_step_backward": (_c_i, [_c_i] * 4 + [_c_f] * 9 + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
 }
 

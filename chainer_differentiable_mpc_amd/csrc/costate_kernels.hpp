@@ -13,22 +13,10 @@
 //   contiguous rows.
 #pragma once
 #include "colwise.hpp"
+#include "costate_args.hpp"
 #include "lqr_kernels.hpp"
 
 namespace dmpc {
-
-struct CostateArgs {
-  int T, B;
-  const float *C, *c, *F;
-  const float *x, *u;    // tau   [T,B,nx], [T,B,nu]
-  const float *dx, *du;  // dtau' [T,B,nx], [T,B,nu]  (solution of the second LQR solve)
-  const float *r;        // affine term of the d_lambda recursion, rows of length ns: [T,B,ns]; only [:nx] is read
-  float r_sign;          // d_lambda_t = r_sign * r_t[:nx] + ...      (+1 DiffLqr :115,124; -1 MPCstep :417,420)
-  float out_sign;        // +1 DiffLqr, -1 MPCstep
-  int dC_mode;           // 0: 0.5*dtau(x)tau + tau(x)dtau (differentiable_lqr.py:128); 1: 0.5*(dtau(x)tau + tau(x)dtau)
-  int df_shift;          // 0: df[t] = d_lambda[t] (differentiable_lqr.py:133); 1: df[t] = d_lambda[t+1]
-  float *dx0, *dC, *dc, *dF, *df;  // outputs (dC, dF, df may be nullptr)
-};
 
 template <int N>
 __device__ __forceinline__ void store_contig(float *__restrict__ p, const float (&src)[N]) {
@@ -121,9 +109,6 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   }
   if (a.dx0 != nullptr && live && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
 }
-
-// Shape dispatch (defined in kkt_api.hip; also used by the MPC-step backward entry point).
-int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream);
 
 // Runtime-dimension version: one wavefront per trajectory, vectors in LDS (completeness path).
 struct CostateDims {

@@ -16,7 +16,8 @@ Hazards handled inside each statement (hipcc pads nothing inside asm):
     INPUT of the statement (never written inside it), and the statement opens with `s_nop 1`, which
     covers a producer that hipcc scheduled right in front of it;
   * the statement ends with `s_nop 1` so that a compiler-generated v_mov_b32_dpp reading one of its
-    outputs right behind it is safe as well.
+    outputs right behind it is safe as well;
+  * accumulators are early-clobber ("+&v"): they are written before all inputs have been read.
 Accumulators are interleaved (k outer, i inner) so that no two consecutive FMAs depend on each other.
 
     python chainer_differentiable_mpc_amd/csrc/gen_dpp_blocks.py   # rewrites dpp_blocks_gen.hpp
@@ -40,7 +41,10 @@ def statement(lines, outs, ins):
     """one asm statement; outs/ins: list of (name, c_expr)"""
     assert len(outs) + len(ins) <= MAX_OPERANDS, (len(outs), len(ins))
     body = ['"s_nop 1\\n\\t"'] + lines + ['"s_nop 1"']
-    o = ", ".join('[%s] "+v"(%s)' % (n, e) for n, e in outs)
+    # "+&v": early-clobber.  A block writes its accumulators before it has read every input, so an
+    # accumulator must never share a register with an input - which hipcc would otherwise do whenever it
+    # can prove both hold the same value on entry (e.g. V[i] = Q[i] right before vupd).
+    o = ", ".join('[%s] "+&v"(%s)' % (n, e) for n, e in outs)
     i = ", ".join('[%s] "v"(%s)' % (n, e) for n, e in ins)
     return "    asm(" + "\n        ".join(body) + "\n        : " + o + "\n        : " + i + ");\n"
 

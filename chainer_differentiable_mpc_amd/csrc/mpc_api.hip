@@ -1,0 +1,235 @@
+// mpc_api.hip - C-ABI entry points of the projected-Newton QP and of the MPC step
+// (include/dmpc.h sections C and E).  Replaces PNQP (mpc/pnqp.py:37-201), MPCstep.forward /
+// backward_rec / forward_rec / backward (mpc/mpc_step.py:70-460) of the reference.
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmpc.h"
+#include "api_util.hpp"
+#include "costate_args.hpp"
+#include "mpc_kernels.hpp"
+
+namespace dmpc {
+
+// Standalone PNQP: one lane per QP, everything in registers.
+template <int N>
+__global__ __launch_bounds__(256) void pnqp_kernel(int B, const float *__restrict__ H, const float *__restrict__ q,
+                                                   const float *__restrict__ lower, const float *__restrict__ upper,
+                                                   const float *__restrict__ x_init, int n_iter,
+                                                   float *__restrict__ x_out, float *__restrict__ fac,
+                                                   int32_t *__restrict__ piv, float *__restrict__ index_f,
+                                                   int32_t *__restrict__ n_iter_out, int32_t *info) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float Hm[N][N], qv[N], lo[N], hi[N], x[N];
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+#pragma unroll
+    for (int c = 0; c < N; ++c) Hm[r][c] = H[((size_t)b * N + r) * N + c];
+    qv[r] = q[(size_t)b * N + r];
+    lo[r] = lower[(size_t)b * N + r];
+    hi[r] = upper[(size_t)b * N + r];
+    x[r] = x_init != nullptr ? x_init[(size_t)b * N + r] : 0.f;
+  }
+  PnqpResult<N> res;
+  pnqp_solve<N>(Hm, qv, lo, hi, x, x_init != nullptr, n_iter, res);
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    x_out[(size_t)b * N + r] = x[r];
+    index_f[(size_t)b * N + r] = res.free_[r] ? 1.0f : 0.0f;
+    if (piv != nullptr) piv[(size_t)b * N + r] = res.piv[r];
+#pragma unroll
+    for (int c = 0; c < N; ++c) fac[((size_t)b * N + r) * N + c] = res.fac[r][c];
+  }
+  n_iter_out[b] = res.it;
+  if (info != nullptr && !res.converged) atomicOr(&info[b], DMPC_INFO_QP_ITERCAP);
+}
+
+#define DMPC_MPC_SHAPES(X) \
+  X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
+  X(4, 4, 16) X(8, 4, 16) X(12, 3, 16)
+
+static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a, hipStream_t stream) {
+#define X(NX_, NU_, L_)                                                                                       \
+  if (nx == NX_ && nu == NU_) {                                                                               \
+    constexpr int GPB = 256 / L_;                                                                             \
+    hipLaunchKernelGGL((mpc_backward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
+                       a);                                                                                    \
+    return (int)hipGetLastError();                                                                            \
+  }
+  DMPC_MPC_SHAPES(X)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
+static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a, hipStream_t stream) {
+#define X(NX_, NU_, L_)                                                                                      \
+  if (nx == NX_ && nu == NU_) {                                                                              \
+    constexpr int GPB = 256 / L_;                                                                            \
+    hipLaunchKernelGGL((mpc_forward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
+                       a);                                                                                   \
+    return (int)hipGetLastError();                                                                           \
+  }
+  DMPC_MPC_SHAPES(X)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
+struct MpcWs {
+  size_t c_back, neg, x0, dx, du, mask, lqr, total;
+};
+static MpcWs mpc_layout(int T, int B, int nx, int nu) {
+  const size_t ns = nx + nu;
+  MpcWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += round_up(bytes, 256);
+    return o;
+  };
+  w.c_back = take((size_t)T * B * ns * sizeof(float));  // forward: re-centred c ; backward: unused
+  w.neg = take((size_t)T * B * ns * sizeof(float));     // backward: -[dl_dx;dl_du]
+  w.x0 = take((size_t)B * nx * sizeof(float));
+  w.dx = take((size_t)T * B * nx * sizeof(float));
+  w.du = take((size_t)T * B * nu * sizeof(float));
+  w.mask = take((size_t)T * B * nu);
+  w.lqr = off;
+  off += round_up(dmpc_lqr_workspace_bytes(T, B, nx, nu), 256);
+  w.total = off;
+  return w;
+}
+
+static int grid_for(size_t n) {
+  const size_t blocks = (n + 255) / 256;
+  return (int)(blocks > 8192 ? 8192 : (blocks == 0 ? 1 : blocks));
+}
+
+}  // namespace dmpc
+
+using namespace dmpc;
+
+extern "C" {
+
+int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
+              const float *x_init, int n_iter, float *x, float *fac, int32_t *piv, float *index_f,
+              int32_t *n_iter_out, int32_t *info, dmpc_stream_t stream_) {
+  if (B <= 0 || n <= 0 || n_iter <= 0 || !H || !q || !lower || !upper || !x || !fac || !index_f || !n_iter_out)
+    return DMPC_E_BADARG;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const dim3 block(256), grid((B + 255) / 256);
+  switch (n) {
+#define CASE(N)                                                                                                  \
+  case N:                                                                                                        \
+    hipLaunchKernelGGL((pnqp_kernel<N>), grid, block, 0, stream, B, H, q, lower, upper, x_init, n_iter, x, fac, piv, \
+                       index_f, n_iter_out, info);                                                               \
+    break;
+    CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+    default: return DMPC_E_UNSUPPORTED;
+  }
+  return (int)hipGetLastError();
+}
+
+int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
+                          const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
+                          const float *u_upper, int n_qp_iter_max, float *Ks_out, float *ks_out,
+                          int32_t *n_qp_iter, int32_t *info, dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
+  if (!C_hat || !c_hat || !F_hat || !controls || !u_lower || !u_upper || !Ks_out || !ks_out || !n_qp_iter)
+    return DMPC_E_BADARG;
+  if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(f_hat)) return DMPC_E_BADARG;
+  MpcBackArgs ba{T, B, C_hat, c_hat, F_hat, f_hat, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
+                 n_qp_iter, info};
+  return launch_mpc_back(nx, nu, ba, static_cast<hipStream_t>(stream_));
+}
+
+int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *controls,
+                         const float *states, const float *u_lower, const float *u_upper, const float *C_true,
+                         const float *c_true, const float *F_true, const float *f_true, float ls_decay,
+                         int max_ls_iter, float *x_out, float *u_out, float *costs, float *old_costs,
+                         float *alphas, float *objs, float *u_first, int32_t *n_ls_iter, int32_t *info,
+                         dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!Ks || !ks || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true || !x_out ||
+      !u_out || !costs || !alphas || !n_ls_iter)
+    return DMPC_E_BADARG;
+  if (!aligned16(C_true) || !aligned16(F_true)) return DMPC_E_BADARG;
+  MpcFwdArgs fa{T, B, Ks, ks, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
+                max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info};
+  return launch_mpc_fwd(nx, nu, fa, static_cast<hipStream_t>(stream_));
+}
+
+size_t dmpc_mpc_step_workspace_bytes(int T, int B, int nx, int nu) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
+  return mpc_layout(T, B, nx, nu).total;
+}
+
+int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
+                          const float *F_hat, const float *f_hat, const float *controls, const float *states,
+                          const float *u_lower, const float *u_upper, const float *C_true, const float *c_true,
+                          const float *F_true, const float *f_true, int need_expand, float ls_decay,
+                          int max_ls_iter, int n_qp_iter_max, float *x_out, float *u_out, float *Ks_out,
+                          float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
+                          float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
+                          int32_t *info, dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
+  if (!C_hat || !c_hat || !F_hat || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true ||
+      !x_out || !u_out || !Ks_out || !ks_out || !costs || !alphas || !n_qp_iter || !n_ls_iter || !ws)
+    return DMPC_E_BADARG;
+  if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(f_hat) || !aligned16(C_true) ||
+      !aligned16(F_true))
+    return DMPC_E_BADARG;
+  const MpcWs w = mpc_layout(T, B, nx, nu);
+  if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char *base = static_cast<char *>(ws);
+  const float *c_use = c_hat;
+  const float *f_use = f_hat;
+  if (need_expand) {  // Taylor re-centring: c_hat <- C [x;u] + c, f_hat <- None           mpc_step.py:305-317
+    float *c_back = reinterpret_cast<float *>(base + w.c_back);
+    const size_t rows = (size_t)T * B;
+    hipLaunchKernelGGL(taylor_c_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, C_hat,
+                       c_hat, states, controls, c_back);
+    c_use = c_back;
+    f_use = nullptr;
+  }
+  MpcBackArgs ba{T, B, C_hat, c_use, F_hat, f_use, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
+                 n_qp_iter, info};
+  int rc = launch_mpc_back(nx, nu, ba, stream);
+  if (rc != 0) return rc;
+  MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
+                max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info};
+  return launch_mpc_fwd(nx, nu, fa, stream);
+}
+
+int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
+                           const float *F_hat, const float *x, const float *u, const float *u_lower,
+                           const float *u_upper, const float *grad_x, const float *grad_u, float *d_x_init,
+                           float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
+                           dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!C_hat || !c_hat || !F_hat || !x || !u || !u_lower || !u_upper || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
+  if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(dC) || !aligned16(dF))
+    return DMPC_E_BADARG;
+  const MpcWs w = mpc_layout(T, B, nx, nu);
+  if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char *base = static_cast<char *>(ws);
+  float *neg = reinterpret_cast<float *>(base + w.neg);
+  float *x0 = reinterpret_cast<float *>(base + w.x0);
+  float *dx = reinterpret_cast<float *>(base + w.dx);
+  float *du = reinterpret_cast<float *>(base + w.du);
+  uint8_t *mask = reinterpret_cast<uint8_t *>(base + w.mask);
+  const size_t rows = (size_t)T * B;
+  hipLaunchKernelGGL(active_mask_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, u,
+                     u_lower, u_upper, grad_x, grad_u, mask, neg, x0, (size_t)B * nx);
+  // LQR_active(0, C, -d_tau, F, None, u_zero_Index=active)                               mpc_step.py:374-376
+  int rc = dmpc_lqr_solve(T, B, nx, nu, C_hat, neg, F_hat, nullptr, x0, mask, nullptr, nullptr, dx, du,
+                          base + w.lqr, w.total - w.lqr, info, stream_);
+  if (rc != 0) return rc;
+  // d_lambda_t = C_xx dx + C_xu du - d_tau[:nx] + ...  ->  r = neg, r_sign = +1; outputs negated  :383-446
+  CostateArgs a{T, B, C_hat, c_hat, F_hat, x, u, dx, du, neg, 1.0f, -1.0f, /*dC_mode=*/1, /*df_shift=*/1,
+                d_x_init, dC, dc, dF, df};
+  return launch_costate(nx, nu, a, stream);
+}
+
+}  // extern "C"

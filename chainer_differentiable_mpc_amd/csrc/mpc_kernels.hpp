@@ -1,0 +1,311 @@
+// mpc_kernels.hpp - one box-constrained iLQR step (MPCstep of the reference), one lane group per
+// trajectory, column-per-lane layout of colwise.hpp.
+//
+//   mpc_backward_rec_kernel   MPCstep.backward_rec, mpc/mpc_step.py:70-173: Riccati sweep whose
+//                             feed-forward term k_t is a box QP (PNQP, warm-started from t+1) and whose
+//                             gain rows of clamped controls are zero.
+//   mpc_forward_rec_kernel    MPCstep.forward_rec, mpc/mpc_step.py:175-286: clamped closed-loop rollout
+//                             under the TRUE linear dynamics with a per-trajectory backtracking line
+//                             search on the TRUE quadratic cost.
+//   taylor_c_kernel           the need_expand re-centring c_hat_t = C_t [x_t;u_t] + c_t, :305-317.
+//   active_mask_kernel        active = |u-lo| <= 1e-8 | |u-hi| <= 1e-8 (:363-364) and -[dl_dx;dl_du].
+#pragma once
+#include "colwise.hpp"
+#include "dpp_blocks_gen.hpp"
+#include "lqr_kernels.hpp"
+#include "pnqp_device.hpp"
+#include "riccati_blocks.hpp"
+
+namespace dmpc {
+
+// "Sits on its bound": the reference tests |u - bound| <= 1e-8 in float64 (mpc_step.py:363-364), where a
+// clamped control differs from its bound by at most an ulp (1e-16).  In float32 an ulp at |bound| ~ 1 is
+// 6e-8, so the same test needs a tolerance of a few float32 ulps; controls that close are also snapped
+// onto the bound by the rollout so that `u == bound` holds exactly for callers.
+__device__ __forceinline__ float bound_tol(float bound) { return 1e-8f + 4.0f * 1.1920929e-07f * fmaxf(1.0f, fabsf(bound)); }
+
+struct MpcBackArgs {
+  int T, B;
+  const float *C, *c, *F, *f;           // model (c is already re-centred when need_expand); f may be nullptr
+  const float *controls, *lower, *upper;  // [T,B,nu]
+  int n_qp_iter;                        // PNQP iteration cap (reference: 20, mpc_step.py:142)
+  float *Ks, *ks;                       // [T,B,nu,nx], [T,B,nu]
+  int32_t *n_qp_total;                  // [B]  sum_t (1 + i_t)   (mpc_step.py:145)
+  int32_t *info;
+};
+
+template <int NX, int NU, int L>
+__global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs a) {
+  constexpr int NS = NX + NU;
+  static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
+  constexpr int GPB = 256 / L;
+  using G = Group<L>;
+  using Blk = RiccatiBlocks<NX, NU, L>;
+
+  const int lane = threadIdx.x % L;
+  const int grp = threadIdx.x / L;
+  int b = blockIdx.x * GPB + grp;
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const bool has_f = a.f != nullptr;
+  const bool col_aff = lane == NS;
+  const int lane_c = lane < NS ? lane : NS - 1;
+
+  float V[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) V[i] = 0.f;
+  float kprev[NU];
+#pragma unroll
+  for (int m = 0; m < NU; ++m) kprev[m] = 0.f;
+  int n_total = 0;
+  int info_bits = 0;
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t tb = (size_t)t * B + b;
+    float Q[NS];
+    {
+      const float *Cp = a.C + tb * NS * NS + lane_c;
+      float cn[NS];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) Q[i] = Cp[i * NS];
+      load_contig<NS>(a.c + tb * NS, cn);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) Q[i] = col_aff ? cn[i] : Q[i];
+    }
+    if (t < T - 1) {
+      float Fc[NX];
+      const float *Fp = a.F + tb * NX * NS + lane_c;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Fc[k] = Fp[k * NS];
+      if (has_f) {
+        float fn[NX];
+        load_contig<NX>(a.f + tb * NX, fn);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? fn[k] : Fc[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? 0.f : Fc[k];
+      }
+      float W[NX];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) W[i] = col_aff ? V[i] : 0.f;
+      Blk::vf(W, V, Fc);   // mpc_step.py:110,116
+      Blk::ftw(Q, Fc, W);
+    }
+    // every lane gets Quu and qu                                             :119-124
+    float Quu[NU][NU], qu[NU], lo[NU], hi[NU];
+    static_for<0, NU>([&](auto l) {
+#pragma unroll
+      for (int m = 0; m < NU; ++m) Quu[m][l.value] = G::template bcast<NX + l.value>(Q[NX + m]);
+    });
+#pragma unroll
+    for (int m = 0; m < NU; ++m) {
+      qu[m] = G::template bcast<NS>(Q[NX + m]);
+      const float uc = a.controls[tb * NU + m];
+      lo[m] = a.lower[tb * NU + m] - uc;  // :136-138
+      hi[m] = a.upper[tb * NU + m] - uc;
+    }
+    // k_t: box QP, warm-started from the later timestep                        :141-146
+    PnqpResult<NU> qp;
+    float kt[NU];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) kt[m] = kprev[m];
+    pnqp_solve<NU>(Quu, qu, lo, hi, kt, /*warm=*/t != T - 1, a.n_qp_iter, qp);
+    n_total += 1 + qp.it;
+    if (!qp.converged) info_bits |= 4;
+#pragma unroll
+    for (int m = 0; m < NU; ++m) kprev[m] = kt[m];
+    // K_t = -LU_free^-1 Qux with the rows of clamped controls zeroed            :147-157
+    float Kt[NU];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Kt[m] = qp.free_[m] ? Q[NX + m] : 0.f;
+    if constexpr (NU == 1) {
+      Kt[0] = -((1.0f / qp.fac[0][0]) * Kt[0]);
+    } else {
+      lu_solve_inplace<NU>(qp.fac, qp.piv, Kt);
+#pragma unroll
+      for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
+    }
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Kt[m] = col_aff ? kt[m] : Kt[m];  // affine column carries k_t
+    if (live) {
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        if (col_aff) a.ks[tb * NU + m] = Kt[m];
+        else if (lane < NX) a.Ks[(tb * NU + m) * NX + lane] = Kt[m];
+      }
+    }
+    if (t > 0) {  // V, v from the UNMASKED blocks                                :165-166
+      float R[NU];
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        R[m] = Q[NX + m];
+#pragma unroll
+        for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) V[i] = Q[i];
+      Blk::vupd(V, Q, Kt, R);
+    }
+  }
+  if (live && lane == 0) {
+    a.n_qp_total[b] = n_total;
+    if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+  }
+}
+
+struct MpcFwdArgs {
+  int T, B;
+  const float *Ks, *ks;                  // gains from backward_rec
+  const float *controls, *states;        // current iterate  [T,B,nu], [T,B,nx]
+  const float *lower, *upper;            // absolute control bounds [T,B,nu]
+  const float *C, *c, *F, *f;            // TRUE QuadCost / LinDx (f may be nullptr)
+  float ls_decay;
+  int max_ls_iter;                       // only guards the first pass in the reference (:196), kept for the record
+  int ls_cap;                            // safety cap on line-search passes (the reference loop is unbounded)
+  float *x, *u;                          // new trajectory
+  float *u_first;                        // controls of the first (alpha = 1) pass, or nullptr      (:260-263)
+  float *costs, *old_costs, *alphas;     // [B]
+  float *objs;                           // [T,B] per-step cost of the accepted pass, or nullptr
+  int32_t *n_ls;                         // [B] passes run
+  int32_t *info;
+};
+
+template <int NX, int NU, int L>
+__global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a) {
+  constexpr int NS = NX + NU;
+  static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
+  constexpr int GPB = 256 / L;
+  using G = Group<L>;
+
+  const int lane = threadIdx.x % L;
+  const int grp = threadIdx.x / L;
+  int b = blockIdx.x * GPB + grp;
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const bool has_f = a.f != nullptr;
+  const bool is_x = lane < NX;
+  const bool is_tau = lane < NS;
+  const bool col_aff = lane == NS;
+  const bool k_lane = is_x || col_aff;
+  const int lane_x = is_x ? lane : NX - 1;
+  const int lane_t = is_tau ? lane : NS - 1;
+
+  // cost of a trajectory under the true QuadCost: sum_t 1/2 tau'C tau + c'tau           util.py:162-198
+  auto step_cost = [&](size_t tb, float tau) {
+    float Crow[NS];
+    load_contig<NS>(a.C + (tb * NS + lane_t) * NS, Crow);
+    float qi = 0.f;
+    static_for<0, NS>([&](auto j) { qi = fmaf(Crow[j.value], G::template bcast<j.value>(tau), qi); });
+    const float ci = a.c[tb * NS + lane_t];
+    return group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, ci) : 0.f);
+  };
+
+  float old_cost = 0.f;
+  for (int t = 0; t < T; ++t) {  // OLD_COST of (states, controls)                      mpc_step.py:191
+    const size_t tb = (size_t)t * B + b;
+    const float tau = lane_t < NX ? a.states[tb * NX + lane_t] : a.controls[tb * NU + (lane_t - NX)];
+    old_cost += step_cost(tb, tau);
+  }
+
+  float alpha = 1.0f;
+  float cost = 0.f;
+  int n_pass = 0;
+  bool worse = true;
+  while (worse && n_pass < a.ls_cap) {  // :196 - until this trajectory is not worse than before
+    float xh = is_x ? a.states[(size_t)b * NX + lane] : 0.f;  // new_x[0] = states[0]     :198
+    cost = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const size_t tb = (size_t)t * B + b;
+      const float xt = is_x ? a.states[tb * NX + lane] : 0.f;
+      const float z = is_x ? (xh - xt) : (col_aff ? alpha : 0.f);  // [dx ; alpha] against [K_t | k_t]
+      float un[NU];
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        const float *kp = col_aff ? (a.ks + tb * NU + m) : (a.Ks + (tb * NU + m) * NX + lane_x);
+        const float kv = *kp;
+        const float uc = a.controls[tb * NU + m];
+        float v = group_sum<L>(k_lane ? kv * z : 0.f) + uc;                           // :209-219
+        const float lb = a.lower[tb * NU + m], ub = a.upper[tb * NU + m];
+        v = fminf(fmaxf(v, lb), ub);                                                  // :221
+        v = (v - lb <= bound_tol(lb)) ? lb : v;
+        un[m] = (ub - v <= bound_tol(ub)) ? ub : v;
+      }
+      float tau = xh;  // [new_x_t ; new_u_t], element per lane
+#pragma unroll
+      for (int m = 0; m < NU; ++m) tau = (lane == NX + m) ? un[m] : tau;
+      const float obj = step_cost(tb, tau);                                          // :246-251
+      cost += obj;
+      if (live) {  // outputs are overwritten by later passes; the last one is the accepted one
+        if (is_x) a.x[tb * NX + lane] = xh;
+        else if (lane < NS) a.u[tb * NU + (lane - NX)] = tau;
+        if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
+        if (a.u_first != nullptr && n_pass == 0 && lane >= NX && lane < NS) a.u_first[tb * NU + (lane - NX)] = tau;
+      }
+      if (t < T - 1) {  // new_x_{t+1} = F_t [new_x;new_u] + f_t under the TRUE dynamics   :229-236
+        float Frow[NS];
+        load_contig<NS>(a.F + (tb * NX + lane_x) * NS, Frow);
+        float acc = has_f ? a.f[tb * NX + lane_x] : 0.f;
+        static_for<0, NS>([&](auto j) { acc = fmaf(Frow[j.value], G::template bcast<j.value>(tau), acc); });
+        xh = is_x ? acc : 0.f;
+      }
+    }
+    ++n_pass;
+    worse = cost > old_cost;             // :266
+    if (worse) alpha *= a.ls_decay;      // :268
+  }
+  int info_bits = 0;
+  if (worse) {                           // cap hit: the reference would still be looping; :274
+    alpha /= a.ls_decay;
+    info_bits |= 8;
+  }
+  if (!is_finite(cost)) info_bits |= 2;
+  if (live && lane == 0) {
+    a.costs[b] = cost;
+    if (a.old_costs != nullptr) a.old_costs[b] = old_cost;
+    a.alphas[b] = alpha;
+    a.n_ls[b] = n_pass;
+    if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+  }
+}
+
+// c_back[t][b][i] = sum_j C[t][b][i][j] tau[t][b][j] + c[t][b][i]        (mpc_step.py:305-317), one lane per (t,b,i)
+__global__ __launch_bounds__(256) void taylor_c_kernel(size_t n_rows, int nx, int nu, const float *__restrict__ C,
+                                                       const float *__restrict__ c, const float *__restrict__ states,
+                                                       const float *__restrict__ controls, float *__restrict__ out) {
+  const int ns = nx + nu;
+  const size_t total = n_rows * ns;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const size_t row = e / ns;  // (t, b)
+    const float *Cr = C + e * ns;
+    float acc = c[e];
+    for (int j = 0; j < nx; ++j) acc = fmaf(Cr[j], states[row * nx + j], acc);
+    for (int j = 0; j < nu; ++j) acc = fmaf(Cr[nx + j], controls[row * nu + j], acc);
+    out[e] = acc;
+  }
+}
+
+// active[t][b][m] = |u-lo| <= 1e-8 | |u-hi| <= 1e-8 (mpc_step.py:363-364);  neg[t][b][:] = -[gx;gu] (:374)
+__global__ __launch_bounds__(256) void active_mask_kernel(size_t n_rows, int nx, int nu, const float *__restrict__ u,
+                                                          const float *__restrict__ lo, const float *__restrict__ hi,
+                                                          const float *__restrict__ gx, const float *__restrict__ gu,
+                                                          uint8_t *__restrict__ active, float *__restrict__ neg,
+                                                          float *__restrict__ x0, size_t n_x0) {
+  const int ns = nx + nu;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t e = tid; e < n_rows * nu; e += stride)
+    active[e] = (fabsf(u[e] - lo[e]) <= bound_tol(lo[e])) || (fabsf(u[e] - hi[e]) <= bound_tol(hi[e]));
+  for (size_t e = tid; e < n_rows * ns; e += stride) {
+    const size_t row = e / ns;
+    const int j = (int)(e % ns);
+    const float v = j < nx ? (gx ? gx[row * nx + j] : 0.f) : (gu ? gu[row * nu + (j - nx)] : 0.f);
+    neg[e] = -v;
+  }
+  for (size_t e = tid; e < n_x0; e += stride) x0[e] = 0.f;
+}
+
+}  // namespace dmpc

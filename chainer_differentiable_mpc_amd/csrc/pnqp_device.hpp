@@ -1,0 +1,158 @@
+// pnqp_device.hpp - projected-Newton box QP in registers (device function).
+//
+//     min 1/2 x'Hx + q'x   s.t.  lo <= x <= hi            (Tassa, Mansard, Todorov 2014, Alg. 1)
+//
+// Follows PNQP, mpc/pnqp.py:37-201 of the reference, with PER-ROW termination: the reference tests
+// convergence and the Armijo condition over the whole batch (pnqp.py:139-144, 172, 187), which makes a
+// row's result depend on its batch-mates; a fused per-trajectory kernel cannot (and should not) do that,
+// so this is the reference called with a batch of one - the semantics pinned by the per-row golden
+// vectors (tests/golden/pnqp_n*.npz, *_row_* keys) and by oracle.pnqp(batch_coupled=False).
+//
+// Everything is float32 (the reference computes in float64 but rounds every solve to float32,
+// util.py:522-527).  The routine is executed redundantly by every lane that needs the result - inside
+// the MPC-step kernel all lanes of a trajectory's group run it on identical data.
+#pragma once
+#include "colwise.hpp"
+
+namespace dmpc {
+
+constexpr float kPnqpGamma = 0.1f;   // pnqp.py:23
+constexpr float kPnqpDecay = 0.1f;   // pnqp.py:163
+constexpr float kPnqpDxTol = 1e-4f;  // pnqp.py:140
+constexpr float kPnqpReg = 1e-11f;   // pnqp.py:73
+constexpr int kPnqpMaxLs = 10;       // pnqp.py:172
+
+template <int N>
+struct PnqpResult {
+  float fac[N][N];  // LU of the last free-set Hessian H_f (N == 1: H_f itself)      pnqp.py:144,201
+  int piv[N];       // LAPACK 1-based pivots of that factorisation
+  bool free_[N];    // Index_f
+  int it;           // the reference's returned `i`
+  bool converged;
+};
+
+template <int N>
+__device__ __forceinline__ float pnqp_obj(const float (&H)[N][N], const float (&q)[N], const float (&x)[N]) {
+  float quad = 0.f, lin = 0.f;  // 0.5 * x'Hx + q'x   (pnqp.py:26-33)
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    float hx = 0.f;
+#pragma unroll
+    for (int c = 0; c < N; ++c) hx = fmaf(H[r][c], x[c], hx);
+    quad = fmaf(x[r], hx, quad);
+    lin = fmaf(q[r], x[r], lin);
+  }
+  return fmaf(0.5f, quad, lin);
+}
+
+// x: in = warm start (if warm) ; out = solution.
+template <int N>
+__device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (&q)[N], const float (&lo)[N],
+                                           const float (&hi)[N], float (&x)[N], bool warm, int n_iter,
+                                           PnqpResult<N> &res) {
+  if (!warm) {  // x_init = -H^-1 q                                                   pnqp.py:75-83
+    if constexpr (N == 1) {
+      x[0] = -(1.0f / H[0][0]) * q[0];
+    } else {
+      float A[N][N];
+      int piv[N];
+#pragma unroll
+      for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int c = 0; c < N; ++c) A[r][c] = H[r][c];
+      lu_factor_inplace<N>(A, piv);
+#pragma unroll
+      for (int r = 0; r < N; ++r) x[r] = q[r];
+      lu_solve_inplace<N>(A, piv, x);
+#pragma unroll
+      for (int r = 0; r < N; ++r) x[r] = -x[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < N; ++r) x[r] = fminf(fmaxf(x[r], lo[r]), hi[r]);  // :93
+  res.converged = false;
+  res.it = n_iter - 1;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    res.free_[r] = true;
+    res.piv[r] = r + 1;
+#pragma unroll
+    for (int c = 0; c < N; ++c) res.fac[r][c] = 0.f;
+  }
+  for (int i = 0; i < n_iter; ++i) {
+    float g[N], gf[N], dx[N];
+    bool clampd[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {  // grad = Hx + q                                    :98
+      float acc = q[r];
+#pragma unroll
+      for (int c = 0; c < N; ++c) acc = fmaf(H[r][c], x[c], acc);
+      g[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {  // exact float equality, as the reference           :110
+      clampd[r] = ((x[r] == lo[r]) && (g[r] > 0.f)) || ((x[r] == hi[r]) && (g[r] < 0.f));
+      gf[r] = clampd[r] ? 0.f : g[r];
+      res.free_[r] = !clampd[r];
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {  // H_f = H on free x free, 0 elsewhere, + 1e-11 I     :124-129
+        float v = (clampd[r] || clampd[c]) ? 0.f : H[r][c];
+        if (r == c) v += kPnqpReg;
+        res.fac[r][c] = v;
+      }
+    if constexpr (N == 1) {
+      dx[0] = -(1.0f / res.fac[0][0]) * gf[0];  // :134
+    } else {
+      lu_factor_inplace<N>(res.fac, res.piv);  // :136
+#pragma unroll
+      for (int r = 0; r < N; ++r) dx[r] = gf[r];
+      lu_solve_inplace<N>(res.fac, res.piv, dx);
+#pragma unroll
+      for (int r = 0; r < N; ++r) dx[r] = -dx[r];
+    }
+    float n2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < N; ++r) n2 = fmaf(dx[r], dx[r], n2);
+    if (!(sqrtf(n2) >= kPnqpDxTol)) {  // :139-144 (a NaN norm counts as converged there too)
+      res.it = i;
+      res.converged = true;
+      return;
+    }
+    // backtracking line search                                                         :162-190
+    // lhs = (J(x) - J(xh)) / (g'(x - xh)).  J is quadratic, so with d = xh - x this is exactly
+    // 1 + 0.5 * d'Hd / g'd; evaluating it that way avoids the float32 cancellation in J(x) - J(xh) that
+    // otherwise makes the Armijo test random near the optimum (the reference evaluates it in float64).
+    float alpha = 1.0f;
+    float xh[N];
+    int count = 0;
+    bool again;
+    do {
+      float d[N];
+      float gd = 0.f, dHd = 0.f;
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        xh[r] = fminf(fmaxf(fmaf(alpha, dx[r], x[r]), lo[r]), hi[r]);  // :173
+        d[r] = xh[r] - x[r];
+        gd = fmaf(g[r], d[r], gd);
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        float hd = 0.f;
+#pragma unroll
+        for (int c = 0; c < N; ++c) hd = fmaf(H[r][c], d[c], hd);
+        dHd = fmaf(d[r], hd, dHd);
+      }
+      const float lhs = 1.0f + 0.5f * dHd / gd;             // :175-176
+      again = lhs <= kPnqpGamma;                            // false for NaN, like numpy's max(nan) <= GAMMA
+      if (again) alpha *= kPnqpDecay;                       // :185-186
+      ++count;
+    } while (again && count < kPnqpMaxLs);                  // :172
+#pragma unroll
+    for (int r = 0; r < N; ++r) x[r] = xh[r];               // :190
+  }
+}
+
+}  // namespace dmpc

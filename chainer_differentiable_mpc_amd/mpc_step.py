@@ -1,0 +1,342 @@
+"""`MPCstep` - one differentiable box-constrained iLQR step with the constructor, methods and
+attributes of mpc/mpc_step.py:33-460 of the reference (chainer FunctionNode -> torch.autograd).
+
+  forward   = Taylor re-centring (need_expand) + backward_rec (Riccati sweep with one projected-Newton
+              box QP per timestep) + forward_rec (clamped rollout and line search on the TRUE cost)
+  backward  = active-set LQR on -[dl_dx;dl_du] + co-state sweeps + outer products
+
+All of it runs in hand-written HIP kernels when the true cost is a `QuadCost` and the true dynamics
+a `LinDx`.  A callable true cost / dynamics (e.g. the pendulum) keeps backward_rec on the GPU kernel
+and rolls the line search out with torch ops around the callable.
+
+Differences from the reference, by design:
+  * PNQP and the line search terminate per trajectory (the reference's batch-global tests make a
+    trajectory's result depend on its batch-mates);
+  * `LqrBackOut.n_total_qp_iter` is the largest per-trajectory total (per-trajectory values in
+    `self.n_qp_iter`);
+  * `full_du_norm` / `alpha_du_norm` reproduce the reference's reshape of a [T,nu,B] array to
+    [B, T*nu] (mpc_step.py:261-263) unless `strict_math=True` (then true per-trajectory norms).
+"""
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+from .lqr_recursion import _as_tensor, _device_of, _workspace, raise_info
+from .util import LinDx, QuadCost, bdot, bmv, bquad, clamp, get_cost
+
+LqrBackOut = namedtuple("lqrBackOut", "n_total_qp_iter")
+LqrForOut = namedtuple("lqrForOut", "objs full_du_norm alpha_du_norm mean_alphas costs")
+
+
+def du_norm(u_old, u_new, scrambled=True):
+    du = u_old - u_new
+    T, B, nu = du.shape
+    if scrambled:   # mpc_step.py:261-263: transpose to [T,nu,B] then reshape to [B, T*nu]
+        du = du.permute(0, 2, 1).reshape(B, T * nu)
+    else:
+        du = du.permute(1, 0, 2).reshape(B, T * nu)
+    return torch.sqrt((du ** 2).sum(dim=1))
+
+
+class _MPCstepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_init, C, c, F, f, node):
+        x, u = node._forward_impl(x_init, C, c, F, f)
+        ctx.node = node
+        ctx.in_meta = [(t.dtype, t.device, tuple(t.shape)) if t is not None else None for t in (x_init, C, c, F, f)]
+        return x, u
+
+    @staticmethod
+    def backward(ctx, dl_dx, dl_du):
+        grads = ctx.node.backward((0, 1, 2, 3, 4), (dl_dx, dl_du))
+        out = []
+        for g, meta in zip(grads, ctx.in_meta):
+            if meta is None or g is None:
+                out.append(None)
+                continue
+            dtype, device, shape = meta
+            g = g.to(device=device, dtype=dtype)
+            if tuple(g.shape) != shape:
+                pad = torch.zeros(shape, dtype=dtype, device=device)
+                pad[: g.shape[0]] = g
+                g = pad
+            out.append(g)
+        return tuple(out) + (None,)
+
+
+class MPCstep:
+    """MPC forward backward calculation (mpc/mpc_step.py:33)."""
+
+    def __init__(self, controls, T, u_upper, u_lower, n_batch, n_state, n_ctrl, current_states,
+                 true_cost, true_dynamics, ls_decay, max_ls_iter, verbose=False, need_expand=False,
+                 no_op_forward=False, strict_math=False, n_qp_iter=20):
+        self.controls = _as_tensor(controls)
+        self.u_upper = _as_tensor(u_upper)
+        self.u_lower = _as_tensor(u_lower)
+        self.n_state, self.n_ctrl = int(n_state), int(n_ctrl)
+        self.n_sc = self.n_state + self.n_ctrl
+        self.n_batch, self.T = int(n_batch), int(T)
+        self.verbose = verbose
+        self.back_out = None
+        self.for_out = None
+        self.current_states = _as_tensor(current_states)
+        self.true_cost = true_cost
+        self.true_dynamics = true_dynamics
+        self.need_expand = need_expand
+        self.ls_decay = float(ls_decay)
+        self.max_ls_iter = int(max_ls_iter)
+        self.no_op_forward = no_op_forward
+        self.strict_math = strict_math
+        self.n_qp_iter_max = int(n_qp_iter)
+        self.n_qp_iter = None     # per-trajectory sum_t (1 + i_t)
+        self.n_ls_iter = None     # per-trajectory line-search passes
+        self.alphas = None
+        self.info = None
+        self._retained = None
+        self._dev = _device_of(self.controls, self.current_states)
+        self._out_dtype = self.controls.dtype if self.controls.dtype.is_floating_point else torch.float32
+        self._out_device = self.controls.device
+        d = self._dev
+        self._u = _lib.f32c(self.controls.detach(), d)
+        self._xs = _lib.f32c(self.current_states.detach(), d)
+        self._lo = _lib.f32c(self.u_lower, d)
+        self._hi = _lib.f32c(self.u_upper, d)
+        T_, B_, nu_, nx_ = self.T, self.n_batch, self.n_ctrl, self.n_state
+        assert list(self._u.shape) == [T_, B_, nu_] and list(self._xs.shape) == [T_, B_, nx_]
+        assert list(self._lo.shape) == [T_, B_, nu_] and list(self._hi.shape) == [T_, B_, nu_]
+
+    def _out(self, t):
+        return t.to(device=self._out_device, dtype=self._out_dtype)
+
+    def _fused_ok(self):
+        return isinstance(self.true_cost, QuadCost) and isinstance(self.true_dynamics, LinDx)
+
+    # ------------------------------------------------------------------ E2
+    def backward_rec(self, C_hat, c_hat, F_hat, f_hat):
+        """-> (Ks [T,B,nu,nx], ks [T,B,nu], LqrBackOut)   mpc_step.py:70-173"""
+        lib = _lib.load()
+        _lib.require_gpu()
+        T, B, nx, nu, ns = self.T, self.n_batch, self.n_state, self.n_ctrl, self.n_sc
+        d = self._dev
+        C, c, F, f = (_lib.f32c(_as_tensor(t), d) for t in (C_hat, c_hat, F_hat, f_hat))
+        assert list(C.shape) == [T, B, ns, ns], "C hat dim mismatch"
+        assert list(c.shape) == [T, B, ns], "c hat dim mismatch"
+        assert F.shape[0] in (T - 1, T) and list(F.shape[1:]) == [B, nx, ns], "F_hat dim mismatch"
+        assert not bool(torch.isnan(self._u).any())
+        assert bool((self._lo <= self._hi).all()), " lower is larger than upper"
+        Ks = torch.empty((T, B, nu, nx), dtype=torch.float32, device=d)
+        ks = torch.empty((T, B, nu), dtype=torch.float32, device=d)
+        nqp = torch.empty((B,), dtype=torch.int32, device=d)
+        info = torch.zeros(B, dtype=torch.int32, device=d)
+        with torch.cuda.device(d):
+            rc = lib.dmpc_mpc_backward_rec(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f),
+                                           _lib.ptr(self._u), _lib.ptr(self._lo), _lib.ptr(self._hi),
+                                           self.n_qp_iter_max, _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(nqp),
+                                           _lib.ptr(info), _lib.stream_ptr(d))
+        _lib.check(rc, "dmpc_mpc_backward_rec")
+        self.n_qp_iter = nqp
+        self.info = info
+        assert not bool(torch.isnan(ks).any()) and not bool(torch.isnan(Ks).any())     # mpc_step.py:161-162
+        return self._out(Ks), self._out(ks), LqrBackOut(n_total_qp_iter=int(nqp.max().item()))
+
+    # ------------------------------------------------------------------ E3
+    def forward_rec(self, Ks, ks, true_cost, true_dynamics, ls_decay, max_ls_iter):
+        """-> (new_x, new_u, LqrForOut)   mpc_step.py:175-286"""
+        T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
+        d = self._dev
+        Kd = _lib.f32c(_as_tensor(Ks), d)
+        kd = _lib.f32c(_as_tensor(ks), d)
+        assert len(Kd) == T, "Ks length error"
+        if isinstance(true_cost, QuadCost) and isinstance(true_dynamics, LinDx):
+            lib = _lib.load()
+            Ct, ct = _lib.f32c(_as_tensor(true_cost.C), d), _lib.f32c(_as_tensor(true_cost.c), d)
+            Ft, ft = _lib.f32c(_as_tensor(true_dynamics.F), d), _lib.f32c(_as_tensor(true_dynamics.f), d)
+            f32 = dict(dtype=torch.float32, device=d)
+            x = torch.empty((T, B, nx), **f32)
+            u = torch.empty((T, B, nu), **f32)
+            u1 = torch.empty((T, B, nu), **f32)
+            costs = torch.empty((B,), **f32)
+            old = torch.empty((B,), **f32)
+            alphas = torch.empty((B,), **f32)
+            objs = torch.empty((T, B), **f32)
+            nls = torch.empty((B,), dtype=torch.int32, device=d)
+            info = torch.zeros(B, dtype=torch.int32, device=d)
+            with torch.cuda.device(d):
+                rc = lib.dmpc_mpc_forward_rec(T, B, nx, nu, _lib.ptr(Kd), _lib.ptr(kd), _lib.ptr(self._u),
+                                              _lib.ptr(self._xs), _lib.ptr(self._lo), _lib.ptr(self._hi),
+                                              _lib.ptr(Ct), _lib.ptr(ct), _lib.ptr(Ft), _lib.ptr(ft),
+                                              float(ls_decay), int(max_ls_iter), _lib.ptr(x), _lib.ptr(u),
+                                              _lib.ptr(costs), _lib.ptr(old), _lib.ptr(alphas), _lib.ptr(objs),
+                                              _lib.ptr(u1), _lib.ptr(nls), _lib.ptr(info), _lib.stream_ptr(d))
+            _lib.check(rc, "dmpc_mpc_forward_rec")
+            raise_info(info, "MPCstep.forward_rec")                                   # mpc_step.py:284-285
+        else:
+            x, u, u1, costs, alphas, objs, nls = self._forward_rec_callable(Kd, kd, true_cost, true_dynamics,
+                                                                            ls_decay, max_ls_iter)
+        self.alphas, self.n_ls_iter = alphas, nls
+        scr = not self.strict_math
+        res = LqrForOut(self._out(objs), self._out(du_norm(self._u, u1, scr)), self._out(du_norm(self._u, u, scr)),
+                        float(alphas.mean().item()), self._out(costs))
+        return self._out(x), self._out(u), res
+
+    def _forward_rec_callable(self, Ks, ks, true_cost, true_dynamics, ls_decay, max_ls_iter, cap=64):
+        """Line search around a callable cost / dynamics (mpc_step.py:237-240, 252-253): gains come from the
+        HIP kernel, the rollout is torch ops on the device, termination is per trajectory."""
+        T, B = self.T, self.n_batch
+        u0, xs, lo, hi = self._u, self._xs, self._lo, self._hi
+
+        def cost_of(x, u):
+            if isinstance(true_cost, QuadCost):
+                return get_cost(T, u, QuadCost(_lib.f32c(_as_tensor(true_cost.C), self._dev),
+                                               _lib.f32c(_as_tensor(true_cost.c), self._dev)), x=x), None
+            tau = torch.cat((x, u), dim=2)
+            per = torch.stack([true_cost(tau[t]) for t in range(T)], dim=0)
+            return per.sum(dim=0), per
+
+        old, _ = cost_of(xs, u0)
+        alphas = torch.ones(B, dtype=torch.float32, device=self._dev)
+        active = torch.ones(B, dtype=torch.bool, device=self._dev)
+        nls = torch.zeros(B, dtype=torch.int32, device=self._dev)
+        best = None
+        u_first = None
+        for it in range(cap):
+            new_x = [xs[0]]
+            new_u = []
+            for t in range(T):
+                dxt = new_x[t] - xs[t]
+                ut = bmv(Ks[t], dxt) + u0[t] + alphas[:, None] * ks[t]
+                ut = torch.minimum(torch.maximum(ut, lo[t]), hi[t])
+                # float32: snap controls within a few ulps of a bound onto it (see bound_tol in mpc_kernels.hpp)
+                tol_lo = 1e-8 + 4 * 1.1920929e-07 * torch.clamp(lo[t].abs(), min=1.0)
+                tol_hi = 1e-8 + 4 * 1.1920929e-07 * torch.clamp(hi[t].abs(), min=1.0)
+                ut = torch.where(ut - lo[t] <= tol_lo, lo[t], ut)
+                ut = torch.where(hi[t] - ut <= tol_hi, hi[t], ut)
+                new_u.append(ut)
+                if t < T - 1:
+                    if isinstance(true_dynamics, LinDx):
+                        Fd = _lib.f32c(_as_tensor(true_dynamics.F), self._dev)
+                        nxt = bmv(Fd[t], torch.cat((new_x[t], ut), dim=1))
+                        if true_dynamics.f is not None:
+                            nxt = nxt + _lib.f32c(_as_tensor(true_dynamics.f), self._dev)[t]
+                    else:
+                        nxt = true_dynamics(new_x[t], ut)
+                    assert not bool(torch.isnan(nxt).any())
+                    new_x.append(nxt)
+            X, U = torch.stack(new_x), torch.stack(new_u)
+            cost, per = cost_of(X, U)
+            if per is None:
+                tau = torch.cat((X, U), dim=2)
+                C_ = _lib.f32c(_as_tensor(true_cost.C), self._dev)
+                c_ = _lib.f32c(_as_tensor(true_cost.c), self._dev)
+                per = 0.5 * torch.einsum("tbi,tbij,tbj->tb", tau, C_, tau) + (tau * c_).sum(dim=2)
+            if best is None:
+                best = [X.clone(), U.clone(), cost.clone(), per.clone()]
+                u_first = U.clone()
+            else:   # only trajectories still searching take the new pass
+                m = active
+                best[0][:, m], best[1][:, m], best[2][m], best[3][:, m] = X[:, m], U[:, m], cost[m], per[:, m]
+            nls += active.to(torch.int32)
+            worse = (cost > old) & active
+            alphas = torch.where(worse, alphas * ls_decay, alphas)
+            active = worse
+            if not bool(active.any()):
+                break
+        return best[0], best[1], u_first, best[2], alphas, best[3], nls
+
+    # ------------------------------------------------------------------ E4
+    def _forward_impl(self, x_init, C_hat, c_hat, F_hat, f_hat):
+        d = self._dev
+        C, c, F, f = (_lib.f32c(None if t is None else _as_tensor(t).detach(), d) for t in (C_hat, c_hat, F_hat, f_hat))
+        x0 = _lib.f32c(_as_tensor(x_init).detach(), d)
+        self._retained = dict(x_init=x0, C=C, c=c, F=F, f=f)
+        if self.no_op_forward:                                                  # mpc_step.py:297-299
+            self._retained.update(x=self._xs, u=self._u)
+            return self._out(self._xs), self._out(self._u)
+        T, B, nx, nu, ns = self.T, self.n_batch, self.n_state, self.n_ctrl, self.n_sc
+        if self._fused_ok():
+            lib = _lib.load()
+            Ct, ct = _lib.f32c(_as_tensor(self.true_cost.C), d), _lib.f32c(_as_tensor(self.true_cost.c), d)
+            Ft, ft = _lib.f32c(_as_tensor(self.true_dynamics.F), d), _lib.f32c(_as_tensor(self.true_dynamics.f), d)
+            f32 = dict(dtype=torch.float32, device=d)
+            x, u, u1 = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32), torch.empty((T, B, nu), **f32)
+            Ks, ks = torch.empty((T, B, nu, nx), **f32), torch.empty((T, B, nu), **f32)
+            costs, old, alphas = torch.empty((B,), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
+            objs = torch.empty((T, B), **f32)
+            nqp = torch.empty((B,), dtype=torch.int32, device=d)
+            nls = torch.empty((B,), dtype=torch.int32, device=d)
+            info = torch.zeros(B, dtype=torch.int32, device=d)
+            need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
+            ws = _workspace(need, d)
+            with torch.cuda.device(d):
+                rc = lib.dmpc_mpc_step_forward(
+                    T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(self._u),
+                    _lib.ptr(self._xs), _lib.ptr(self._lo), _lib.ptr(self._hi), _lib.ptr(Ct), _lib.ptr(ct),
+                    _lib.ptr(Ft), _lib.ptr(ft), 1 if self.need_expand else 0, self.ls_decay, self.max_ls_iter,
+                    self.n_qp_iter_max, _lib.ptr(x), _lib.ptr(u), _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(costs),
+                    _lib.ptr(old), _lib.ptr(alphas), _lib.ptr(objs), _lib.ptr(u1), _lib.ptr(nqp), _lib.ptr(nls),
+                    _lib.ptr(ws), need, _lib.ptr(info), _lib.stream_ptr(d))
+            _lib.check(rc, "dmpc_mpc_step_forward")
+            raise_info(info, "MPCstep.forward")                                 # the reference asserts on NaN
+            self.info, self.n_qp_iter, self.n_ls_iter, self.alphas = info, nqp, nls, alphas
+            self.Ks, self.ks = Ks, ks
+            scr = not self.strict_math
+            self.back_out = LqrBackOut(n_total_qp_iter=int(nqp.max().item()))
+            self.for_out = LqrForOut(self._out(objs), self._out(du_norm(self._u, u1, scr)),
+                                     self._out(du_norm(self._u, u, scr)), float(alphas.mean().item()),
+                                     self._out(costs))
+        else:
+            if self.need_expand:                                                 # mpc_step.py:305-317
+                tau = torch.cat((self._xs, self._u), dim=2)
+                c = (torch.einsum("tbij,tbj->tbi", C, tau) + c).contiguous()
+                f = None
+            Ks, ks, self.back_out = self.backward_rec(C, c, F, f)
+            x, u, self.for_out = self.forward_rec(Ks, ks, self.true_cost, self.true_dynamics, self.ls_decay,
+                                                  self.max_ls_iter)
+            x, u = _lib.f32c(x, d), _lib.f32c(u, d)
+        assert not bool(torch.isnan(u).any())
+        self._retained.update(x=x, u=u)
+        return self._out(x), self._out(u)
+
+    def forward(self, inputs):
+        """inputs = (x_init, C_hat, c_hat, F_hat, f_hat) -> (x, u)   mpc_step.py:288-328"""
+        return self._forward_impl(*inputs)
+
+    def apply(self, inputs):
+        x_init, C, c, F, f = (_as_tensor(t) for t in inputs)
+        return _MPCstepFn.apply(x_init, C, c, F, f, self)
+
+    __call__ = apply
+
+    # ------------------------------------------------------------------ E5
+    def backward(self, target_input_indexes, grad_outputs):
+        """-> (dx_init, dC, dc, dF, df|None)   mpc_step.py:330-460"""
+        r = self._retained
+        assert r is not None, "backward() before forward()"
+        lib = _lib.load()
+        T, B, nx, nu, ns = self.T, self.n_batch, self.n_state, self.n_ctrl, self.n_sc
+        d = self._dev
+        dl_dx, dl_du = grad_outputs
+        gx = None if dl_dx is None else _lib.f32c(_as_tensor(dl_dx), d)
+        gu = None if dl_du is None else _lib.f32c(_as_tensor(dl_du), d)
+        if gx is not None:
+            assert list(gx.shape) == [T, B, nx]
+        if gu is not None:
+            assert list(gu.shape) == [T, B, nu]
+        f32 = dict(dtype=torch.float32, device=d)
+        dx0 = torch.empty((B, nx), **f32)
+        dC = torch.empty((T, B, ns, ns), **f32)
+        dc = torch.empty((T, B, ns), **f32)
+        dF = torch.zeros(tuple(r["F"].shape), **f32)                              # zeros_like(F_hat), :428
+        df = torch.empty((T - 1, B, nx), **f32) if r["f"] is not None else None   # :437-444
+        info = torch.zeros(B, dtype=torch.int32, device=d)
+        need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
+        ws = _workspace(need, d)
+        with torch.cuda.device(d):
+            rc = lib.dmpc_mpc_step_backward(T, B, nx, nu, _lib.ptr(r["C"]), _lib.ptr(r["c"]), _lib.ptr(r["F"]),
+                                            _lib.ptr(r["x"]), _lib.ptr(r["u"]), _lib.ptr(self._lo), _lib.ptr(self._hi),
+                                            _lib.ptr(gx), _lib.ptr(gu), _lib.ptr(dx0), _lib.ptr(dC), _lib.ptr(dc),
+                                            _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need, _lib.ptr(info),
+                                            _lib.stream_ptr(d))
+        _lib.check(rc, "dmpc_mpc_step_backward")
+        return tuple(None if g is None else self._out(g) for g in (dx0, dC, dc, dF, df))

@@ -106,8 +106,9 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
  *   C_hat/c_hat/F_hat/f_hat the quadratic/linear model; C_true/c_true/F_true/f_true the true
  *   QuadCost / LinDx (may alias the model);  f_hat, f_true may be NULL.
  *   outputs: x_out [T,B,nx], u_out [T,B,nu], Ks_out/ks_out (NULL ok), costs [B], old_costs [B]
- *   (NULL ok), alphas [B], objs [T,B] (NULL ok), n_qp_iter [B] int32 = sum_t (1 + i_t),
- *   n_ls_iter [B] int32.                                                                      */
+ *   (NULL ok), alphas [B], objs [T,B] (NULL ok), u_first [T,B,nu] (NULL ok) = the controls of the first
+ *   (alpha = 1) line-search pass, from which the reference derives full_du_norm (mpc_step.py:260-263),
+ *   n_qp_iter [B] int32 = sum_t (1 + i_t), n_ls_iter [B] int32 = line-search passes run.          */
 size_t dmpc_mpc_step_workspace_bytes(int T, int B, int nx, int nu);
 int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
                           const float *F_hat, const float *f_hat, const float *controls, const float *states,
@@ -115,8 +116,22 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_true, const float *f_true, int need_expand, float ls_decay,
                           int max_ls_iter, int n_qp_iter_max, float *x_out, float *u_out, float *Ks_out,
                           float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
-                          int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes, int32_t *info,
-                          dmpc_stream_t stream);
+                          float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
+                          int32_t *info, dmpc_stream_t stream);
+
+/* The two halves of forward(), separately callable like the reference's methods:
+ * backward_rec (mpc_step.py:70-173): c_hat must already be re-centred when need_expand applies;
+ * forward_rec (mpc_step.py:175-286): gains in, line-searched trajectory out. */
+int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
+                          const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
+                          const float *u_upper, int n_qp_iter_max, float *Ks_out, float *ks_out,
+                          int32_t *n_qp_iter, int32_t *info, dmpc_stream_t stream);
+int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *controls,
+                         const float *states, const float *u_lower, const float *u_upper, const float *C_true,
+                         const float *c_true, const float *F_true, const float *f_true, float ls_decay,
+                         int max_ls_iter, float *x_out, float *u_out, float *costs, float *old_costs,
+                         float *alphas, float *objs, float *u_first, int32_t *n_ls_iter, int32_t *info,
+                         dmpc_stream_t stream);
 
 /* backward(): active-set LQR on (-d_tau) + co-state sweeps + outer products (mpc_step.py:330-460).
  *   outputs carry the reference's signs: dC = -1/2(dtau'(x)tau + tau(x)dtau'), dc = -dtau',

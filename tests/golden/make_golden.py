@@ -187,6 +187,27 @@ def gen_mpc(ref):
                                                        T, nx, nu, u_zero_Index=active)
             adx, adu = la.solve_recursion()
             fo = step.for_out
+            # the same step with every trajectory as a batch of one: removes the reference's batch-global
+            # PNQP termination (pnqp.py:139-144,172,187) - the semantics of the fused GPU kernels
+            rows = {k: [] for k in ("x", "u", "costs", "d_x_init", "dC", "dc", "dF", "df", "n_qp")}
+            for b in range(B):
+                sl = slice(b, b + 1)
+                st = ref.mpc_step.MPCstep(u_nom[:, sl], T, hi[:, sl], lo[:, sl], 1, nx, nu, x_nom[:, sl],
+                                          U.QuadCost(p["C"][:, sl], p["c"][:, sl]), U.LinDx(p["F"][:, sl], p["f"][:, sl]),
+                                          ls_decay=0.2, max_ls_iter=5, need_expand=need_expand)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    xb, ub = st.apply((x_nom[0, sl], p["C"][:, sl], p["c"][:, sl], p["F"][:, sl], p["f"][:, sl]))
+                gb = st.backward((0, 1, 2, 3, 4), (gx[:, sl], gu[:, sl]))
+                rows["x"].append(arr(xb)); rows["u"].append(arr(ub)); rows["costs"].append(st.for_out.costs)
+                rows["n_qp"].append(st.back_out.n_total_qp_iter)
+                for key, val in zip(("d_x_init", "dC", "dc", "dF", "df"), gb):
+                    rows[key].append(arr(val))
+            row = dict(row_x=np.concatenate(rows["x"], axis=1), row_u=np.concatenate(rows["u"], axis=1),
+                       row_costs=np.concatenate(rows["costs"]), row_n_qp=np.array(rows["n_qp"]),
+                       row_d_x_init=np.concatenate(rows["d_x_init"], axis=0), row_dC=np.concatenate(rows["dC"], axis=1),
+                       row_dc=np.concatenate(rows["dc"], axis=1), row_dF=np.concatenate(rows["dF"], axis=1),
+                       row_df=np.concatenate(rows["df"], axis=1))
             name = "mpc_%d_%d_%d_%d_%s.npz" % (B, T, nx, nu, "exp" if need_expand else "noexp")
             np.savez_compressed(
                 os.path.join(HERE, name), B=B, T=T, nx=nx, nu=nu, seed=seed, bound=bound,
@@ -195,7 +216,7 @@ def gen_mpc(ref):
                 objs=fo.objs, full_du_norm=fo.full_du_norm, alpha_du_norm=fo.alpha_du_norm,
                 mean_alphas=fo.mean_alphas, costs=fo.costs, active=active,
                 d_x_init=arr(dx0), dC=arr(dC), dc=arr(dc), dF=arr(dF), df=arr(df),
-                active_dx=adx, active_du=adu)
+                active_dx=adx, active_du=adu, **row)
             print("wrote", name, "sat=%.2f" % active.mean(), "qp_it", step.back_out.n_total_qp_iter,
                   "mean_alpha", fo.mean_alphas)
 
@@ -258,4 +279,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "mpc":
+        gen_mpc(load_reference.load())
+    else:
+        main()

@@ -1,0 +1,199 @@
+"""GPU parity: MPCstep forward (backward_rec + forward_rec) and backward, LQR_active - through the C-ABI,
+against golden vectors recorded from the reference and against the numpy oracle.  Rows E, F."""
+import glob
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from chainer_differentiable_mpc_amd import LQR_active, LinDx, MPCstep, QuadCost, synthetic
+from oracle import mpc as ompc
+from tests.helpers import GOLDEN, assert_close, npy
+
+pytestmark = pytest.mark.gpu
+
+MPC_FILES = sorted(glob.glob(os.path.join(GOLDEN, "mpc_*.npz")))
+TOL = 2e-4      # float32 solves inside both implementations (util.py:522-527)
+
+
+def dev(a):
+    return None if a is None else torch.as_tensor(a, dtype=torch.float32, device="cuda")
+
+
+def setup(g):
+    B, T, nx, nu = int(g["B"]), int(g["T"]), int(g["nx"]), int(g["nu"])
+    bound = float(g["bound"])
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=int(g["seed"]), with_f=True)
+    lo = -bound * np.ones((T, B, nu))
+    hi = bound * np.ones((T, B, nu))
+    return B, T, nx, nu, p, lo, hi
+
+
+def make_step(g, p, lo, hi, B, T, nx, nu, **kw):
+    return MPCstep(dev(g["u_nom"]), T, dev(hi), dev(lo), B, nx, nu, dev(g["x_nom"]),
+                   QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5,
+                   need_expand=bool(g["need_expand"]), **kw)
+
+
+def coupling_spread(g, key):
+    """how far the reference's own batched run is from its per-trajectory runs (its batch-global PNQP
+    termination, pnqp.py:139-144,172,187) - the GPU path is per-trajectory"""
+    a, b = g[key], g["row_" + key]
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a))))
+
+
+@pytest.mark.parametrize("path", MPC_FILES, ids=[os.path.basename(p) for p in MPC_FILES])
+def test_forward_matches_reference_golden(path):
+    g = np.load(path)
+    B, T, nx, nu, p, lo, hi = setup(g)
+    step = make_step(g, p, lo, hi, B, T, nx, nu)
+    x, u = step.forward((dev(g["x_nom"][0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    # (1) the reference run one trajectory at a time: the semantics of the fused kernels
+    assert_close(npy(u), g["row_u"], TOL, "u vs per-trajectory reference")
+    assert_close(npy(x), g["row_x"], TOL, "x vs per-trajectory reference")
+    assert_close(npy(step.for_out.costs), g["row_costs"], TOL, "costs vs per-trajectory reference")
+    # (2) the reference run on the whole batch: equal up to its own batch-coupling spread
+    assert_close(npy(u), g["u"], TOL + 2 * coupling_spread(g, "u"), "u")
+    assert_close(npy(x), g["x"], TOL + 2 * coupling_spread(g, "x"), "x")
+    fo = step.for_out
+    assert_close(npy(fo.costs), g["costs"], TOL + 2 * coupling_spread(g, "costs"), "costs")
+    assert_close(npy(fo.objs), g["objs"], 5 * TOL, "objs")
+    assert_close(npy(fo.full_du_norm), g["full_du_norm"], 5 * TOL, "full_du_norm")       # scrambled reshape quirk
+    assert_close(npy(fo.alpha_du_norm), g["alpha_du_norm"], 5 * TOL, "alpha_du_norm")
+    assert abs(fo.mean_alphas - float(g["mean_alphas"])) <= 1e-6
+    # the same controls sit on their bounds - exactly on them
+    un = npy(u)
+    active = (un == lo) | (un == hi)
+    np.testing.assert_array_equal(active, g["active"])
+    assert int(step.n_qp_iter.max()) <= int(g["n_total_qp_iter"])   # a trajectory never needs more than the coupled batch
+    np.testing.assert_array_equal(step.n_qp_iter.cpu().numpy(), g["row_n_qp"])
+
+
+@pytest.mark.parametrize("path", MPC_FILES, ids=[os.path.basename(p) for p in MPC_FILES])
+def test_backward_matches_reference_golden(path):
+    g = np.load(path)
+    B, T, nx, nu, p, lo, hi = setup(g)
+    step = make_step(g, p, lo, hi, B, T, nx, nu)
+    step.forward((dev(g["x_nom"][0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    out = step.backward((0, 1, 2, 3, 4), (dev(g["grad_x"]), dev(g["grad_u"])))
+    for got, key in zip(out, ("d_x_init", "dC", "dc", "dF", "df")):
+        assert_close(npy(got), g["row_" + key], 5e-4, key + " vs per-trajectory reference")
+        assert_close(npy(got), g[key], 5e-4 + 2 * coupling_spread(g, key), key)
+
+
+@pytest.mark.parametrize("path", MPC_FILES[::2], ids=[os.path.basename(p) for p in MPC_FILES[::2]])
+def test_backward_rec_and_forward_rec_against_per_trajectory_oracle(path):
+    g = np.load(path)
+    B, T, nx, nu, p, lo, hi = setup(g)
+    c_hat, f_hat = p["c"], p["f"]
+    if bool(g["need_expand"]):
+        tau = np.concatenate((g["x_nom"], g["u_nom"]), axis=2)
+        c_hat = np.einsum("tbij,tbj->tbi", p["C"], tau) + p["c"]
+        f_hat = None
+    Ksr, ksr, bo, Ifree = ompc.mpc_backward_rec(p["C"], c_hat, p["F"], f_hat, g["u_nom"], lo, hi, T, nx, nu,
+                                                batch_coupled=False)
+    step = make_step(g, p, lo, hi, B, T, nx, nu)
+    Ks, ks, back_out = step.backward_rec(dev(p["C"]), dev(c_hat), dev(p["F"]), dev(f_hat))
+    assert_close(npy(ks), ksr, TOL, "ks")
+    assert_close(npy(Ks), Ksr, TOL, "Ks")
+    clamped = Ifree == 0
+    assert np.all(npy(Ks)[clamped] == 0)             # gain rows of clamped controls are exactly zero
+    xr, ur, fo, alphas, n_it = ompc.mpc_forward_rec(Ksr, ksr, g["u_nom"], g["x_nom"], lo, hi, ompc.QuadCost(p["C"], p["c"]),
+                                                    ompc.LinDx(p["F"], p["f"]), 0.2, 5, T)
+    x, u, for_out = step.forward_rec(Ks, ks, step.true_cost, step.true_dynamics, 0.2, 5)
+    assert_close(npy(x), xr, TOL, "x")
+    assert_close(npy(u), ur, TOL, "u")
+    assert_close(npy(step.alphas), alphas, 1e-6, "alphas")
+    assert_close(npy(for_out.costs), fo.costs, TOL, "costs")
+
+
+@pytest.mark.parametrize("path", MPC_FILES[1::3], ids=[os.path.basename(p) for p in MPC_FILES[1::3]])
+def test_lqr_active_class_golden(path):
+    g = np.load(path)
+    B, T, nx, nu, p, lo, hi = setup(g)
+    la = LQR_active(torch.zeros(B, nx).cuda(), dev(p["C"]), -dev(np.concatenate((g["grad_x"], g["grad_u"]), axis=2)),
+                    dev(p["F"]), None, T, nx, nu, u_zero_Index=torch.as_tensor(g["active"]).cuda())
+    dx, du = la.solve_recursion()
+    assert_close(npy(dx), g["active_dx"], 5e-4, "dx")
+    assert_close(npy(du), g["active_du"], 5e-4, "du")
+
+
+def test_callable_dynamics_and_cost_line_search():
+    """non-linear true dynamics + callable cost: gains from the kernel, rollout in torch (mpc_step.py:237-253)"""
+    B, T, nx, nu = 6, 7, 3, 1
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=41)
+    rng = np.random.RandomState(42)
+    u_nom = np.clip(0.3 * rng.randn(T, B, nu), -0.5, 0.5).astype(np.float32).astype(np.float64)
+    lo, hi = -0.5 * np.ones((T, B, nu)), 0.5 * np.ones((T, B, nu))
+
+    def dyn_np(x, u):
+        return np.stack((x[:, 0] + 0.1 * np.sin(x[:, 1]), x[:, 1] + 0.1 * x[:, 2], 0.9 * x[:, 2] + 0.2 * u[:, 0]), axis=1)
+
+    def dyn_t(x, u):
+        return torch.stack((x[:, 0] + 0.1 * torch.sin(x[:, 1]), x[:, 1] + 0.1 * x[:, 2], 0.9 * x[:, 2] + 0.2 * u[:, 0]), dim=1)
+
+    def cost_np(tau):
+        return 0.5 * (tau ** 2).sum(axis=1) + 0.1 * tau[:, 0]
+
+    def cost_t(tau):
+        return 0.5 * (tau ** 2).sum(dim=1) + 0.1 * tau[:, 0]
+
+    xs = [p["x_init"]]
+    for t in range(T - 1):
+        xs.append(dyn_np(xs[t], u_nom[t]))
+    x_nom = np.stack(xs)
+    Ksr, ksr, _, _ = ompc.mpc_backward_rec(p["C"], p["c"], p["F"], p["f"], u_nom, lo, hi, T, nx, nu, batch_coupled=False)
+    xr, ur, fo, alphas, _ = ompc.mpc_forward_rec(Ksr, ksr, u_nom, x_nom, lo, hi, cost_np, dyn_np, 0.2, 5, T)
+    step = MPCstep(dev(u_nom), T, dev(hi), dev(lo), B, nx, nu, dev(x_nom), cost_t, dyn_t, ls_decay=0.2, max_ls_iter=5)
+    x, u = step.forward((dev(x_nom[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    assert_close(npy(u), ur, TOL, "u")
+    assert_close(npy(x), xr, TOL, "x")
+    assert_close(npy(step.for_out.costs), fo.costs, TOL, "costs")
+
+
+def test_autograd_through_mpc_step_and_no_op_forward():
+    g = np.load(MPC_FILES[2])
+    B, T, nx, nu, p, lo, hi = setup(g)
+    C = dev(p["C"]).requires_grad_(True)
+    c = dev(p["c"]).requires_grad_(True)
+    step = make_step(g, p, lo, hi, B, T, nx, nu)
+    x, u = step.apply((dev(g["x_nom"][0]), C, c, dev(p["F"]), dev(p["f"])))
+    (x * dev(g["grad_x"])).sum().add((u * dev(g["grad_u"])).sum()).backward()
+    assert_close(npy(C.grad), g["dC"], 5e-4, "dC")
+    assert_close(npy(c.grad), g["dc"], 5e-4, "dc")
+    # no_op_forward returns the iterate it was given and still differentiates (box_ddp.py:247-259)
+    xd, ud = x.detach(), u.detach()
+    noop = MPCstep(ud, T, dev(hi), dev(lo), B, nx, nu, xd, step.true_cost, step.true_dynamics, 0.2, 5,
+                   need_expand=True, no_op_forward=True)
+    x2, u2 = noop.forward((xd[0], dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    assert torch.equal(x2, xd) and torch.equal(u2, ud)
+    out = noop.backward((0, 1, 2, 3, 4), (dev(g["grad_x"]), dev(g["grad_u"])))
+    assert_close(npy(out[1]), g["dC"], 5e-4, "dC via no-op node")
+
+
+def test_headline_shape_properties():
+    """B=4096, T=50, nx=8, nu=2 with bounds: feasibility, descent, dynamics consistency"""
+    B, T, nx, nu = 4096, 50, 8, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=0)
+    d = {k: dev(v) for k, v in p.items()}
+    u0 = torch.zeros((T, B, nu), device="cuda")
+    xs = [d["x_init"]]
+    for t in range(T - 1):
+        xs.append(torch.einsum("bij,bj->bi", d["F"][t], torch.cat((xs[t], u0[t]), dim=1)) + d["f"][t])
+    x0 = torch.stack(xs)
+    lo = torch.full((T, B, nu), -0.5, device="cuda")
+    hi = torch.full((T, B, nu), 0.5, device="cuda")
+    step = MPCstep(u0, T, hi, lo, B, nx, nu, x0, QuadCost(d["C"], d["c"]), LinDx(d["F"], d["f"]), 0.2, 5, need_expand=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, u = step.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert bool(((u >= lo) & (u <= hi)).all())
+    tau = torch.cat((x, u), dim=2)
+    nxt = torch.einsum("tbij,tbj->tbi", d["F"], tau[:-1]) + d["f"]
+    assert float((nxt - x[1:]).abs().max()) <= 1e-3 * max(1.0, float(x.abs().max()))
+    old = 0.5 * torch.einsum("tbi,tbij,tbj->b", torch.cat((x0, u0), 2), d["C"], torch.cat((x0, u0), 2)) + \
+        (torch.cat((x0, u0), 2) * d["c"]).sum(dim=(0, 2))
+    assert bool((step.for_out.costs <= old * (1 + 1e-5) + 1e-3).all())        # the line search never accepts a worse cost
+    assert float((u == lo).float().mean() + (u == hi).float().mean()) > 0.05  # the box is active somewhere

@@ -219,3 +219,24 @@ def test_mpc_step_golden(path):
                            g["grad_x"], g["grad_u"], T, nx, nu)
     for got, key in zip(out, ("d_x_init", "dC", "dc", "dF", "df")):
         np.testing.assert_allclose(got, g[key], rtol=1e-4, atol=1e-5, err_msg=key)
+
+
+@pytest.mark.parametrize("path", MPC_FILES, ids=[os.path.basename(p) for p in MPC_FILES])
+def test_mpc_step_per_trajectory_golden(path):
+    """oracle(batch_coupled=False) == the reference run one trajectory at a time (row_* keys)"""
+    g = np.load(path)
+    B, T, nx, nu = int(g["B"]), int(g["T"]), int(g["nx"]), int(g["nu"])
+    bound = float(g["bound"])
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=int(g["seed"]), with_f=True)
+    lo = -bound * np.ones((T, B, nu))
+    hi = bound * np.ones((T, B, nu))
+    x, u, back_out, for_out, Ks, ks = mpc.mpc_forward(
+        p["C"], p["c"], p["F"], p["f"], g["u_nom"], g["x_nom"], lo, hi, mpc.QuadCost(p["C"], p["c"]),
+        mpc.LinDx(p["F"], p["f"]), 0.2, 5, T, nx, nu, need_expand=bool(g["need_expand"]), batch_coupled=False)
+    np.testing.assert_allclose(u, g["row_u"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(x, g["row_x"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(for_out.costs, g["row_costs"], rtol=1e-5)
+    out = mpc.mpc_backward(g["x_nom"][0], p["C"], p["c"], p["F"], p["f"], g["row_x"], g["row_u"], lo, hi,
+                           g["grad_x"], g["grad_u"], T, nx, nu)
+    for got, key in zip(out, ("d_x_init", "dC", "dc", "dF", "df")):
+        np.testing.assert_allclose(got, g["row_" + key], rtol=1e-4, atol=1e-5, err_msg=key)
