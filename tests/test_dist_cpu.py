@@ -1,0 +1,65 @@
+"""CPU, world_size 2, gloo: the batch-sharding path (shard -> independent local solves -> all-gather).
+The local solver here is the numpy oracle (test infrastructure) - on the GPU box the same helpers wrap
+the HIP kernels (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chainer_differentiable_mpc_amd import synthetic
+from chainer_differentiable_mpc_amd.dist import all_gather_batch, all_reduce_param_grad, shard_bounds, shard_problem
+from oracle import lqr as olqr
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def worker(rank, world, port, B, T, nx, nu, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=3)
+    full = [torch.as_tensor(p[k]) for k in ("x_init", "C", "c", "F", "f")]
+    x0, C, c, F, f = shard_problem(*full)
+    b0, b1 = shard_bounds(B, rank, world)
+    assert C.shape[1] == b1 - b0 and x0.shape[0] == b1 - b0
+    x, u = olqr.lqr_solve(x0.numpy(), C.numpy(), c.numpy(), F.numpy(), f.numpy(), T, nx, nu)
+    gx = all_gather_batch(torch.as_tensor(x), B)
+    gu = all_gather_batch(torch.as_tensor(u), B)
+    # a parameter-shaped reduction: sum_{t,b} of something per-sample
+    g = torch.as_tensor(x).sum(dim=(0, 1))
+    all_reduce_param_grad(g)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gathered.npz"), x=gx.numpy(), u=gu.numpy(), g=g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 7])          # even and ragged split
+def test_shard_solve_gather_world2(tmp_path, B):
+    T, nx, nu = 5, 4, 2
+    port = free_port()
+    mp.spawn(worker, args=(2, port, B, T, nx, nu, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), "gathered.npz"))
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=3)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    np.testing.assert_allclose(got["x"], xr, rtol=0, atol=1e-12)    # sharding changes nothing
+    np.testing.assert_allclose(got["u"], ur, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(got["g"], xr.sum(axis=(0, 1)), rtol=1e-12, atol=1e-12)
+
+
+def test_shard_bounds_partition_the_batch():
+    for B in (1, 5, 8, 4096, 65536):
+        for world in (1, 2, 3, 8):
+            edges = [shard_bounds(B, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == B
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
