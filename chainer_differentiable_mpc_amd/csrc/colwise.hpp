@@ -130,6 +130,88 @@ __device__ __forceinline__ void lu_solve_inplace(const float (&LU)[N][N], const 
   }
 }
 
+// Reciprocal to within ~1 ulp: v_rcp_f32 (1 ulp) + one Newton step.  The in-kernel solves multiply by the
+// stored reciprocal pivots instead of dividing (LAPACK getf2 scales by the reciprocal pivot as well); an
+// IEEE division costs ~10 VALU issue slots, this costs 3.
+__device__ __forceinline__ float fast_rcp(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+
+// LU as lu_factor_inplace, additionally returning the reciprocal pivots for lu_solve_rinv.
+template <int N>
+__device__ __forceinline__ bool lu_factor_rinv(float (&A)[N][N], int (&piv)[N], float (&rinv)[N]) {
+  bool singular = false;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    float best = fabsf(A[k][k]);
+    int p = k;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const float v = fabsf(A[i][k]);
+      const bool gt = v > best;
+      best = gt ? v : best;
+      p = gt ? i : p;
+    }
+    piv[k] = p + 1;
+    if constexpr (N > 1) {
+#pragma unroll
+      for (int c = 0; c < N; ++c) {
+        const float ak = A[k][c];
+        float nk = ak;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+          const bool s = (p == i);
+          nk = s ? A[i][c] : nk;
+          A[i][c] = s ? ak : A[i][c];
+        }
+        A[k][c] = nk;
+      }
+    }
+    const float d = A[k][k];
+    singular = singular || (d == 0.0f);
+    const float r = fast_rcp(d);
+    rinv[k] = r;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const float l = A[i][k] * r;
+      A[i][k] = l;
+#pragma unroll
+      for (int c = k + 1; c < N; ++c) A[i][c] = fmaf(-l, A[k][c], A[i][c]);
+    }
+  }
+  return singular;
+}
+
+template <int N>
+__device__ __forceinline__ void lu_solve_rinv(const float (&LU)[N][N], const int (&piv)[N], const float (&rinv)[N],
+                                              float (&x)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const int p = piv[k] - 1;
+    const float xk = x[k];
+    float nk = xk;
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) {
+      const bool s = (p == i);
+      nk = s ? x[i] : nk;
+      x[i] = s ? xk : x[i];
+    }
+    x[k] = nk;
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+#pragma unroll
+    for (int i = k + 1; i < N; ++i) x[i] = fmaf(-LU[i][k], x[k], x[i]);
+  }
+#pragma unroll
+  for (int k = N - 1; k >= 0; --k) {
+    x[k] = x[k] * rinv[k];
+#pragma unroll
+    for (int i = 0; i < k; ++i) x[i] = fmaf(-LU[i][k], x[k], x[i]);
+  }
+}
+
 // Sum of v over the lanes of a group, result in every lane of the group.
 template <int L>
 __device__ __forceinline__ float group_sum(float v);

@@ -37,10 +37,15 @@ def fmac(acc, a, b, lane):
         acc, a, b, lane)
 
 
-def statement(lines, outs, ins):
-    """one asm statement; outs/ins: list of (name, c_expr)"""
+def statement(lines, outs, ins, tail_nop=True):
+    """one asm statement; outs/ins: list of (name, c_expr).  tail_nop: the outputs may be read through DPP
+    by compiler-generated code right behind the statement (true only for ftw: Q feeds the Quu broadcast);
+    the other blocks' outputs are next consumed by another block, which opens with its own s_nop 1."""
     assert len(outs) + len(ins) <= MAX_OPERANDS, (len(outs), len(ins))
-    body = ['"s_nop 1\\n\\t"'] + lines + ['"s_nop 1"']
+    lines = list(lines)
+    if not tail_nop:
+        lines[-1] = lines[-1].replace('\\n\\t"', '"')
+    body = ['"s_nop 1\\n\\t"'] + lines + (['"s_nop 1"'] if tail_nop else [])
     # "+&v": early-clobber.  A block writes its accumulators before it has read every input, so an
     # accumulator must never share a register with an input - which hipcc would otherwise do whenever it
     # can prove both hold the same value on entry (e.g. V[i] = Q[i] right before vupd).
@@ -61,7 +66,7 @@ def gen_vf(nx):
         lines = [fmac("w%d" % i, "v%d" % i, "f%d" % k, k) for k in range(nx) for i in rows]
         outs = [("w%d" % i, "W[%d]" % i) for i in rows]
         ins = [("v%d" % i, "V[%d]" % i) for i in rows] + [("f%d" % k, "Fc[%d]" % k) for k in range(nx)]
-        out += statement(lines, outs, ins)
+        out += statement(lines, outs, ins, tail_nop=False)
     return out
 
 
@@ -87,7 +92,7 @@ def gen_vupd(nx, nu):
         outs = [("v%d" % i, "V[%d]" % i) for i in rows]
         ins = [("q%d" % i, "Q[%d]" % i) for i in rows] + [("k%d" % m, "Kt[%d]" % m) for m in range(nu)] + \
               [("r%d" % m, "R[%d]" % m) for m in range(nu)]
-        out += statement(lines, outs, ins)
+        out += statement(lines, outs, ins, tail_nop=False)
     return out
 
 

@@ -26,9 +26,13 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
     x0[e] = 0.f;
 }
 
+#ifdef DMPC_EXPERIMENT_ONLY_8_2
+#define DMPC_COSTATE_SHAPES(X) X(8, 2, 16)
+#else
 #define DMPC_COSTATE_SHAPES(X) \
   X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
+#endif
 
 int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
 #define X(NX_, NU_, L_)                                                                                     \

@@ -3,8 +3,11 @@
 // LQR_active (mpc/active_constrained_lqr.py:67-202) of the reference.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
+#include "lqr_dma_kernel.hpp"
 #include "lqr_generic.hpp"
 #include "lqr_kernels.hpp"
 
@@ -12,6 +15,17 @@ namespace dmpc {
 
 // LDS a 256-thread workgroup may spend on gains before we spill them to HBM.
 constexpr size_t kGainLdsBudget = 64 * 1024;
+// LDS-DMA path: ring depths (timesteps in flight per wave) and the LDS it may use (one workgroup per CU).
+#ifndef DMPC_DMA_DEPTH_B
+#define DMPC_DMA_DEPTH_B 4
+#define DMPC_DMA_DEPTH_F 8
+#endif
+constexpr int kDmaDepthB = DMPC_DMA_DEPTH_B, kDmaDepthF = DMPC_DMA_DEPTH_F;
+constexpr size_t kDmaLdsBudget = 156 * 1024;
+static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_DMA"); return e && e[0] == '1'; }();
+  return off;
+}
 
 template <int NX, int NU, int L>
 static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
@@ -21,6 +35,18 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
 #define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
   hipLaunchKernelGGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
+  if constexpr (L == 16) {
+    // fast path: LDS-DMA staged inputs (lqr_dma_kernel.hpp) - plain solve, at least one full wave of
+    // trajectories, gains + rings within the 160 KB of a CU
+    using Lay = LqrDmaLayout<NX, NU, kDmaDepthB, kDmaDepthF>;
+    if (mode == kSolve && !masked && a.B >= 4 && a.T >= 2 && Lay::lds_bytes(a.T) <= kDmaLdsBudget &&
+        !dma_path_disabled()) {
+      const int waves = (a.B + 3) / 4;
+      hipLaunchKernelGGL((lqr_dma_kernel<NX, NU, kDmaDepthB, kDmaDepthF>), dim3((waves + 3) / 4), block,
+                         Lay::lds_bytes(a.T), stream, a);
+      return (int)hipGetLastError();
+    }
+  }
   if (mode == kSolve) {
     const bool in_lds = lds_gain <= kGainLdsBudget;
     if (in_lds) {

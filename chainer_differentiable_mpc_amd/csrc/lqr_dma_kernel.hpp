@@ -1,0 +1,325 @@
+// lqr_dma_kernel.hpp - fused LQR solve for the 16-lane row layout with the per-timestep blocks staged
+// through LDS by LDS-DMA (global_load_lds_dwordx4), for B >= 4 and horizons whose gains fit in LDS.
+//
+// Same arithmetic as lqr_kernel (lqr_kernels.hpp; lqr/lqr_recursion.py:69-209); what changes is how the
+// inputs reach the registers:
+//   * a wavefront owns four CONSECUTIVE trajectories, so for one timestep its C, c, F, f blocks are four
+//     contiguous runs of HBM (4*ns^2, 4*ns, 4*nx*ns, 4*nx floats).  Each run is copied to an LDS ring slot
+//     by full-width 16-byte-per-lane DMA - every byte is fetched by exactly one coalesced request, no
+//     VGPR is tied up, and the ring is DB (backward) / DF (forward) timesteps deep;
+//   * the column-per-lane registers are then filled by ds_read_b32 with per-lane LDS indices computed once
+//     (lane ns reads c / f directly: no merge of the affine column, no address arithmetic per step).
+// The strided 4-byte global loads of lqr_kernel cost ~20 L1 tag lookups per instruction (64 lanes 40 B
+// apart); that, not HBM latency, is what the register-prefetch version waits on.
+//
+// LDS-DMA is issued from inline asm, so hipcc neither tracks it in vmcnt nor drains it; completion is
+// waited for with counted `s_waitcnt vmcnt(N)`: every wave issues exactly kDmaB (kDmaF) DMA instructions
+// per timestep, in order, so "all but the youngest (D-1)*kDma operations" covers the slot being consumed.
+// Out-of-range prefetches are clamped, never skipped, to keep that count exact; stores issued in between
+// only make the wait more conservative.  A wave reads only the LDS it filled itself: no barrier.
+#pragma once
+#include "colwise.hpp"
+#include "dpp_blocks_gen.hpp"
+#include "lqr_kernels.hpp"
+#include "riccati_blocks.hpp"
+
+namespace dmpc {
+
+__device__ __forceinline__ unsigned lds_byte_address(const void *p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+// One DMA instruction: 64 lanes x 16 bytes, global (sbase + voff) -> LDS (m0 + lane*16).  hipcc does not use M0
+// in these kernels (no LDS-DMA builtin, no movrel), so it is written without save/restore; the instruction
+// between the M0 write and the DMA provides the required wait state.
+__device__ __forceinline__ void dma16(unsigned voff, unsigned lds_dst, const void *sbase) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(lds_dst), "s"(sbase)
+               : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field on gfx9");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Copy a run of BYTES bytes (multiple of 16) starting at `src` (wave-uniform) into LDS at `dst`.
+template <int BYTES>
+__device__ __forceinline__ void dma_run(const char *src, unsigned dst, unsigned lane_off /* lane*16 */) {
+  static_assert(BYTES % 16 == 0, "runs are whole 16-byte units");
+  constexpr int FULL = BYTES / 1024, REM = BYTES % 1024;
+#pragma unroll
+  for (int q = 0; q < FULL; ++q) dma16(lane_off + q * 1024, dst + q * 1024, src);
+  // Partial last chunk: let hipcc mask the lanes.  (Setting EXEC by hand inside the asm statement right in front
+  // of the DMA was measured to corrupt the copy - an EXEC write needs a wait state before a VMEM instruction.)
+  if constexpr (REM > 0) {
+    if (lane_off < (unsigned)REM) dma16(lane_off + FULL * 1024, dst + FULL * 1024, src);
+  }
+}
+template <int BYTES>
+constexpr int dma_count() {
+  return BYTES / 1024 + (BYTES % 1024 ? 1 : 0);
+}
+
+template <int NX, int NU, int DB, int DF>
+struct LqrDmaLayout {
+  static constexpr int NS = NX + NU;
+  static constexpr int C_FL = 4 * NS * NS, c_FL = 4 * NS, F_FL = 4 * NX * NS, f_FL = 4 * NX;  // floats per wave-step
+  static constexpr int OFF_C = 0, OFF_c = OFF_C + C_FL, OFF_F = OFF_c + c_FL, OFF_f = OFF_F + F_FL;
+  static constexpr int SLOT_B = OFF_f + f_FL;  // backward slot: [C | c | F | f]
+  static constexpr int SLOT_F = F_FL + f_FL;   // forward slot:  [F | f]
+  static constexpr int RING_FL = (DB * SLOT_B > DF * SLOT_F) ? DB * SLOT_B : DF * SLOT_F;  // per wave
+  static constexpr int kDmaB = dma_count<C_FL * 4>() + dma_count<c_FL * 4>() + dma_count<F_FL * 4>() + dma_count<f_FL * 4>();
+  static constexpr int kDmaF = dma_count<F_FL * 4>() + dma_count<f_FL * 4>();
+  static constexpr size_t lds_bytes(int T) {
+    return (size_t)4 * RING_FL * 4 + (size_t)16 * T * NU * (NX + 1) * 4;
+  }
+};
+
+template <int NX, int NU, int DB, int DF>
+__global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
+  using Lay = LqrDmaLayout<NX, NU, DB, DF>;
+  constexpr int NS = NX + NU, L = 16, KROW = NX + 1;
+  static_assert(NS + 1 <= L, "augmented columns must fit a DPP row");
+  static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
+  using G = Group<L>;
+  using Blk = RiccatiBlocks<NX, NU, L>;
+
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const bool has_f = a.f != nullptr;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r = lane64 >> 4;   // trajectory within the wave
+  const int lane = lane64 & 15;
+  int b0 = ((int)blockIdx.x * 4 + wave) * 4;  // first trajectory of this wave
+  if (b0 > a.B - 4) b0 = a.B - 4;             // last wave overlaps its neighbour instead of running ragged
+  b0 = __builtin_amdgcn_readfirstlane(b0);
+  const int b = b0 + r;
+
+  extern __shared__ float lds[];
+  float *ring = lds + wave * Lay::RING_FL;
+  float *kl = lds + 4 * Lay::RING_FL + (size_t)(wave * 4 + r) * T * NU * KROW;  // gains of this trajectory
+  const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+  const unsigned lane_off = (unsigned)lane64 * 16u;
+
+  const bool col_aff = lane == NS;
+  const int lane_c = lane < NS ? lane : NS - 1;
+  const bool k_lane = lane < NX || col_aff;
+  const int kidx = lane < NX ? lane : NX;
+  int info_bits = 0;
+
+  // ------------------------------------------------------------------ backward Riccati sweep
+  {
+    // running (wave-uniform) source pointers of the next timestep to fetch; F_{T-1} does not exist and is
+    // replaced by F_{T-2}; a missing f still issues its DMA (from c) so that the DMA count per step is exact
+    const size_t sC = B * (NS * NS * 4), sc = B * (NS * 4), sF = B * (NX * NS * 4), sf = B * (NX * 4);
+    int ti = T - 1;  // next timestep to fetch
+    const char *pC = (const char *)a.C + ((size_t)(T - 1) * B + b0) * (NS * NS * 4);
+    const char *pc = (const char *)a.c + ((size_t)(T - 1) * B + b0) * (NS * 4);
+    const char *pF = (const char *)(T > 1 ? a.F : a.C) + ((size_t)(T > 1 ? T - 2 : 0) * B + b0) * (NX * NS * 4);
+    const char *pf = (const char *)(has_f ? a.f : a.c) + ((size_t)(T > 1 ? T - 2 : 0) * B + b0) * (NX * 4);
+    auto issue_next = [&](int slot) {
+      const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT_B * 4);
+      dma_run<Lay::C_FL * 4>(pC, dst + Lay::OFF_C * 4, lane_off);
+      dma_run<Lay::c_FL * 4>(pc, dst + Lay::OFF_c * 4, lane_off);
+      dma_run<Lay::F_FL * 4>(pF, dst + Lay::OFF_F * 4, lane_off);
+      dma_run<Lay::f_FL * 4>(pf, dst + Lay::OFF_f * 4, lane_off);
+      if (ti > 0) {  // past t = 0 the same block is fetched again (never consumed): the count stays exact
+        if (ti <= T - 2) { pF -= sF; pf -= sf; }
+        pC -= sC;
+        pc -= sc;
+        --ti;
+      }
+    };
+    // per-lane LDS indices (floats, relative to a slot), computed once: lane ns reads c / f directly
+    int iq[NS], ifc[NX];
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      iq[i] = col_aff ? (Lay::OFF_c + r * NS + i) : (Lay::OFF_C + r * NS * NS + i * NS + lane_c);
+#pragma unroll
+    for (int k = 0; k < NX; ++k)
+      ifc[k] = col_aff ? (Lay::OFF_f + r * NX + k) : (Lay::OFF_F + r * NX * NS + k * NS + lane_c);
+    auto read_slot = [&](const float *slot, float (&Qn)[NS], float (&Fn)[NX]) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) Qn[i] = slot[iq[i]];
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Fn[k] = slot[ifc[k]];
+    };
+
+    float V[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) V[i] = 0.f;
+
+    auto step = [&](int t, float (&Q)[NS], float (&Fc)[NX]) {
+      const size_t tb = (size_t)t * B + b;
+      if (t < T - 1) {
+        if (!has_f) {
+#pragma unroll
+          for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? 0.f : Fc[k];
+        }
+        float W[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) W[i] = col_aff ? V[i] : 0.f;
+        Blk::vf(W, V, Fc);   // lqr_recursion.py:89,96
+        Blk::ftw(Q, Fc, W);
+      }
+      float Quu[NU][NU];
+      static_for<0, NU>([&](auto l) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) Quu[m][l.value] = G::template bcast<NX + l.value>(Q[NX + m]);
+      });
+      float Kt[NU];
+#pragma unroll
+      for (int m = 0; m < NU; ++m) Kt[m] = Q[NX + m];
+      if constexpr (NU == 1) {
+        Kt[0] = -(fast_rcp(Quu[0][0]) * Kt[0]);  // :112-115
+        if (Quu[0][0] == 0.f) info_bits |= 1;
+      } else {
+        float A[NU][NU], rinv[NU];
+        int piv[NU];
+#pragma unroll
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+          for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
+        if (lu_factor_rinv<NU>(A, piv, rinv)) info_bits |= 1;  // :116-120
+        lu_solve_rinv<NU>(A, piv, rinv, Kt);
+#pragma unroll
+        for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
+      }
+      if (k_lane) {
+#pragma unroll
+        for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + kidx] = Kt[m];
+        if (a.Ks != nullptr) {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) {
+            if (col_aff) a.ks[tb * NU + m] = Kt[m];
+            else a.Ks[(tb * NU + m) * NX + lane] = Kt[m];
+          }
+        }
+      }
+      if (t > 0) {  // :151-152
+        float R[NU];
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+          R[m] = Q[NX + m];
+#pragma unroll
+          for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) V[i] = Q[i];
+        Blk::vupd(V, Q, Kt, R);
+      }
+    };
+
+    // Software pipeline (DB even): at the start of step t the DMA for step t-DB goes into the slot whose
+    // contents (step t) were moved to registers one step ago, the slot of step t-1 is waited for and read into
+    // the other register set, and only then step t is computed from its own set.
+    static_assert(DB % 2 == 0 && DB >= 2, "two alternating register sets");
+    float QA[NS], FA[NX], QB[NS], FB[NX];
+    static_for<0, DB>([&](auto j) { issue_next(j.value); });
+    wait_vmcnt<(DB - 1) * Lay::kDmaB>();
+    read_slot(ring, QA, FA);
+    for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
+      static_for<0, DB>([&](auto j) {
+        const int t = t0 - j.value;
+        if (t >= 0) {
+          constexpr int nslot = (j.value + 1) % DB;
+          issue_next(j.value);
+          wait_vmcnt<(DB - 1) * Lay::kDmaB>();
+          if constexpr (j.value % 2 == 0) {
+            read_slot(ring + nslot * Lay::SLOT_B, QB, FB);
+            step(t, QA, FA);
+          } else {
+            read_slot(ring + nslot * Lay::SLOT_B, QA, FA);
+            step(t, QB, FB);
+          }
+        }
+      });
+    }
+    wait_vmcnt<0>();  // the ring memory is reused by the forward sweep
+  }
+
+  // ------------------------------------------------------------------ forward rollout (lqr_recursion.py:160-200)
+  {
+    const size_t sF = B * (NX * NS * 4), sf = B * (NX * 4);
+    int ti = 0;
+    const char *pF = (const char *)(T > 1 ? a.F : a.C) + (size_t)b0 * (NX * NS * 4);
+    const char *pf = (const char *)(has_f ? a.f : a.C) + (has_f ? (size_t)b0 * (NX * 4) : 0);
+    auto issue_next = [&](int slot) {
+      const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT_F * 4);
+      dma_run<Lay::F_FL * 4>(pF, dst, lane_off);
+      dma_run<Lay::f_FL * 4>(pf, dst + Lay::F_FL * 4, lane_off);
+      if (ti < T - 2) {  // F/f have T-1 slices; beyond that the last one is fetched again (never consumed)
+        pF += sF;
+        if (has_f) pf += sf;
+        ++ti;
+      }
+    };
+    const bool row_x = lane < NX;
+    const int lane_x = row_x ? lane : NX - 1;
+    const int ifr = r * NX * NS + lane_x * NS;    // row lane_x of F_t in the slot
+    const int iff = Lay::F_FL + r * NX + lane_x;  // f_t[lane_x]
+    auto read_slot = [&](const float *slot, float (&Mn)[NS + 1]) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) Mn[j] = slot[ifr + j];
+      Mn[NS] = slot[iff];
+    };
+    float xv = row_x ? a.x_init[(size_t)b * NX + lane] : (col_aff ? 1.f : 0.f);
+    bool bad = false;
+    auto fstep = [&](int t, const float (&Mc)[NS + 1]) {
+      const size_t tb = (size_t)t * B + b;
+      float u[NU];
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        const float kv = kl[(t * NU + m) * KROW + kidx];
+        u[m] = group_sum<L>(k_lane ? kv * xv : 0.f);  // :177
+        bad = bad || !is_finite(u[m]);
+      }
+      bad = bad || !is_finite(xv);
+      if (row_x) a.x[tb * NX + lane] = xv;
+      if (lane < NU) {
+        float uo = u[0];
+#pragma unroll
+        for (int m = 1; m < NU; ++m) uo = (lane == m) ? u[m] : uo;
+        a.u[tb * NU + lane] = uo;
+      }
+      if (t < T - 1) {
+        float M[NS + 1];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) M[j] = Mc[j];
+        M[NS] = 0.f;
+        float acc = has_f ? Mc[NS] : 0.f;
+        Blk::dot_x(acc, xv, M);  // :189, state part
+#pragma unroll
+        for (int m = 0; m < NU; ++m) acc = fmaf(M[NX + m], u[m], acc);
+        if (row_x) xv = acc;
+      }
+    };
+    static_assert(DF % 2 == 0 && DF >= 2, "two alternating register sets");
+    float MA[NS + 1], MB[NS + 1];
+    static_for<0, DF>([&](auto j) { issue_next(j.value); });
+    wait_vmcnt<(DF - 1) * Lay::kDmaF>();
+    read_slot(ring, MA);
+    for (int t0 = 0; t0 < T; t0 += DF) {
+      static_for<0, DF>([&](auto j) {
+        const int t = t0 + j.value;
+        if (t < T) {
+          constexpr int nslot = (j.value + 1) % DF;
+          issue_next(j.value);
+          wait_vmcnt<(DF - 1) * Lay::kDmaF>();
+          if constexpr (j.value % 2 == 0) {
+            read_slot(ring + nslot * Lay::SLOT_F, MB);
+            fstep(t, MA);
+          } else {
+            read_slot(ring + nslot * Lay::SLOT_F, MA);
+            fstep(t, MB);
+          }
+        }
+      });
+    }
+    if (bad) info_bits |= 2;
+  }
+  if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+}
+
+}  // namespace dmpc

@@ -44,9 +44,13 @@ __global__ __launch_bounds__(256) void pnqp_kernel(int B, const float *__restric
   if (info != nullptr && !res.converged) atomicOr(&info[b], DMPC_INFO_QP_ITERCAP);
 }
 
+#ifdef DMPC_EXPERIMENT_ONLY_8_2
+#define DMPC_MPC_SHAPES(X) X(8, 2, 16)
+#else
 #define DMPC_MPC_SHAPES(X) \
   X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16)
+#endif
 
 static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a, hipStream_t stream) {
 #define X(NX_, NU_, L_)                                                                                       \

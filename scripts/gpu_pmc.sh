@@ -17,7 +17,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if 'lqr_kernel' in r.get('Kernel_Name', ''):
+    if 'lqr_' in r.get('Kernel_Name', ''):
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(agg.items()):
     print("  %-28s n=%3d  mean=%.4g" % (k, len(v), sum(v) / len(v)))

@@ -6,8 +6,7 @@ mkdir -p /tmp/var
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I$REPO/include -DDMPC_EXPERIMENT_ONLY_8_2 $flags \
-      -shared -o /tmp/var/lib_$name.so $REPO/chainer_differentiable_mpc_amd/csrc/lqr_api.hip \
-      $REPO/chainer_differentiable_mpc_amd/csrc/lu_api.hip 2>&1 | grep -E "error" ) &
+      -shared -o /tmp/var/lib_$name.so $REPO/chainer_differentiable_mpc_amd/csrc/*.hip 2>&1 | grep -E "error" ) &
 done
 wait
 for spec in "$@"; do
