@@ -33,13 +33,18 @@ __device__ __forceinline__ unsigned lds_byte_address(const void *p) {
 // in these kernels (no LDS-DMA builtin, no movrel), so it is written without save/restore; the instruction
 // between the M0 write and the DMA provides the required wait state.
 __device__ __forceinline__ void dma16(unsigned voff, unsigned lds_dst, const void *sbase) {
+#ifdef DMPC_TIMING_NO_DMA      // timing experiments only
+  return;
+#endif
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(lds_dst), "s"(sbase)
                : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field on gfx9");
+#ifndef DMPC_TIMING_NO_WAIT   // timing experiments only (results are wrong without the wait)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
 }
 
 // Copy a run of BYTES bytes (multiple of 16) starting at `src` (wave-uniform) into LDS at `dst`.
@@ -71,14 +76,14 @@ struct LqrDmaLayout {
   static constexpr int kDmaB = dma_count<C_FL * 4>() + dma_count<c_FL * 4>() + dma_count<F_FL * 4>() + dma_count<f_FL * 4>();
   static constexpr int kDmaF = dma_count<F_FL * 4>() + dma_count<f_FL * 4>();
   static constexpr size_t lds_bytes(int T) {
-    return (size_t)4 * RING_FL * 4 + (size_t)16 * T * NU * (NX + 1) * 4;
+    return (size_t)4 * RING_FL * 4 + (size_t)16 * T * NU * (NS + 1) * 4;  // rings + gain rows [K_m | 0 | k_m]
   }
 };
 
 template <int NX, int NU, int DB, int DF>
 __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
   using Lay = LqrDmaLayout<NX, NU, DB, DF>;
-  constexpr int NS = NX + NU, L = 16, KROW = NX + 1;
+  constexpr int NS = NX + NU, L = 16, KROW = NS + 1;  // gain rows share the shape of an [F_i | f_i] row
   static_assert(NS + 1 <= L, "augmented columns must fit a DPP row");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
   using G = Group<L>;
@@ -105,7 +110,6 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
   const bool col_aff = lane == NS;
   const int lane_c = lane < NS ? lane : NS - 1;
   const bool k_lane = lane < NX || col_aff;
-  const int kidx = lane < NX ? lane : NX;
   int info_bits = 0;
 
   // ------------------------------------------------------------------ backward Riccati sweep
@@ -140,6 +144,13 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
     for (int k = 0; k < NX; ++k)
       ifc[k] = col_aff ? (Lay::OFF_f + r * NX + k) : (Lay::OFF_F + r * NX * NS + k * NS + lane_c);
     auto read_slot = [&](const float *slot, float (&Qn)[NS], float (&Fn)[NX]) {
+#ifdef DMPC_TIMING_NO_LDSREAD
+#pragma unroll
+      for (int i = 0; i < NS; ++i) Qn[i] = 1.0f + 0.01f * i + 0.001f * lane;
+#pragma unroll
+      for (int k = 0; k < NX; ++k) Fn[k] = 0.1f + 0.01f * k;
+      return;
+#endif
 #pragma unroll
       for (int i = 0; i < NS; ++i) Qn[i] = slot[iq[i]];
 #pragma unroll
@@ -186,9 +197,11 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
 #pragma unroll
         for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
       }
-      if (k_lane) {
+      if (lane <= NS) {  // row m of the gains as [K_m (nx) | 0 (nu) | k_m]: the forward sweep reads it like an F row
 #pragma unroll
-        for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + kidx] = Kt[m];
+        for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + lane] = k_lane ? Kt[m] : 0.f;
+      }
+      if (k_lane) {
         if (a.Ks != nullptr) {
 #pragma unroll
           for (int m = 0; m < NU; ++m) {
@@ -219,7 +232,11 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
     static_for<0, DB>([&](auto j) { issue_next(j.value); });
     wait_vmcnt<(DB - 1) * Lay::kDmaB>();
     read_slot(ring, QA, FA);
+#ifdef DMPC_TIMING_SKIP_BWD
+    for (int t0 = -1; t0 >= 0; t0 -= DB) {
+#else
     for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
+#endif
       static_for<0, DB>([&](auto j) {
         const int t = t0 - j.value;
         if (t >= 0) {
@@ -255,68 +272,68 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
         ++ti;
       }
     };
+    // Lane i < NX owns row i of [F_t | f_t] (ring slot), lane NX+m owns row m of [K_t | 0 | k_t] (gain rows in
+    // LDS); both are NS+1 floats, so ONE instruction stream serves both:
+    //     acc  = M[NS] + sum_{j<NX} x[j] * M[j]        -> lanes NX+m: u_t[m] ; lanes < NX: f + Fx x
+    //     acc += sum_m u[m] * M[NX+m]                   -> lanes < NX: x_{t+1}
+    // with x[j], u[m] broadcast from lanes j, NX+m of the row (lqr_recursion.py:177,189).
     const bool row_x = lane < NX;
+    const bool row_u = lane >= NX && lane < NS;
     const int lane_x = row_x ? lane : NX - 1;
-    const int ifr = r * NX * NS + lane_x * NS;    // row lane_x of F_t in the slot
-    const int iff = Lay::F_FL + r * NX + lane_x;  // f_t[lane_x]
-    auto read_slot = [&](const float *slot, float (&Mn)[NS + 1]) {
+    const int m_own = row_u ? lane - NX : 0;
+    const float *xbase = ring + r * NX * NS + lane_x * NS;           // + slot * SLOT_F : row lane_x of F_t
+    const float *xaff = ring + Lay::F_FL + r * NX + lane_x;          // + slot * SLOT_F : f_t[lane_x]
+    const float *ubase = kl + m_own * KROW;                          // + t * NU * KROW : row m of the gains
+    auto read_rows = [&](int t, int slot, float (&Mn)[NS + 1]) {
+      const float *row = row_u ? ubase + (size_t)t * (NU * KROW) : xbase + slot * Lay::SLOT_F;
+      const float *aff = row_u ? ubase + (size_t)t * (NU * KROW) + NS : xaff + slot * Lay::SLOT_F;
 #pragma unroll
-      for (int j = 0; j < NS; ++j) Mn[j] = slot[ifr + j];
-      Mn[NS] = slot[iff];
+      for (int j = 0; j < NS; ++j) Mn[j] = row[j];
+      Mn[NS] = aff[0];
     };
-    float xv = row_x ? a.x_init[(size_t)b * NX + lane] : (col_aff ? 1.f : 0.f);
-    bool bad = false;
+    float xv = row_x ? a.x_init[(size_t)b * NX + lane] : 0.f;  // lane j < NX: x[j]; lane NX+m: u[m]
     auto fstep = [&](int t, const float (&Mc)[NS + 1]) {
       const size_t tb = (size_t)t * B + b;
-      float u[NU];
+      float M[NS + 1];
 #pragma unroll
-      for (int m = 0; m < NU; ++m) {
-        const float kv = kl[(t * NU + m) * KROW + kidx];
-        u[m] = group_sum<L>(k_lane ? kv * xv : 0.f);  // :177
-        bad = bad || !is_finite(u[m]);
-      }
-      bad = bad || !is_finite(xv);
+      for (int j = 0; j <= NS; ++j) M[j] = Mc[j];
+      float acc = (row_u || has_f) ? M[NS] : 0.f;
+      Blk::dot_x(acc, xv, M);
+      if (row_u) xv = acc;
       if (row_x) a.x[tb * NX + lane] = xv;
-      if (lane < NU) {
-        float uo = u[0];
-#pragma unroll
-        for (int m = 1; m < NU; ++m) uo = (lane == m) ? u[m] : uo;
-        a.u[tb * NU + lane] = uo;
-      }
-      if (t < T - 1) {
-        float M[NS + 1];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) M[j] = Mc[j];
-        M[NS] = 0.f;
-        float acc = has_f ? Mc[NS] : 0.f;
-        Blk::dot_x(acc, xv, M);  // :189, state part
-#pragma unroll
-        for (int m = 0; m < NU; ++m) acc = fmaf(M[NX + m], u[m], acc);
-        if (row_x) xv = acc;
-      }
+      else if (row_u) a.u[tb * NU + m_own] = xv;
+      Blk::dot_u(acc, xv, M);  // for t = T-1 this consumes a re-fetched F_{T-2}: the result is never used
+      if (row_x) xv = acc;
     };
     static_assert(DF % 2 == 0 && DF >= 2, "two alternating register sets");
     float MA[NS + 1], MB[NS + 1];
     static_for<0, DF>([&](auto j) { issue_next(j.value); });
     wait_vmcnt<(DF - 1) * Lay::kDmaF>();
-    read_slot(ring, MA);
+    read_rows(0, 0, MA);
+#ifdef DMPC_TIMING_SKIP_FWD
+    for (int t0 = T; t0 < T; t0 += DF) {
+#else
     for (int t0 = 0; t0 < T; t0 += DF) {
+#endif
       static_for<0, DF>([&](auto j) {
         const int t = t0 + j.value;
         if (t < T) {
           constexpr int nslot = (j.value + 1) % DF;
           issue_next(j.value);
           wait_vmcnt<(DF - 1) * Lay::kDmaF>();
+          const int tn = t + 1 < T ? t + 1 : T - 1;
           if constexpr (j.value % 2 == 0) {
-            read_slot(ring + nslot * Lay::SLOT_F, MB);
+            read_rows(tn, nslot, MB);
             fstep(t, MA);
           } else {
-            read_slot(ring + nslot * Lay::SLOT_F, MA);
+            read_rows(tn, nslot, MA);
             fstep(t, MB);
           }
         }
       });
     }
+    // NaN/Inf propagate through the recursion, so the state after the last step tells whether anything broke
+    const bool bad = !is_finite(xv);
     if (bad) info_bits |= 2;
   }
   if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
