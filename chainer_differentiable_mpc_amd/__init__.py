@@ -16,5 +16,9 @@ from .differentiable_lqr import DiffLqr, LqrNet, LqrNet_cost_dx  # noqa: F401
 from .pnqp import PNQP  # noqa: F401
 from .active_constrained_lqr import LQR_active  # noqa: F401
 from .mpc_step import MPCstep, LqrBackOut, LqrForOut  # noqa: F401
+from .approximate import approximate_cost, linearize_dynamics  # noqa: F401
+from .box_ddp import BoxDDP  # noqa: F401
+from .mpc_net import MpcNet_cost, MpcNet_dx  # noqa: F401
+from .pendulum import PendulumDx  # noqa: F401
 
 __version__ = "0.1.0"

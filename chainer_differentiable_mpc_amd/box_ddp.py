@@ -1,0 +1,172 @@
+"""`BoxDDP` - the outer box-constrained iLQR loop with the constructor and call signature of
+mpc/box_ddp.py:24-291 of the reference.  Host-side control flow over device tensors; every heavy step
+(`get_traj` rollouts aside, which are tiny torch ops) is an `MPCstep` running on the HIP kernels.
+
+    solver = BoxDDP(T, u_lower, u_upper, n_batch, n_state, n_ctrl, u_init, ...)
+    x, u, costs = solver((x_init, cost, dynamics))      # cost: QuadCost | callable, dynamics: LinDx | callable
+
+Per-sample "best so far" bookkeeping is a masked `torch.where` instead of the reference's Python loop over
+the batch (:200-209); stop tests, the final no-op MPCstep node that carries the gradient (:247-259) and the
+detach mask for unconverged samples (:263-289) follow the reference.
+"""
+import warnings
+
+import torch
+
+from .approximate import approximate_cost, linearize_dynamics
+from .lqr_recursion import _as_tensor
+from .mpc_step import MPCstep
+from .util import LinDx, QuadCost, get_cost, get_traj
+
+
+def table_log(tag, d, _seen=[]):
+    """markdown-ish progress rows (util.py:67-91)"""
+    if tag not in _seen:
+        print('| ' + ' | '.join(str(di[0]) for di in d) + ' |')
+        _seen.append(tag)
+    row = []
+    for di in d:
+        row.append(di[2].format(float(di[1])) if len(di) == 3 else str(di[1]))
+    print('| ' + ' | '.join(row) + ' |')
+
+
+class BoxDDP(torch.nn.Module):
+    def __init__(self, T, u_lower, u_upper, n_batch, n_state, n_ctrl, u_init, eps=1e-5, not_improved_lim=5,
+                 line_search_decay=0.2, max_line_search_iter=10, best_cost_eps=1e-4, max_iter=10,
+                 detach_unconverged=True, exit_unconverged=True, verbose=False, ilqr_verbose=False,
+                 update_dynamics=True, quiet=False):
+        super().__init__()
+        self.T, self.n_batch, self.n_state, self.n_ctrl = T, n_batch, n_state, n_ctrl
+        self.n_sc = n_state + n_ctrl
+        self.eps = eps
+        self.not_improved_lim = not_improved_lim
+        self.ls_decay = line_search_decay
+        self.max_ls_iter = max_line_search_iter
+        self.best_cost_eps = best_cost_eps
+        self.max_iter = max_iter
+        self.verbose = verbose
+        self.ilqr_verbose = ilqr_verbose
+        self.u_init = u_init
+        self.detach_unconverged = detach_unconverged
+        self.exit_unconverged = exit_unconverged
+        self.update_dynamics = update_dynamics
+        self.quiet = quiet          # suppress the reference's "Converged" / "Not improved lim" prints
+        self.status = None
+        self.n_iter = 0
+        if isinstance(u_lower, (int, float)):       # scalar bounds are broadcast to [T,B,nu] (:68-90)
+            u_lower = torch.full((T, n_batch, n_ctrl), float(u_lower))
+            u_upper = torch.full((T, n_batch, n_ctrl), float(u_upper))
+        self.u_lower = _as_tensor(u_lower)
+        self.u_upper = _as_tensor(u_upper)
+        assert list(self.u_lower.shape) == [T, n_batch, n_ctrl], 'actual' + str(tuple(self.u_lower.shape))
+        assert list(self.u_upper.shape) == [T, n_batch, n_ctrl]
+
+    def _say(self, msg):
+        self.status = msg.strip()
+        if not self.quiet:
+            print(msg)
+
+    def forward(self, inputs):
+        x_init, cost, dynamics = inputs
+        x_init = _as_tensor(x_init)
+        T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
+        assert list(x_init.shape) == [B, nx], " x_init dim mismatch"
+        dev, dt = x_init.device, x_init.dtype
+        lo, hi = self.u_lower.to(device=dev, dtype=dt), self.u_upper.to(device=dev, dtype=dt)
+        if self.u_init is None:
+            u = torch.zeros((T, B, nu), dtype=dt, device=dev)
+        else:
+            u = _as_tensor(self.u_init).to(device=dev, dtype=dt)
+            if list(u.shape) == [T, nu]:
+                u = u.unsqueeze(1).repeat(1, B, 1)
+        assert list(u.shape) == [T, B, nu], "u dim mismatch, actual" + str(tuple(u.shape))
+        u = u.detach()
+
+        def models(x, u):
+            if isinstance(dynamics, LinDx):
+                Fm, fm = dynamics.F, dynamics.f
+            else:
+                Fm, fm = linearize_dynamics(x, u, dynamics)
+            if isinstance(cost, QuadCost):
+                Cm, cm = cost.C, cost.c
+            else:
+                Cm, cm, _ = approximate_cost(x, u, cost)
+            return Cm, cm, Fm, fm
+
+        def detached_dyn():
+            if isinstance(dynamics, LinDx):
+                return LinDx(dynamics.F.detach(), None if dynamics.f is None else dynamics.f.detach())
+            return dynamics
+
+        def detached_cost():
+            if isinstance(cost, QuadCost):
+                return QuadCost(cost.C.detach(), cost.c.detach())
+            return cost
+
+        if self.verbose:
+            with torch.no_grad():
+                c0 = get_cost(T, u, detached_cost(), detached_dyn(), x_init=x_init.detach())
+            print('Initial mean(cost): {:.4e}'.format(float(c0.mean())))
+        best = None
+        n_not_improved = 0
+        for_out = None
+        for i in range(self.max_iter):
+            with torch.no_grad():
+                x = get_traj(T, u, x_init.detach(), detached_dyn())
+                Cm, cm, Fm, fm = models(x, u)
+                step = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu,
+                               current_states=x, true_cost=detached_cost(), true_dynamics=detached_dyn(),
+                               ls_decay=self.ls_decay, max_ls_iter=self.max_ls_iter, verbose=self.ilqr_verbose,
+                               need_expand=True)
+                x, u = step.forward((x[0], Cm, cm, Fm, fm))
+            back_out, for_out = step.back_out, step.for_out
+            n_not_improved += 1
+            if best is None:
+                best = {'x': x.clone(), 'u': u.clone(), 'costs': for_out.costs.clone(),
+                        'full_du_norm': for_out.full_du_norm.clone()}
+            else:   # per-sample best (:200-209)
+                better = for_out.costs <= best['costs'] + self.best_cost_eps
+                if bool(better.any()):
+                    n_not_improved = 0
+                best['x'] = torch.where(better[None, :, None], x, best['x'])
+                best['u'] = torch.where(better[None, :, None], u, best['u'])
+                best['costs'] = torch.where(better, for_out.costs, best['costs'])
+                best['full_du_norm'] = torch.where(better, for_out.full_du_norm, best['full_du_norm'])
+            if self.verbose:
+                table_log('lqr', (('iter', i), ('mean(cost)', best['costs'].mean(), '{:.4e}'),
+                                  ('||full_du||_max', for_out.full_du_norm.max(), '{:.2e}'),
+                                  ('mean(alphas)', for_out.mean_alphas, '{:.2e}'),
+                                  ('total_qp_iters', back_out.n_total_qp_iter)))
+            self.n_iter = i + 1
+            if float(for_out.full_du_norm.max()) < self.eps:       # :223-230
+                self._say("Converged")
+                break
+            if n_not_improved > self.not_improved_lim:
+                self._say("Not improved lim")
+                break
+            if i == self.max_iter - 1:
+                self._say("Not Converged ")
+        x, u = best['x'], best['u']
+        costs = best['costs']
+        # Taylor models at the best point and a no-op MPCstep node that carries the gradient (:234-259)
+        Cm, cm, Fm, fm = models(x, u)
+        if self.update_dynamics:
+            Cm, cm = Cm.detach(), cm.detach()
+        else:
+            Fm = Fm.detach()
+            fm = None if fm is None else fm.detach()
+        node = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu, current_states=x,
+                       true_cost=detached_cost(), true_dynamics=detached_dyn(), ls_decay=self.ls_decay,
+                       max_ls_iter=self.max_ls_iter, verbose=self.ilqr_verbose, need_expand=True, no_op_forward=True)
+        needs_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (Cm, cm, Fm, fm, x_init))
+        if needs_graph:
+            x, u = node.apply((x[0].detach(), Cm, cm, Fm, fm))
+        if self.detach_unconverged and float(best['full_du_norm'].max()) > self.eps:      # :263-289
+            if self.verbose:
+                print("LQR Warning: All examples did not converge to a fixed point.")
+                print("Detaching and *not* backpropping through the bad examples.")
+            warnings.warn("LQR Warning: All examples did not converge to a fixed point.")
+            keep = (for_out.full_du_norm < self.eps).to(x.dtype)[None, :, None]
+            x = x * keep + x.detach() * (1. - keep)
+            u = u * keep + u.detach() * (1. - keep)
+        return x, u, costs

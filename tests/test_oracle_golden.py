@@ -240,3 +240,40 @@ def test_mpc_step_per_trajectory_golden(path):
                            g["grad_x"], g["grad_u"], T, nx, nu)
     for got, key in zip(out, ("d_x_init", "dC", "dc", "dF", "df")):
         np.testing.assert_allclose(got, g["row_" + key], rtol=1e-4, atol=1e-5, err_msg=key)
+
+
+def test_box_ddp_trace_golden():
+    """BoxDDP + LinDx/QuadCost (mpc/box_ddp.py:93-291): final x, u, costs and the stop reason of the reference"""
+    from oracle import box_ddp
+    g = load("boxddp_trace.npz")
+    B, T, nx, nu = int(g["B"]), int(g["T"]), int(g["nx"]), int(g["nu"])
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=int(g["seed"]), with_f=True)
+    x, u, costs, status, n_iter, _ = box_ddp.box_ddp(p["x_init"], mpc.QuadCost(p["C"], p["c"]), mpc.LinDx(p["F"], p["f"]),
+                                                     T, -float(g["bound"]), float(g["bound"]), nx, nu)
+    assert status in str(g["stdout"])
+    np.testing.assert_allclose(u, g["u"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(x, g["x"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(costs, g["costs"], rtol=1e-5)
+
+
+def test_pendulum_jacobian_matches_finite_differences():
+    from oracle import box_ddp
+    rng = np.random.RandomState(0)
+    T, B = 4, 5
+    th = rng.uniform(-1.5, 1.5, B)
+    x0 = np.stack((np.cos(th), np.sin(th), rng.uniform(-1, 1, B)), axis=1)
+    u = rng.uniform(-1.5, 1.5, (T, B, 1))
+    xs = [x0]
+    for t in range(T - 1):
+        xs.append(box_ddp.pendulum_step(xs[t], u[t]))
+    x = np.stack(xs)
+    F, f = box_ddp.pendulum_linearize(x, u)
+    eps = 1e-6
+    for t in range(T - 1):
+        tau = np.concatenate((x[t], u[t]), axis=1)
+        np.testing.assert_allclose(np.einsum("bij,bj->bi", F[t], tau) + f[t], x[t + 1], atol=1e-12)
+        for j in range(4):
+            d = np.zeros(4); d[j] = eps
+            plus = box_ddp.pendulum_step(x[t] + d[:3], u[t] + d[3:])
+            minus = box_ddp.pendulum_step(x[t] - d[:3], u[t] - d[3:])
+            np.testing.assert_allclose(F[t][:, :, j], (plus - minus) / (2 * eps), atol=1e-6)
