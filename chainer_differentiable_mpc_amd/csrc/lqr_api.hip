@@ -7,6 +7,7 @@
 
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
+#include "lqr_asm_kernel.hpp"
 #include "lqr_dma_kernel.hpp"
 #include "lqr_generic.hpp"
 #include "lqr_kernels.hpp"
@@ -22,6 +23,11 @@ constexpr size_t kGainLdsBudget = 64 * 1024;
 #endif
 constexpr int kDmaDepthB = DMPC_DMA_DEPTH_B, kDmaDepthF = DMPC_DMA_DEPTH_F;
 constexpr size_t kDmaLdsBudget = 156 * 1024;
+constexpr size_t kAsmLdsBudget = 160 * 1024;
+static bool asm_path_disabled() {  // DMPC_NO_ASM=1 forces the HIP kernels (A/B timing, debugging)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_ASM"); return e && e[0] == '1'; }();
+  return off;
+}
 static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
   static const bool off = [] { const char *e = getenv("DMPC_NO_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -35,6 +41,21 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
 #define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
   hipLaunchKernelGGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
+  if constexpr (L == 16 && LqrAsm<NX, NU, false>::kAvailable) {
+    // fastest path: the whole solve as one generated instruction stream (lqr_asm_kernel.hpp)
+    if (mode == kSolve && !masked && a.B >= 4 && a.T >= 2 && lqr_asm_lds_bytes<NX, NU>(a.T) <= kAsmLdsBudget &&
+        !asm_path_disabled()) {
+      const int waves = (a.B + 3) / 4;
+      const dim3 g((waves + 3) / 4);
+      const size_t shmem = lqr_asm_lds_bytes<NX, NU>(a.T);
+      const bool has_f = a.f != nullptr, write_k = a.Ks != nullptr;
+      if (has_f && !write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false>), g, block, shmem, stream, a);
+      else if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true>), g, block, shmem, stream, a);
+      else if (!write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false>), g, block, shmem, stream, a);
+      else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true>), g, block, shmem, stream, a);
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (L == 16) {
     // fast path: LDS-DMA staged inputs (lqr_dma_kernel.hpp) - plain solve, at least one full wave of
     // trajectories, gains + rings within the 160 KB of a CU

@@ -1,0 +1,171 @@
+// lqr_asm_kernel.hpp - fused LQR solve whose whole body is one generated gfx950 instruction stream
+// (lqr_asm_gen.hpp, written by gen_lqr_asm.py).  This file is the C++ side: it lays out LDS, prepares the
+// per-lane operands of the stream (DMA source pointers and strides, LDS read addresses, store pointers) and
+// turns the stream's two outputs into the per-trajectory info flags.
+//
+// Arithmetic, layout and semantics are those of lqr_kernel / lqr_dma_kernel (lqr/lqr_recursion.py:69-209):
+// a wavefront owns four consecutive trajectories, one 16-lane DPP row each, column-per-lane registers, the
+// affine terms in lane ns.  What differs is that nothing is left to the compiler between the first DMA and
+// the last store - with one wavefront per SIMD the kernel's time is its instruction count.
+//
+// LDS (dynamic), per 256-thread workgroup:
+//   [0, 4*RING)                    one ring per wave: DB backward slots [C|c|F|f] of the wave's 4 trajectories,
+//                                  later DF forward slots [F|f]; kept below 64 KB (M0 carries the DMA target)
+//   [4*RING, +64)                  unused
+//   [.., + 16*T*NU*KROW*4)         gain rows [K_m | 0 | k_m | pad] per trajectory, time-major, zero-initialised
+#pragma once
+#include "colwise.hpp"
+#include "lqr_asm_gen.hpp"
+#include "lqr_dma_kernel.hpp"
+#include "lqr_kernels.hpp"
+
+namespace dmpc {
+
+// What the f lanes of the DMA groups fetch when the caller passes no f: zeros from the code object's own data
+// segment (the library allocates nothing), so that the stream itself has no "f is absent" case.
+__device__ const float4 dmpc_zero_chunks[16] = {};
+
+template <int NX, int NU>
+constexpr size_t lqr_asm_lds_bytes(int T) {
+  using G = LqrAsm<NX, NU, false>;
+  return (size_t)4 * G::RING_BYTES + 64 + (size_t)16 * T * NU * G::KROW * 4;
+}
+
+template <int NX, int NU, bool HAS_F, bool WRITE_K>
+__global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
+  using G = LqrAsm<NX, NU, WRITE_K>;
+  static_assert(G::kAvailable, "no generated instruction stream for this shape");
+  constexpr int NS = NX + NU, AFF = NS, KROW = G::KROW;
+  constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
+  static_assert(4 * G::RING_BYTES <= 65536, "DMA targets must stay below 64 KB");
+
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r = lane64 >> 4;  // trajectory within the wave
+  const int lane = lane64 & 15;
+  int b0 = ((int)blockIdx.x * 4 + wave) * 4;  // first trajectory of this wave
+  if (b0 > a.B - 4) b0 = a.B - 4;             // last wave overlaps its neighbour instead of running ragged
+  b0 = __builtin_amdgcn_readfirstlane(b0);
+  const int b = b0 + r;
+
+  extern __shared__ float lds[];
+  const unsigned lds0 = lds_byte_address(lds);
+  const unsigned ring = lds0 + (unsigned)wave * G::RING_BYTES;
+  const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + 64u + (unsigned)(wave * 4) * (unsigned)(T * NU * KROW * 4);
+  const unsigned gain_traj = gain_wave + (unsigned)r * (unsigned)(T * NU * KROW * 4);
+
+  {  // zero this wave's gain rows (columns nx..ns-1 and the pad are never written afterwards)
+    float4 *g4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + (gain_wave - lds0));
+    const int n4 = T * NU * KROW;  // float4 per wave: 4 trajectories * T*NU*KROW floats / 4
+    for (int i = lane64; i < n4; i += 64) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  LqrAsmIn<NX, NU> in;
+  in.ring = __builtin_amdgcn_readfirstlane(ring);
+  in.T = T;
+
+  // ---- backward DMA: chunk g = q*64 + lane64 of the slot [C | c | F | f]
+  const char *Cb = reinterpret_cast<const char *>(a.C), *cb = reinterpret_cast<const char *>(a.c);
+  const char *Fb = reinterpret_cast<const char *>(a.F);
+  const char *fb = HAS_F ? reinterpret_cast<const char *>(a.f) : reinterpret_cast<const char *>(dmpc_zero_chunks);
+  constexpr size_t per_f = HAS_F ? (size_t)NX * 4 : 0;  // bytes of f per trajectory and timestep (0: the zero chunks)
+  static_assert(nf <= 16, "dmpc_zero_chunks too small");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q >= G::NDB) {
+      in.ptr[q] = in.str1[q] = in.str[q] = 0;
+      continue;
+    }
+    const int g = q * 64 + lane64;
+    const char *base = Cb;
+    size_t per = (size_t)NS * NS * 4;  // bytes per trajectory and timestep
+    size_t off = 0;
+    int t0 = T - 1;
+    bool dyn = false;
+    if (g < nC) {
+      off = (size_t)g * 16;
+    } else if (g < nC + nc) {
+      base = cb; per = (size_t)NS * 4; off = (size_t)(g - nC) * 16;
+    } else if (g < nC + nc + nF) {
+      base = Fb; per = (size_t)NX * NS * 4; off = (size_t)(g - nC - nc) * 16; t0 = T - 2; dyn = true;
+    } else if (g < nC + nc + nF + nf) {
+      base = fb; per = per_f; off = (size_t)(g - nC - nc - nF) * 16; t0 = T - 2; dyn = true;
+    }  // else: padding lanes fetch chunk 0 of C again - never read
+    const uint64_t p = reinterpret_cast<uint64_t>(base) + ((size_t)t0 * B + (size_t)b0) * per + off;
+    in.ptr[q] = p - (uint64_t)q * 1024u;  // the instruction offset q*1024 moves the global address as well
+    const uint64_t s = (uint64_t)0 - (uint64_t)(B * per);
+    in.str[q] = s;
+    in.str1[q] = dyn ? 0 : s;  // there is no F_{T-1}: the first group fetches F_{T-2} (unused), as does the second
+  }
+  const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
+  const bool col_aff = lane == AFF;
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    in.aq[i] = ring + (col_aff ? (unsigned)(G::OFF_c + (r * NS + i) * 4)
+                               : (unsigned)(G::OFF_C + ((r * NS + i) * NS + lane_c) * 4));
+#pragma unroll
+  for (int k = 0; k < NX; ++k)
+    in.af[k] = col_aff ? ring + (unsigned)(G::OFF_f + (r * NX + k) * 4)
+                       : ring + (unsigned)(G::OFF_F + ((r * NX + k) * NS + lane_c) * 4);
+  in.ak = gain_traj + (unsigned)((T - 1) * NU * KROW * 4) + (unsigned)lane * 4u;
+  in.eaff = col_aff ? 1.f : 0.f;
+  if constexpr (WRITE_K) {
+    const size_t tb = (size_t)(T - 1) * B + (size_t)b;
+#pragma unroll
+    for (int m = 0; m < NU; ++m)
+      in.pk[m] = col_aff ? reinterpret_cast<uint64_t>(a.ks + tb * NU + m)
+                         : reinterpret_cast<uint64_t>(a.Ks + (tb * NU + m) * NX + (lane < NX ? lane : 0));
+    in.dk = (uint64_t)0 - (uint64_t)(col_aff ? B * NU * 4 : B * NU * NX * 4);
+  } else {
+#pragma unroll
+    for (int m = 0; m < NU; ++m) in.pk[m] = 0;
+    in.dk = 0;
+  }
+
+  // ---- forward DMA: chunk g of the slot [F | f]
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (q >= G::NDF) {
+      in.fptr[q] = in.fstr[q] = 0;
+      continue;
+    }
+    const int g = q * 64 + lane64;
+    const char *base = Fb;
+    size_t per = (size_t)NX * NS * 4, off = 0;
+    if (g < nF) {
+      off = (size_t)g * 16;
+    } else if (g < nF + nf) {
+      base = fb; per = per_f; off = (size_t)(g - nF) * 16;
+    }
+    in.fptr[q] = reinterpret_cast<uint64_t>(base) + (size_t)b0 * per + off - (uint64_t)q * 1024u;
+    in.fstr[q] = (uint64_t)(B * per);
+  }
+  // lane i < nx: row i of [F_t | f_t]; lane nx+m: gain row m; the other lanes shadow the last gain row
+  const bool row_x = lane < NX;
+  const int m_own = row_x ? 0 : (lane < NS ? lane - NX : NU - 1);
+  in.arow = row_x ? ring + (unsigned)((r * NX + lane) * NS * 4) : gain_traj + (unsigned)(m_own * KROW * 4);
+  in.aaff = row_x ? ring + (unsigned)(G::FOFF_f + (r * NX + lane) * 4) : in.arow + (unsigned)(NS * 4);
+  in.drow = row_x ? (unsigned)G::SLOT_F : (unsigned)(NU * KROW * 4);
+  in.drow2 = row_x ? (unsigned)G::SLOT_F - (unsigned)(G::DEPTH_F * G::SLOT_F) : (unsigned)(NU * KROW * 4);
+  in.daff = in.drow;
+  in.daff2 = in.drow2;
+  in.pst = row_x ? reinterpret_cast<uint64_t>(a.x + (B + (size_t)b) * NX + lane)
+                 : reinterpret_cast<uint64_t>(a.u + (size_t)b * NU + m_own);
+  in.dst = row_x ? (uint64_t)(B * NX * 4) : (uint64_t)(B * NU * 4);
+  in.xv = row_x ? a.x_init[(size_t)b * NX + lane] : 0.f;
+  if (row_x) a.x[(size_t)b * NX + lane] = in.xv;  // x_0
+
+  float xvout, minpiv;
+  G::run(in, xvout, minpiv);
+
+  if (a.info != nullptr) {
+    int bits = 0;
+    if (minpiv == 0.f) bits |= 1;                       // a zero pivot in some Quu (uniform over the row)
+    if (lane < NS && !is_finite(xvout)) bits |= 2;      // NaN/Inf propagate to u_{T-1} through the recursion
+    if (bits != 0) atomicOr(&a.info[b], bits);
+  }
+}
+
+}  // namespace dmpc
