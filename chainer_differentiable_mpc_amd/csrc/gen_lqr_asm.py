@@ -43,6 +43,16 @@ DF = 6        # forward ring depth == unroll (lcm of 2 row sets and 3 accumulato
 KROW = 12     # floats per gain row in LDS: [K_m (nx) | 0 (nu) | k_m | pad], 8-byte aligned rows
 VBASE = 128   # first VGPR owned by the asm block (operands chosen by hipcc live below)
 
+# timing experiments only (scripts/asm_variants.sh): the results of such builds are wrong on purpose
+X_NO_VMWAIT = os.environ.get("GEN_NO_VMWAIT") == "1"    # drop the counted vmcnt waits inside the loops
+X_NO_DMA = os.environ.get("GEN_NO_DMA") == "1"          # issue no DMA inside the loops
+X_NO_LDSREAD = os.environ.get("GEN_NO_LDSREAD") == "1"  # no ds_read inside the loops
+X_SKIP_FWD = os.environ.get("GEN_SKIP_FWD") == "1"
+X_SKIP_BWD = os.environ.get("GEN_SKIP_BWD") == "1"
+X_FWD = set(os.environ.get("GEN_FWD_SKIP", "").split(","))   # forward-sweep parts to drop: store,pst,stage,read,xpart,upart
+X_TIMING = os.environ.get("GEN_TIMING") == "1"
+USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
+
 
 class Layout:
     def __init__(self, nx, nu):
@@ -63,6 +73,26 @@ class Layout:
         self.RING = max(DB * self.SLOT_B, DF * self.SLOT_F)
         assert self.ndma_b * 1024 - 1024 <= 4095 and ns + 1 <= 12 and nu in (1, 2)
         assert (DB - 1) * self.ndma_b <= 63 and (DF - 1) * self.ndma_f <= 63
+        # ---- F stash (registers instead of a second HBM read of F): per wave-step the F block of the slot
+        # (16*nF bytes) is read linearly, lane l taking bytes [w*l, w*l + w) of each piece
+        self.stash_ok = (64 % nx == 0)
+        fb = 16 * self.nF
+        self.stash_reads = []          # (bytes per lane, byte offset inside the F block)
+        off = 0
+        while fb - off >= 1024:
+            self.stash_reads.append((16, off))
+            off += 1024
+        rem = fb - off
+        if rem > 0:
+            w = 4 if rem <= 256 else (8 if rem <= 512 else 16)
+            self.stash_reads.append((w, off))
+        self.stash_regs = sum(w // 4 for w, _ in self.stash_reads)
+        self.NSTASH = min(256 // self.stash_regs - (1 if 256 % self.stash_regs == 0 else 0), 64)
+        self.STAGE = sum(64 * w for w, _ in self.stash_reads)   # bytes per forward staging buffer (two, in the ring)
+        self.RING = max(self.RING, 2 * self.STAGE)
+        self.SPD = 64 // nx                              # timesteps of f per DMA instruction
+        self.NFD = (self.NSTASH + 1 + self.SPD - 1) // self.SPD
+        self.FAREA = self.NFD * 1024                     # bytes of f per wave: f[tt] at tt * nx * 16
 
 
 class Prog:
@@ -72,13 +102,14 @@ class Prog:
         self.lines = []
         self.age = {}       # vgpr -> wait states since a VALU wrote it
         self.trans = {}     # vgpr -> wait states since a transcendental wrote it
+        self.mf = {}        # vgpr -> wait states since an MFMA wrote it
         self.n_instr = 0
 
     def _tick(self, n=1):
-        for d in (self.age, self.trans):
+        for d in (self.age, self.trans, self.mf):
             for r in list(d):
                 d[r] += n
-                if d[r] > 8:
+                if d[r] > 12:
                     del d[r]
 
     def raw(self, text, ticks=1):
@@ -98,6 +129,7 @@ class Prog:
         if reset:  # anything may have been written right before a jump here
             self.age = {"*": 0}
             self.trans = {"*": 0}
+            self.mf = {"*": 0}
 
     def exec_written(self):
         # SALU write of EXEC -> DPP: not a documented hazard (the documented one is a VALU write, 5 wait states);
@@ -109,7 +141,31 @@ class Prog:
         if have < states:
             self.nop(states - have)
 
+    def mfma(self, dst, a, b, c, abid):
+        """v_mfma_f32_4x4x1_16b_f32 dst[4], a, b, c[4] | 0, A broadcast from block `abid` of each 16-lane row.
+        Wait states kept (the ISA's own numbers for this 2-pass, non-XDL op are smaller: passes + 2 for a VALU
+        read of the result, passes for a dependent SrcC): 8 before anything but an accumulating MFMA reads an MFMA
+        result, 2 before a dependent accumulation, 2 after a VALU write of any source."""
+        for r in (a, b):
+            self._need(self.age, r, 2)
+            self._need(self.trans, r, 2)
+            self._need(self.mf, r, 8)
+        if c:
+            for r in c:
+                self._need(self.age, r, 2)
+                self._need(self.mf, r, 2)
+        self.raw("v_mfma_f32_4x4x1_16b_f32 %s, %s, %s, %s cbsz:2 abid:%d" % (vrange(dst), a, b, vrange(c) if c else "0", abid))
+        for r in dst:
+            self.mf[r] = 0
+
+    def uses(self, regs):
+        """a non-VALU instruction (LDS / memory) is about to read or overwrite these VGPRs"""
+        for r in regs:
+            self._need(self.mf, r, 8)
+
     def valu(self, text, writes=(), reads=(), dpp=None, trans=False):
+        for r in tuple(reads) + tuple(writes) + ((dpp,) if dpp else ()):
+            self._need(self.mf, r, 8)
         if dpp is not None:
             self._need(self.age, dpp, 2)
         for r in tuple(reads) + ((dpp,) if dpp else ()):
@@ -161,12 +217,13 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k):
+def gen_kernel(nx, nu, write_k, stash):
     L = Layout(nx, nu)
     ns, aff = L.ns, L.ns
+    assert not stash or L.stash_ok
     P = Prog()
     R = Regs(VBASE)
-    # ---- operand names (C++ side: struct LqrAsmIn of lqr_asm_kernel.hpp)
+    # ---- operand names (C++ side: struct LqrAsmIn of lqr_asm_gen.hpp, filled by lqr_asm_kernel.hpp)
     ptr = ["%%[ptr%d]" % q for q in range(L.ndma_b)]
     str1 = ["%%[str1_%d]" % q for q in range(L.ndma_b)]
     strd = ["%%[str%d]" % q for q in range(L.ndma_b)]
@@ -174,12 +231,16 @@ def gen_kernel(nx, nu, write_k):
     af = ["%%[af%d]" % k for k in range(nx)]
     fptr = ["%%[fptr%d]" % q for q in range(L.ndma_f)]
     fstr = ["%%[fstr%d]" % q for q in range(L.ndma_f)]
+    fp = ["%%[fp%d]" % q for q in range(L.NFD)]
     pk = ["%%[pk%d]" % m for m in range(nu)]
 
     # ---- fixed registers
-    Q = [R.take(ns) for _ in range(3)]
+    mfma = USE_MFMA and ns <= 12 and nx % 4 == 0
+    NQ = 4 * ((ns + 3) // 4)            # MFMA accumulator tiles are 4 consecutive rows
+    Q = [R.take(NQ if mfma else ns, align=4) for _ in range(3)]
     F = [R.take(nx) for _ in range(3)]
-    W = R.take(nx)
+    W = R.take(nx, align=4)             # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V)
+    G10 = R.take(1)[0]                  # MFMA path: row "1" of G^ = F^T v
     A = [R.take(nu) for _ in range(nu)]
     Kt = R.take(nu)
     Rr = R.take(nu)
@@ -187,14 +248,26 @@ def gen_kernel(nx, nu, write_k):
     MINPIV = R.take(1)[0]
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
     RF = Regs(VBASE)
-    M = [RF.take(ns, align=4), RF.take(ns, align=4)]
-    ACC = RF.take(3)
+    M = [RF.take(ns, align=4), RF.take(ns, align=4), RF.take(ns, align=4)]
+    ACC = RF.take(4)
     assert RF.next <= int(MINPIV[1:])
     last_vgpr = R.next - 1
     assert last_vgpr <= 255
 
+    # stash registers (AGPRs): piece p of stash slot j
+    def stash_reg(p, j):
+        base = 0
+        for pp in range(p):
+            base += (L.stash_reads[pp][0] // 4) * L.NSTASH
+        w = L.stash_reads[p][0] // 4
+        lo = base + j * w
+        return "a%d" % lo if w == 1 else "a[%d:%d]" % (lo, lo + w - 1)
+    n_agpr = L.stash_regs * L.NSTASH if stash else 0
+    assert n_agpr <= 256
+
     S_N, S_TF = "s70", "s71"
     S_KM, S_SM, S_UM = "s[72:73]", "s[74:75]", "s[76:77]"
+    S_RET, S_STUB, S_JMP, S_TMP = "s[78:79]", "s[80:81]", "s[82:83]", "s84"
 
     def mask64(lanes):
         m16 = sum(1 << l for l in lanes)
@@ -203,8 +276,11 @@ def gen_kernel(nx, nu, write_k):
     km = mask64(list(range(nx)) + [aff])
     sm = mask64(range(ns))
     um = mask64(range(nx, ns))
+    in_loop = [False]
 
     def issue_group(ptrs, slot, slot_bytes):
+        if X_NO_DMA and in_loop[0]:
+            return
         if slot == 0:
             P.raw("s_mov_b32 m0, %[ring]")
         else:
@@ -226,8 +302,15 @@ def gen_kernel(nx, nu, write_k):
         P.raw("s_sub_i32 %s, %s, 1" % (S_TF, S_TF))
         P.label(lab, reset=False)   # only pointer registers are written on the fall-through path
 
+    def vmwait(n):
+        if not ((X_NO_VMWAIT or X_NO_DMA) and in_loop[0]):
+            P.raw("s_waitcnt vmcnt(%d)" % n)
+
     def read_set(s, slot):
+        if X_NO_LDSREAD and in_loop[0]:
+            return
         off = slot * L.SLOT_B
+        P.uses(Q[s][:ns] + F[s])
         for i in range(ns):
             P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][i], aq[i], off))
         for k in range(nx):
@@ -299,13 +382,26 @@ def gen_kernel(nx, nu, write_k):
             for i in range(nx):
                 P.fmac_dpp(Qs[i], Kt[m], Rr[m], i)
 
-    def bstep(s, first):
+    def bstep(s, first, extra_outstanding=0):
         p, n = (s + 2) % 3, (s + 1) % 3
         V = Q[p]
         P.raw("s_waitcnt lgkmcnt(0)")
         issue_group(ptr, s, L.SLOT_B)
         advance(ptr, strd)
-        if not first:
+        if not first and mfma:
+            # Q~ += F~^T V^ F^ as (V^^T F^)^T F^ - both products have the A^T B shape that an outer-product MFMA
+            # computes from column-per-lane registers (A operand = 4 lanes of a register = 4 rows of A^T):
+            #   G[b][j]  = sum_a V[a][b] F~[a][j]      rows b = x columns: tiles of 4, A = V[a] block b/4, B = F~[a]
+            #   g1[j]    = sum_a v[a] F~[a][j]         the row of the homogeneous coordinate (8 DPP FMAs)
+            # This is the reference's own association, (F^T V) F  (lqr_recursion.py:89,96).
+            P.mul_dpp(G10, V[0], F[s][0], aff)
+            for a_ in range(1, nx):
+                P.fmac_dpp(G10, V[a_], F[s][a_], aff)
+            for a_ in range(nx):
+                for I in range(nx // 4):
+                    Gt = W[4 * I:4 * I + 4]
+                    P.mfma(Gt, V[a_], F[s][a_], Gt if a_ else None, I)
+        elif not first:
             # W~ = V~ F~  (+ v in column aff):  W[i] = sum_k bcast<k>(V[i]) F[k] + bcast<aff>(V[i]) e_aff
             for i in range(nx):
                 P.mul_dpp(W[i], V[i], F[s][0], 0)
@@ -314,9 +410,25 @@ def gen_kernel(nx, nu, write_k):
                     P.fmac_dpp(W[i], V[i], F[s][k], k)
             for i in range(nx):
                 P.fmac_dpp(W[i], V[i], "%[eaff]", aff)
-        P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * L.ndma_b))
+        vmwait((DB - 1) * L.ndma_b + extra_outstanding)
         read_set(n, n)
-        if not first:
+        if stash:
+            # F of the NEXT step goes from its ring slot into this step's stash registers: the register numbers
+            # differ per step, so the two reads live in a table of stubs (one per step) that is called here
+            P.raw("s_swappc_b64 %s, %s" % (S_RET, S_STUB))
+            lo = int(S_STUB[2:S_STUB.index(":")])
+            P.raw("s_add_u32 s%d, s%d, %d" % (lo, lo, BSTUB))
+            P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+        if not first and mfma:
+            #   Q~[i][j] += sum_b G[b][i] F~[b][j] + g1[i] e_aff[j]    tiles of 4 rows i: A = G[b] block i/4, B = F~[b]
+            for b_ in range(nx):
+                for I in range(NQ // 4):
+                    Qt = Q[s][4 * I:4 * I + 4]
+                    P.mfma(Qt, W[b_], F[s][b_], Qt, I)
+            for I in range(NQ // 4):
+                Qt = Q[s][4 * I:4 * I + 4]
+                P.mfma(Qt, G10, "%[eaff]", Qt, I)
+        elif not first:
             # Q~ += F~^T W~ ; the u-rows first in the last pass so that the Quu broadcasts need no wait states
             for k in range(nx):
                 order = list(range(ns)) if k < nx - 1 else list(range(nx, ns)) + list(range(nx))
@@ -325,9 +437,22 @@ def gen_kernel(nx, nu, write_k):
         gains(s)
         vupdate(s)
 
+    BSTUB = 32     # bytes per backward stub (two LDS reads + s_setpc_b64 = 20)
+    assert 8 * len(L.stash_reads) + 4 <= BSTUB
+
+    TS = R.take(4) if X_TIMING else []
+    last_vgpr = R.next - 1
+
+    def stamp(i):
+        if X_TIMING:
+            P.raw("s_memtime s[86:87]")
+            P.raw("s_waitcnt lgkmcnt(0)")
+            P.v("v_mov_b32_e32 %s, s86" % TS[i], writes=(TS[i],))
+
     # =============================================================== backward sweep
     P.comment("---- prologue")
     P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    stamp(0)
     for name, val in ((S_KM, km), (S_SM, sm), (S_UM, um)):
         lo = int(name[2:name.index(":")])
         P.raw("s_mov_b32 s%d, 0x%x" % (lo, val & 0xffffffff))
@@ -335,40 +460,56 @@ def gen_kernel(nx, nu, write_k):
     for m in range(nu):
         P.v("v_mov_b32_e32 %s, 0" % Kt[m], writes=(Kt[m],))
     P.v("v_mov_b32_e32 %s, 0x7f7fffff" % MINPIV, writes=(MINPIV,))
+    if stash:
+        lo = int(S_STUB[2:S_STUB.index(":")])
+        P.raw("s_getpc_b64 " + S_STUB)
+        P.label("Lpcb_%=", reset=False)
+        P.raw("s_add_u32 s%d, s%d, Lbstub_%%=-Lpcb_%%=" % (lo, lo))
+        P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
     P.raw("s_sub_i32 %s, %%[T], 1" % S_TF)
     issue_group(ptr, 0, L.SLOT_B)
     advance(ptr, str1)
     for j in range(1, DB):
         issue_group(ptr, j, L.SLOT_B)
         advance(ptr, strd)
-    P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * L.ndma_b))
+    n_extra = 0
+    if stash:
+        # all of f (the forward sweep's only input from memory) goes to LDS now, BEHIND the first groups: the
+        # backward sweep's first two waits allow for these NFD younger operations, later ones are merely conservative
+        n_extra = L.NFD
+        for q in range(L.NFD):
+            if q == 0:
+                P.raw("s_mov_b32 m0, %[farea]")
+            else:
+                P.raw("s_add_u32 m0, %%[farea], %d" % (q * 1024))
+            P.nop(1)
+            P.raw("global_load_lds_dwordx4 %s, off" % fp[q])
+    P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * L.ndma_b + n_extra))
     read_set(0, 0)
-    P.raw("s_sub_i32 %s, %%[T], 1" % S_N)      # steps left after the first
+    P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
     P.comment("---- t = T-1")
-    bstep(0, True)
+    stamp(1)
+    bstep(0, True, n_extra)
+    if X_SKIP_BWD:
+        P.raw("s_branch Lbwd_done_%=")
+    in_loop[0] = True
     P.label("Lbwd_%=")
     for s in (1, 2, 0):
         P.comment("---- backward step, register set %d" % s)
         bstep(s, False)
-        P.raw("s_sub_i32 %s, %s, 1" % (S_N, S_N))
-        P.raw("s_cmp_lg_u32 %s, 0" % S_N)
+        P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
         if s != 0:
-            P.raw("s_cbranch_scc0 Lbwd_done_%=")
+            P.raw("s_cbranch_scc1 Lbwd_done_%=")
         else:
-            P.raw("s_cbranch_scc1 Lbwd_%=")
+            P.raw("s_cbranch_scc0 Lbwd_%=")
     P.label("Lbwd_done_%=")
+    in_loop[0] = False
     n_bwd = P.n_instr
 
     # =============================================================== forward rollout
-    P.comment("---- forward rollout")
-    P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    P.raw("s_sub_i32 %s, %%[T], 2" % S_TF)
-    for j in range(DF):
-        issue_group(fptr, j, L.SLOT_F)
-        advance(fptr, fstr)
-    P.raw("s_waitcnt vmcnt(%d)" % ((DF - 1) * L.ndma_f))
-
     def read_rows(c, a):
+        if X_NO_LDSREAD and in_loop[0]:
+            return
         Mc = M[c]
         if ns % 2 == 0:
             i = 0
@@ -386,64 +527,195 @@ def gen_kernel(nx, nu, write_k):
                 P.raw("ds_read_b32 %s, %%[arow] offset:%d" % (Mc[i], i * 4))
         P.raw("ds_read_b32 %s, %%[aaff]" % ACC[a])
 
-    read_rows(0, 0)
-    P.v("v_mov_b32_e32 %s, %%[xv]" % ACC[2], writes=(ACC[2],))
-    P.raw("s_sub_i32 %s, %%[T], 1" % S_N)      # full steps t = 0 .. T-2
-    P.raw("s_cmp_lg_u32 %s, 0" % S_N)
-    P.raw("s_cbranch_scc0 Lfin0_%=")
-    P.label("Lfwd_%=")
-    n_fwd0 = P.n_instr
-    for j in range(DF):
-        c, a = j % 2, j % 3
-        o, an, ap = 1 - c, (a + 1) % 3, (a + 2) % 3
-        P.comment("---- forward step, slot %d" % j)
-        P.raw("s_waitcnt lgkmcnt(0)")
-        issue_group(fptr, j, L.SLOT_F)
-        advance(fptr, fstr)
-        P.raw("s_waitcnt vmcnt(%d)" % ((DF - 1) * L.ndma_f))
-        d = "2" if j == DF - 1 else ""
-        P.v("v_add_u32_e32 %%[arow], %%[drow%s], %%[arow]" % d)
-        P.v("v_add_u32_e32 %%[aaff], %%[daff%s], %%[aaff]" % d)
-        read_rows(o, an)
+    def fcompute(c, a, ap, mask, last, fillers=()):
+        """fillers: independent work emitted in the wait states between the dependent control FMAs"""
+        fillers = list(fillers)
+        skip = X_FWD if in_loop[0] else set()
         for jj in range(nx):                       # u_t = K_t x_t + k_t (lanes nx+m) ; f_t + Fx x_t (lanes < nx)
-            P.fmac_dpp(ACC[a], ACC[ap], M[c][jj], jj)
-        for m in range(nu):                        # x_{t+1} += Fu u_t : the gain rows hold 0 in these columns
-            P.fmac_dpp(ACC[a], ACC[a], M[c][nx + m], nx + m)
-        P.raw("s_mov_b64 exec, " + S_SM)
-        P.raw("global_store_dword %%[pst], %s, off" % ACC[a])
-        P.raw("s_mov_b64 exec, -1")
-        P.v("v_lshl_add_u64 %[pst], %[pst], 0, %[dst]")
-        P.raw("s_sub_i32 %s, %s, 1" % (S_N, S_N))
+            if "xpart" not in skip:
+                P.fmac_dpp(ACC[a], ACC[ap], M[c][jj], jj)
+        if not last:
+            for m in range(nu):                    # x_{t+1} += Fu u_t : the gain rows hold 0 in these columns
+                if fillers:
+                    fillers.pop(0)()
+                if "upart" not in skip:
+                    P.fmac_dpp(ACC[a], ACC[a], M[c][nx + m], nx + m)
+        for f in fillers:
+            f()
+        if "store" not in skip:
+            P.raw("s_mov_b64 exec, " + mask)
+            P.raw("global_store_dword %%[pst], %s, off" % ACC[a])
+            P.raw("s_mov_b64 exec, -1")
+            P.exec_written()
+        if not last and "pst" not in skip:
+            P.v("v_lshl_add_u64 %[pst], %[pst], 0, %[dst]")
+
+    P.comment("---- forward rollout")
+    stamp(2)
+    P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    if not stash:
+        P.raw("s_sub_i32 %s, %%[T], 2" % S_TF)
+        for j in range(DF):
+            issue_group(fptr, j, L.SLOT_F)
+            advance(fptr, fstr)
+        P.raw("s_waitcnt vmcnt(%d)" % ((DF - 1) * L.ndma_f))
+        read_rows(0, 0)
+        P.v("v_mov_b32_e32 %s, %%[xv]" % ACC[2], writes=(ACC[2],))
+        P.raw("s_sub_i32 %s, %%[T], 1" % S_N)      # full steps t = 0 .. T-2
         P.raw("s_cmp_lg_u32 %s, 0" % S_N)
-        if j < DF - 1:
-            P.raw("s_cbranch_scc0 Lfin%d_%%=" % (j + 1))
-        else:
-            P.raw("s_cbranch_scc1 Lfwd_%=")
+        P.raw("s_cbranch_scc0 Lfin0_%=")
+        if X_SKIP_FWD:
             P.raw("s_branch Lfin0_%=")
-    n_fwd = P.n_instr - n_fwd0
-    for j in range(DF):                            # t = T-1: only u_{T-1}
-        c, a = j % 2, j % 3
-        ap = (a + 2) % 3
-        P.label("Lfin%d_%%=" % j)
+        in_loop[0] = True
+        P.label("Lfwd_%=")
+        n_fwd0 = P.n_instr
+        for j in range(DF):
+            c, a = j % 2, j % 3
+            o, an, ap = 1 - c, (a + 1) % 3, (a + 2) % 3
+            P.comment("---- forward step, slot %d" % j)
+            P.raw("s_waitcnt lgkmcnt(0)")
+            issue_group(fptr, j, L.SLOT_F)
+            advance(fptr, fstr)
+            vmwait((DF - 1) * L.ndma_f)
+            d = "2" if j == DF - 1 else ""
+            P.v("v_add_u32_e32 %%[arow], %%[drow%s], %%[arow]" % d)
+            P.v("v_add_u32_e32 %%[aaff], %%[daff%s], %%[aaff]" % d)
+            read_rows(o, an)
+            fcompute(c, a, ap, S_SM, False)
+            P.raw("s_sub_i32 %s, %s, 1" % (S_N, S_N))
+            P.raw("s_cmp_lg_u32 %s, 0" % S_N)
+            if j < DF - 1:
+                P.raw("s_cbranch_scc0 Lfin%d_%%=" % (j + 1))
+            else:
+                P.raw("s_cbranch_scc1 Lfwd_%=")
+                P.raw("s_branch Lfin0_%=")
+        n_fwd = P.n_instr - n_fwd0
+        n_fwd_steps = DF
+        in_loop[0] = False
+        for j in range(DF):                            # t = T-1: only u_{T-1}
+            c, a = j % 2, j % 3
+            ap = (a + 2) % 3
+            P.label("Lfin%d_%%=" % j)
+            P.raw("s_waitcnt lgkmcnt(0)")
+            fcompute(c, a, ap, S_UM, True)
+            P.v("v_mov_b32_e32 %%[xvout], %s" % ACC[a])
+            P.raw("s_branch Ldone_%=")
+    else:
+        # F comes back from the stash registers through two staging buffers in the (now idle) ring: the code is
+        # unrolled over n = T-1-t (the stash slot is a register NUMBER), entered at n = T-1 through a table of
+        # entry stubs, and runs down to n = 1 without any loop control; n = 0 is the u-only step t = T-1.
+        # Rows are prepared TWO steps ahead (three row sets, four accumulators): a step is only ~25 instructions,
+        # shorter than the LDS round trip stash -> staging -> rows.
+        def sets(n):
+            return n % 3, n % 4, (n + 1) % 4     # row set, accumulator, x_t register of step n
+
+        def stage_write(n):
+            """stash slot n-1 (F of step n) -> staging buffer n % 2"""
+            if "stage" in X_FWD and in_loop[0]:
+                return
+            for p, (w, off) in enumerate(L.stash_reads):
+                op = {4: "ds_write_b32", 8: "ds_write_b64", 16: "ds_write_b128"}[w]
+                P.raw("%s %%[fr%d], %s offset:%d" % (op, w, stash_reg(p, n - 1), (n % 2) * L.STAGE + off))
+
+        n_rowreads = (ns + 3) // 4 + (1 if ns % 4 in (1, 2, 3) and ns % 2 == 0 and ns % 4 else 0)
+
+        def prefetch_a(m, move=True):
+            """first half of the preparation of step m (>= 0): stage F, move the row pointers"""
+            if m >= 1:
+                stage_write(m)
+            if move:   # the row pointers go from step m+1 to step m
+                P.v("v_add_u32_e32 %%[arow], %%[drow%s], %%[arow]" % ("o" if (m + 1) % 2 else "e"))
+                P.v("v_add_u32_e32 %[aaff], %[daff], %[aaff]")
+
+        def prefetch_b(m):
+            c, a, _ = sets(m)
+            if not ("read" in X_FWD and in_loop[0]):
+                read_rows(c, a)
+
+        def prefetch(m, move=True):
+            """stage + read the rows of step m (>= 0); returns the number of LDS operations issued"""
+            before = len(P.lines)
+            prefetch_a(m, move)
+            prefetch_b(m)
+            return sum(1 for ln in P.lines[before:] if ln.startswith("ds_"))
+
+        def group_size(m):      # LDS operations of prefetch(m), without emitting anything
+            if m < 0:
+                return 0
+            save = (list(P.lines), P.n_instr, dict(P.age), dict(P.trans))
+            k = prefetch(m)
+            P.lines, P.n_instr, P.age, P.trans = save
+            return k
+
+        FSTUB = 64
+        while FSTUB < 8 * (2 * (len(L.stash_reads) + ns // 2 + 2) + 4):
+            FSTUB *= 2
+        lo = int(S_JMP[2:S_JMP.index(":")])
+        P.raw("s_getpc_b64 " + S_JMP)
+        P.label("Lpcf_%=", reset=False)
+        P.raw("s_sub_i32 %s, %%[T], 2" % S_TMP)                 # entry stub index: (T-1) - 1
+        P.raw("s_mul_i32 %s, %s, %d" % (S_TMP, S_TMP, FSTUB))
+        P.raw("s_add_u32 s%d, s%d, Lfstub_%%=-Lpcf_%%=" % (lo, lo))
+        P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+        P.raw("s_add_u32 s%d, s%d, %s" % (lo, lo, S_TMP))
+        P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+        P.raw("s_setpc_b64 " + S_JMP)
+        n_fwd0 = P.n_instr
+        in_loop[0] = True
+        for n in range(L.NSTASH, 0, -1):
+            c, a, ap = sets(n)
+            P.label("Lfs%d_%%=" % n)
+            P.raw("s_waitcnt lgkmcnt(%d)" % group_size(n - 1))   # rows of step n are in; those of n-1 may be in flight
+            fill = []
+            if n >= 2:
+                fill = [lambda m=n - 2: prefetch_a(m), lambda m=n - 2: prefetch_b(m)]
+                if nu == 1:
+                    fill = [lambda m=n - 2: prefetch(m)]
+            fcompute(c, a, ap, S_SM, False, fill)
+        n_fwd = P.n_instr - n_fwd0
+        n_fwd_steps = L.NSTASH
+        in_loop[0] = False
+        c, a, ap = sets(0)
         P.raw("s_waitcnt lgkmcnt(0)")
-        for jj in range(nx):
-            P.fmac_dpp(ACC[a], ACC[ap], M[c][jj], jj)
-        P.raw("s_mov_b64 exec, " + S_UM)
-        P.raw("global_store_dword %%[pst], %s, off" % ACC[a])
-        P.raw("s_mov_b64 exec, -1")
+        fcompute(c, a, ap, S_UM, True)
         P.v("v_mov_b32_e32 %%[xvout], %s" % ACC[a])
         P.raw("s_branch Ldone_%=")
+        # ---- entry stubs: stage F of the first two steps, read their rows, place x_init
+        P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
+        P.label("Lfstub_%=")
+        for n in range(1, L.NSTASH + 1):
+            c, a, ap = sets(n)
+            P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
+            prefetch(n, move=False)
+            prefetch(n - 1)
+            P.v("v_mov_b32_e32 %s, %%[xv]" % ACC[ap], writes=(ACC[ap],))
+            P.raw("s_branch Lfs%d_%%=" % n)
+        # ---- backward stubs: F block of ring slot (n % 3) -> stash slot n-1
+        P.lines.append(".p2align 5")
+        P.label("Lbstub_%=")
+        for n in range(1, L.NSTASH + 1):
+            P.lines.append(".p2align 5")
+            for p, (w, off) in enumerate(L.stash_reads):
+                op = {4: "ds_read_b32", 8: "ds_read_b64", 16: "ds_read_b128"}[w]
+                P.raw("%s %s, %%[fr%d] offset:%d" % (op, stash_reg(p, n - 1), w, (n % 3) * L.SLOT_B + L.OFF_F + off))
+            P.raw("s_setpc_b64 " + S_RET)
     P.label("Ldone_%=")
     P.v("v_mov_b32_e32 %%[minpiv], %s" % MINPIV)
     P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    stamp(3)
+    for i in range(len(TS)):
+        P.v("v_mov_b32_e32 %%[ts%d], %s" % (i, TS[i]))
 
     # ---- operand lists
     outs = [("xvout", '"=&v"(xvout)'), ("minpiv", '"=&v"(minpiv)')]
+    if X_TIMING:
+        outs += [("ts%d" % i, '"=&v"(in.ts[%d])' % i) for i in range(4)]
     rw = []
     for q in range(L.ndma_b):
         rw.append(("ptr%d" % q, '"+v"(in.ptr[%d])' % q))
-    for q in range(L.ndma_f):
-        rw.append(("fptr%d" % q, '"+v"(in.fptr[%d])' % q))
+    if not stash:
+        for q in range(L.ndma_f):
+            rw.append(("fptr%d" % q, '"+v"(in.fptr[%d])' % q))
     rw += [("ak", '"+v"(in.ak)'), ("arow", '"+v"(in.arow)'), ("aaff", '"+v"(in.aaff)'), ("pst", '"+v"(in.pst)')]
     if write_k:
         for m in range(nu):
@@ -452,30 +724,41 @@ def gen_kernel(nx, nu, write_k):
     for q in range(L.ndma_b):
         ins.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
         ins.append(("str%d" % q, '"v"(in.str[%d])' % q))
-    for q in range(L.ndma_f):
-        ins.append(("fstr%d" % q, '"v"(in.fstr[%d])' % q))
     for i in range(ns):
         ins.append(("aq%d" % i, '"v"(in.aq[%d])' % i))
     for k in range(nx):
         ins.append(("af%d" % k, '"v"(in.af[%d])' % k))
-    ins += [("eaff", '"v"(in.eaff)'), ("drow", '"v"(in.drow)'), ("drow2", '"v"(in.drow2)'),
-            ("daff", '"v"(in.daff)'), ("daff2", '"v"(in.daff2)'), ("dst", '"v"(in.dst)'), ("xv", '"v"(in.xv)')]
+    ins += [("eaff", '"v"(in.eaff)'), ("dst", '"v"(in.dst)'), ("xv", '"v"(in.xv)')]
+    if stash:
+        for q in range(L.NFD):
+            ins.append(("fp%d" % q, '"v"(in.fp[%d])' % q))
+        for w in sorted(set(w for w, _ in L.stash_reads)):
+            ins.append(("fr%d" % w, '"v"(in.fr%d)' % w))
+        ins += [("drowo", '"v"(in.drow)'), ("drowe", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'),
+                ("farea", '"s"(in.farea)')]
+    else:
+        for q in range(L.ndma_f):
+            ins.append(("fstr%d" % q, '"v"(in.fstr[%d])' % q))
+        ins += [("drow", '"v"(in.drow)'), ("drow2", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'), ("daff2", '"v"(in.daff2)')]
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)')]
-    clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"s70"', '"s71"', '"s72"', '"s73"', '"s74"', '"s75"',
-                                                                 '"s76"', '"s77"', '"vcc"', '"scc"', '"memory"']
+    clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
+        ['"s%d"' % i for i in range(70, 88)] + ['"vcc"', '"scc"', '"memory"']
 
-    name = "LqrAsm<%d, %d, %s>" % (nx, nu, "true" if write_k else "false")
+    tf = lambda b: "true" if b else "false"
+    name = "LqrAsm<%d, %d, %s, %s>" % (nx, nu, tf(write_k), tf(stash))
     o = []
-    o.append("// (%d,%d) write_k=%d: %d instructions in the 3 unrolled backward steps + prologue, %d in the %d unrolled\n"
-             "// forward steps\n" % (nx, nu, write_k, n_bwd, n_fwd, DF))
+    o.append("// (%d,%d) write_k=%d stash=%d: %d instructions in prologue + 4 backward steps, %d in %d unrolled forward steps\n"
+             % (nx, nu, write_k, stash, n_bwd, n_fwd, n_fwd_steps))
     o.append("template <>\nstruct %s {\n" % name)
     o.append("  static constexpr bool kAvailable = true;\n")
     o.append("  static constexpr int NDB = %d, NDF = %d, SLOT_B = %d, SLOT_F = %d, RING_BYTES = %d, KROW = %d, DEPTH_F = %d;\n"
              % (L.ndma_b, L.ndma_f, L.SLOT_B, L.SLOT_F, L.RING, KROW, DF))
     o.append("  static constexpr int OFF_C = %d, OFF_c = %d, OFF_F = %d, OFF_f = %d, FOFF_f = %d;\n"
              % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
+    o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, STAGE = %d, SPD = %d;\n"
+             % (L.NSTASH, L.NFD, L.FAREA, L.STAGE, L.SPD))
     o.append("  static __device__ __forceinline__ void run(LqrAsmIn<%d, %d> &in, float &xvout, float &minpiv) {\n" % (nx, nu))
     o.append("    asm volatile(\n")
     for ln in P.text():
@@ -489,7 +772,7 @@ def gen_kernel(nx, nu, write_k):
 
 HEADER = """// lqr_asm_gen.hpp - GENERATED by gen_lqr_asm.py; do not edit.
 // Whole-kernel gfx950 instruction streams of the fused LQR solve (lqr/lqr_recursion.py:69-209 of the reference),
-// 16-lane row layout, one per (nx, nu, write_k).  The C++ side that prepares the per-lane operands is
+// 16-lane row layout, one per (nx, nu, write_k, stash).  The C++ side that prepares the per-lane operands is
 // lqr_asm_kernel.hpp.
 #pragma once
 #include <cstdint>
@@ -507,16 +790,20 @@ struct LqrAsmIn {
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
   // forward sweep
-  uint64_t fptr[2], fstr[2];
+  uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
+  uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
+  unsigned fr4, fr8, fr16;           // stash variant: ring + lane64 * {4, 8, 16} (linear piece addresses)
+  unsigned farea;                    // stash variant (wave-uniform): LDS byte address of this wave's f area
   unsigned arow, aaff, drow, drow2, daff, daff2;
   uint64_t pst, dst;                 // [x_{t+1} | u_t] store pointer and time stride
   float xv;                          // x_init in lanes < nx
   // wave-uniform
   unsigned ring;                     // LDS byte address of this wave's ring
   int T;
+  unsigned ts[4];                    // GEN_TIMING builds only: s_memtime at the phase boundaries
 };
 
-template <int NX, int NU, bool WRITE_K>
+template <int NX, int NU, bool WRITE_K, bool STASH>
 struct LqrAsm {
   static constexpr bool kAvailable = false;
 };
@@ -525,10 +812,17 @@ struct LqrAsm {
 
 
 def main():
-    out = [HEADER]
+    import sys
+    global OUT
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":
+        OUT = sys.argv[2]
+    out = [HEADER.replace("#pragma once\n", "#pragma once\n#define DMPC_ASM_TIMING_GEN 1\n") if X_TIMING else HEADER]
     for nx, nu in SHAPES:
         for write_k in (False, True):
-            out.append(gen_kernel(nx, nu, write_k))
+            for stash in (False, True):
+                if stash and not Layout(nx, nu).stash_ok:
+                    continue
+                out.append(gen_kernel(nx, nu, write_k, stash))
     out.append("}  // namespace dmpc\n")
     with open(OUT, "w") as fh:
         fh.write("".join(out))

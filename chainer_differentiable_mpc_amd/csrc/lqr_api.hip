@@ -28,6 +28,10 @@ static bool asm_path_disabled() {  // DMPC_NO_ASM=1 forces the HIP kernels (A/B 
   static const bool off = [] { const char *e = getenv("DMPC_NO_ASM"); return e && e[0] == '1'; }();
   return off;
 }
+static bool stash_disabled() {  // DMPC_NO_STASH=1: forward sweep re-reads F by LDS-DMA (A/B timing)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_STASH"); return e && e[0] == '1'; }();
+  return off;
+}
 static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
   static const bool off = [] { const char *e = getenv("DMPC_NO_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -41,19 +45,29 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
 #define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
   hipLaunchKernelGGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
-  if constexpr (L == 16 && LqrAsm<NX, NU, false>::kAvailable) {
-    // fastest path: the whole solve as one generated instruction stream (lqr_asm_kernel.hpp)
-    if (mode == kSolve && !masked && a.B >= 4 && a.T >= 2 && lqr_asm_lds_bytes<NX, NU>(a.T) <= kAsmLdsBudget &&
-        !asm_path_disabled()) {
+  if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
+    // fastest path: the whole solve as one generated instruction stream (lqr_asm_kernel.hpp); with the F stash
+    // (no second read of F) when the horizon fits the stash registers
+    if (mode == kSolve && !masked && a.B >= 4 && a.T >= 2 && !asm_path_disabled()) {
       const int waves = (a.B + 3) / 4;
       const dim3 g((waves + 3) / 4);
-      const size_t shmem = lqr_asm_lds_bytes<NX, NU>(a.T);
       const bool has_f = a.f != nullptr, write_k = a.Ks != nullptr;
-      if (has_f && !write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false>), g, block, shmem, stream, a);
-      else if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true>), g, block, shmem, stream, a);
-      else if (!write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false>), g, block, shmem, stream, a);
-      else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true>), g, block, shmem, stream, a);
-      return (int)hipGetLastError();
+#define DMPC_ASM_LAUNCH(STASH)                                                                                   \
+  do {                                                                                                           \
+    const size_t shmem = lqr_asm_lds_bytes<NX, NU, STASH>(a.T);                                                  \
+    if (has_f && !write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, STASH>), g, block, shmem, stream, a); \
+    else if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, STASH>), g, block, shmem, stream, a); \
+    else if (!write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, STASH>), g, block, shmem, stream, a); \
+    else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, STASH>), g, block, shmem, stream, a);           \
+    return (int)hipGetLastError();                                                                               \
+  } while (0)
+      if constexpr (LqrAsm<NX, NU, false, true>::kAvailable) {
+        if (a.T <= LqrAsm<NX, NU, false, true>::NSTASH && lqr_asm_lds_bytes<NX, NU, true>(a.T) <= kAsmLdsBudget &&
+            !stash_disabled())
+          DMPC_ASM_LAUNCH(true);
+      }
+      if (lqr_asm_lds_bytes<NX, NU, false>(a.T) <= kAsmLdsBudget) DMPC_ASM_LAUNCH(false);
+#undef DMPC_ASM_LAUNCH
     }
   }
   if constexpr (L == 16) {

@@ -8,10 +8,16 @@
 // affine terms in lane ns.  What differs is that nothing is left to the compiler between the first DMA and
 // the last store - with one wavefront per SIMD the kernel's time is its instruction count.
 //
+// Two variants of the forward sweep.  Ring: F and f are fetched a second time by LDS-DMA (any T whose gains fit
+// in LDS).  Stash (T <= NSTASH): while the backward sweep has F_t in its ring slot it also parks the block in
+// accumulation registers (AGPRs, 5 per step at (8,2) - the one on-chip store large enough: 251 KB per CU), f is
+// fetched once more into LDS by a handful of DMAs in the prologue, and the forward sweep reads no F from memory at
+// all - it is bandwidth bound otherwise (70 MB at the headline shape, a third of the kernel's traffic).
+//
 // LDS (dynamic), per 256-thread workgroup:
 //   [0, 4*RING)                    one ring per wave: DB backward slots [C|c|F|f] of the wave's 4 trajectories,
-//                                  later DF forward slots [F|f]; kept below 64 KB (M0 carries the DMA target)
-//   [4*RING, +64)                  unused
+//                                  later DF forward slots [F|f] (ring) or two F staging buffers (stash)
+//   [.., + 4*FAREA)                stash only: f of all timesteps of the wave's 4 trajectories
 //   [.., + 16*T*NU*KROW*4)         gain rows [K_m | 0 | k_m | pad] per trajectory, time-major, zero-initialised
 #pragma once
 #include "colwise.hpp"
@@ -25,19 +31,19 @@ namespace dmpc {
 // segment (the library allocates nothing), so that the stream itself has no "f is absent" case.
 __device__ const float4 dmpc_zero_chunks[16] = {};
 
-template <int NX, int NU>
+template <int NX, int NU, bool STASH>
 constexpr size_t lqr_asm_lds_bytes(int T) {
-  using G = LqrAsm<NX, NU, false>;
-  return (size_t)4 * G::RING_BYTES + 64 + (size_t)16 * T * NU * G::KROW * 4;
+  using G = LqrAsm<NX, NU, false, STASH>;
+  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) + (size_t)16 * T * NU * G::KROW * 4;
 }
 
-template <int NX, int NU, bool HAS_F, bool WRITE_K>
+template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
-  using G = LqrAsm<NX, NU, WRITE_K>;
+  using G = LqrAsm<NX, NU, WRITE_K, STASH>;
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU, AFF = NS, KROW = G::KROW;
   constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
-  static_assert(4 * G::RING_BYTES <= 65536, "DMA targets must stay below 64 KB");
+  // (M0 carries the LDS-DMA target; it reaches all 160 KB - scripts/microbench/m0_range.hip)
 
   const int T = a.T;
   const size_t B = (size_t)a.B;
@@ -53,7 +59,9 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   extern __shared__ float lds[];
   const unsigned lds0 = lds_byte_address(lds);
   const unsigned ring = lds0 + (unsigned)wave * G::RING_BYTES;
-  const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + 64u + (unsigned)(wave * 4) * (unsigned)(T * NU * KROW * 4);
+  const unsigned farea = lds0 + 4u * G::RING_BYTES + (unsigned)wave * (STASH ? G::FAREA_BYTES : 0);
+  const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + (STASH ? 4u * G::FAREA_BYTES : 0u) +
+                             (unsigned)(wave * 4) * (unsigned)(T * NU * KROW * 4);
   const unsigned gain_traj = gain_wave + (unsigned)r * (unsigned)(T * NU * KROW * 4);
 
   {  // zero this wave's gain rows (columns nx..ns-1 and the pad are never written afterwards)
@@ -124,33 +132,57 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     in.dk = 0;
   }
 
-  // ---- forward DMA: chunk g of the slot [F | f]
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (q >= G::NDF) {
-      in.fptr[q] = in.fstr[q] = 0;
-      continue;
-    }
-    const int g = q * 64 + lane64;
-    const char *base = Fb;
-    size_t per = (size_t)NX * NS * 4, off = 0;
-    if (g < nF) {
-      off = (size_t)g * 16;
-    } else if (g < nF + nf) {
-      base = fb; per = per_f; off = (size_t)(g - nF) * 16;
-    }
-    in.fptr[q] = reinterpret_cast<uint64_t>(base) + (size_t)b0 * per + off - (uint64_t)q * 1024u;
-    in.fstr[q] = (uint64_t)(B * per);
-  }
   // lane i < nx: row i of [F_t | f_t]; lane nx+m: gain row m; the other lanes shadow the last gain row
   const bool row_x = lane < NX;
   const int m_own = row_x ? 0 : (lane < NS ? lane - NX : NU - 1);
-  in.arow = row_x ? ring + (unsigned)((r * NX + lane) * NS * 4) : gain_traj + (unsigned)(m_own * KROW * 4);
-  in.aaff = row_x ? ring + (unsigned)(G::FOFF_f + (r * NX + lane) * 4) : in.arow + (unsigned)(NS * 4);
-  in.drow = row_x ? (unsigned)G::SLOT_F : (unsigned)(NU * KROW * 4);
-  in.drow2 = row_x ? (unsigned)G::SLOT_F - (unsigned)(G::DEPTH_F * G::SLOT_F) : (unsigned)(NU * KROW * 4);
-  in.daff = in.drow;
-  in.daff2 = in.drow2;
+  const unsigned arow_u = gain_traj + (unsigned)(m_own * KROW * 4);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) in.fptr[q] = in.fstr[q] = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) in.fp[q] = 0;
+  in.fr4 = ring + (unsigned)lane64 * 4u;
+  in.fr8 = ring + (unsigned)lane64 * 8u;
+  in.fr16 = ring + (unsigned)lane64 * 16u;
+  in.farea = __builtin_amdgcn_readfirstlane(farea);
+  if constexpr (STASH) {
+    // f of timestep tt (the wave's 4 trajectories, nx chunks) lives at farea + tt*nx*16: DMA q brings SPD steps
+    static_assert(G::NFD <= 8 && 64 % NX == 0, "f area layout");
+#pragma unroll
+    for (int q = 0; q < G::NFD; ++q) {
+      int tt = q * G::SPD + lane64 / NX;
+      if (tt > T - 2) tt = T - 2;  // nothing past f_{T-2} exists (or is read)
+      in.fp[q] = reinterpret_cast<uint64_t>(fb) + ((size_t)tt * B + (size_t)b0) * per_f + (size_t)(lane64 % NX) * 16;
+    }
+    // F of step n = T-1-t is staged in buffer n % 2 of the ring; the first step is t = 0, n = T-1
+    in.arow = row_x ? ring + (unsigned)(((T - 1) & 1) * G::STAGE + (r * NX + lane) * NS * 4) : arow_u;
+    in.aaff = row_x ? farea + (unsigned)((r * NX + lane) * 4) : arow_u + (unsigned)(NS * 4);
+    in.drow = row_x ? 0u - (unsigned)G::STAGE : (unsigned)(NU * KROW * 4);   // leaving an odd n
+    in.drow2 = row_x ? (unsigned)G::STAGE : (unsigned)(NU * KROW * 4);       // leaving an even n
+    in.daff = row_x ? (unsigned)(NX * 16) : (unsigned)(NU * KROW * 4);
+    in.daff2 = in.daff;
+  } else {
+    // ---- forward DMA: chunk g of the slot [F | f]
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q >= G::NDF) continue;
+      const int g = q * 64 + lane64;
+      const char *base = Fb;
+      size_t per = (size_t)NX * NS * 4, off = 0;
+      if (g < nF) {
+        off = (size_t)g * 16;
+      } else if (g < nF + nf) {
+        base = fb; per = per_f; off = (size_t)(g - nF) * 16;
+      }
+      in.fptr[q] = reinterpret_cast<uint64_t>(base) + (size_t)b0 * per + off - (uint64_t)q * 1024u;
+      in.fstr[q] = (uint64_t)(B * per);
+    }
+    in.arow = row_x ? ring + (unsigned)((r * NX + lane) * NS * 4) : arow_u;
+    in.aaff = row_x ? ring + (unsigned)(G::FOFF_f + (r * NX + lane) * 4) : arow_u + (unsigned)(NS * 4);
+    in.drow = row_x ? (unsigned)G::SLOT_F : (unsigned)(NU * KROW * 4);
+    in.drow2 = row_x ? (unsigned)G::SLOT_F - (unsigned)(G::DEPTH_F * G::SLOT_F) : (unsigned)(NU * KROW * 4);
+    in.daff = in.drow;
+    in.daff2 = in.drow2;
+  }
   in.pst = row_x ? reinterpret_cast<uint64_t>(a.x + (B + (size_t)b) * NX + lane)
                  : reinterpret_cast<uint64_t>(a.u + (size_t)b * NU + m_own);
   in.dst = row_x ? (uint64_t)(B * NX * 4) : (uint64_t)(B * NU * 4);
@@ -160,6 +192,16 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   float xvout, minpiv;
   G::run(in, xvout, minpiv);
 
+#ifdef DMPC_ASM_TIMING_GEN  // timing builds: info[4*w + i] = cycles from the stream's start to phase boundary i
+  if (a.info != nullptr && lane64 == 0) {
+    const int w = (int)blockIdx.x * 4 + wave;
+    if (4 * w + 3 < a.B) {
+      a.info[4 * w + 0] = (int)in.ts[0];
+      for (int i = 1; i < 4; ++i) a.info[4 * w + i] = (int)(in.ts[i] - in.ts[0]);
+    }
+  }
+  return;
+#endif
   if (a.info != nullptr) {
     int bits = 0;
     if (minpiv == 0.f) bits |= 1;                       // a zero pivot in some Quu (uniform over the row)
