@@ -66,6 +66,16 @@ def make_inputs(B, T, nx, nu, seed, device):
     return None, dict(C=C, c=c, F=F, f=f, x_init=x_init)
 
 
+def kernel_name(T, B, nx, nu):
+    """the kernel dmpc_lqr_solve dispatches to at this size (what rocprofv3 --kernel-trace lists)"""
+    from chainer_differentiable_mpc_amd import _lib
+    path = _lib.load().dmpc_lqr_solve_path(T, B, nx, nu)
+    return {0: "dmpc::lqr_generic_kernel", 1: "dmpc::lqr_kernel<%d, %d, ...>" % (nx, nu),
+            2: "dmpc::lqr_dma_kernel<%d, %d, ...>" % (nx, nu),
+            3: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=false>" % (nx, nu),
+            4: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=true>" % (nx, nu)}.get(path, "?")
+
+
 def cpu_baseline(p, T, nx, nu, budget_s=12.0):
     """the oracle (kind "port") on this host, float64, one thread; bounded sample"""
     from oracle import lqr as olqr
@@ -190,7 +200,7 @@ def main():
                            world, " + all-gather(x,u)" if gx is not None else ", no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "dmpc::lqr_kernel<%d,%d,...>" % (nx, nu),
+                         "kernel": kernel_name(T, B, nx, nu),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3},
         }
         if not args.no_cpu_baseline and p is not None:

@@ -25,6 +25,7 @@ _c_sz = ctypes.c_size_t
 SIGNATURES = {
     "dmpc_version": (_c_i, []),
     "dmpc_lqr_kernel_family": (_c_i, [_c_i, _c_i]),
+    "dmpc_lqr_solve_path": (_c_i, [_c_i] * 4),
     "dmpc_lqr_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_lqr_solve": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_lqr_backward_sweep": (_c_i, [_c_i] * 4 + [_c_f] * 9),

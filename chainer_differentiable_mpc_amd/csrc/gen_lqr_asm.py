@@ -51,6 +51,10 @@ X_SKIP_FWD = os.environ.get("GEN_SKIP_FWD") == "1"
 X_SKIP_BWD = os.environ.get("GEN_SKIP_BWD") == "1"
 X_FWD = set(os.environ.get("GEN_FWD_SKIP", "").split(","))   # forward-sweep parts to drop: store,pst,stage,read,xpart,upart
 X_TIMING = os.environ.get("GEN_TIMING") == "1"
+X_NEWTON = os.environ.get("GEN_NEWTON") == "1"          # one Newton step on each v_rcp_f32 (1 ulp -> ~0.5 ulp)
+X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by a direct s_branch (else s_setpc_b64)
+MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
+X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
 USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
 
 
@@ -153,7 +157,7 @@ class Prog:
         if c:
             for r in c:
                 self._need(self.age, r, 2)
-                self._need(self.mf, r, 2)
+                self._need(self.mf, r, MFMA_DEP)
         self.raw("v_mfma_f32_4x4x1_16b_f32 %s, %s, %s, %s cbsz:2 abid:%d" % (vrange(dst), a, b, vrange(c) if c else "0", abid))
         for r in dst:
             self.mf[r] = 0
@@ -326,8 +330,9 @@ def gen_kernel(nx, nu, write_k, stash):
             P.v("v_rcp_f32_e32 %s, %s" % (tRP, A[0][0]), writes=(tRP,), reads=(A[0][0],), trans=True)
             P.v("v_min_f32_e64 %s, |%s|, %s" % (MINPIV, A[0][0], MINPIV), writes=(MINPIV,), reads=(A[0][0], MINPIV))
             P.nop(1)
-            P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, A[0][0], tRP), writes=(tT,), reads=(A[0][0], tRP))
-            P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP))
+            if X_NEWTON:
+                P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, A[0][0], tRP), writes=(tT,), reads=(A[0][0], tRP))
+                P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP))
             P.raw("s_mov_b64 exec, " + S_KM)
             P.v("v_mul_f32_e64 %s, %s, -%s" % (Kt[0], Qs[nx], tRP), writes=(Kt[0],), reads=(Qs[nx], tRP))
         else:
@@ -340,15 +345,17 @@ def gen_kernel(nx, nu, write_k, stash):
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tM1, a11, a01), writes=(tM1,), reads=(a01, a11))
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRA, Qs[nx], Qs[nx + 1]), writes=(tRA,), reads=(Qs[nx], Qs[nx + 1]))
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRB, Qs[nx + 1], Qs[nx]), writes=(tRB,), reads=(Qs[nx], Qs[nx + 1]))
-            P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, tP, tRP), writes=(tT,), reads=(tP, tRP))
-            P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP))
+            if X_NEWTON:
+                P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, tP, tRP), writes=(tT,), reads=(tP, tRP))
+                P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP))
             P.v("v_mul_f32_e32 %s, %s, %s" % (tLL, tL0, tRP), writes=(tLL,), reads=(tL0, tRP))
             P.v("v_fma_f32 %s, -%s, %s, %s" % (tD2, tLL, tPQ, tM1), writes=(tD2,), reads=(tLL, tPQ, tM1))
             P.v("v_rcp_f32_e32 %s, %s" % (tRD, tD2), writes=(tRD,), reads=(tD2,), trans=True)
             P.v("v_fma_f32 %s, -%s, %s, %s" % (tY1, tLL, tRA, tRB), writes=(tY1,), reads=(tLL, tRA, tRB))
             P.v("v_min3_f32 %s, |%s|, |%s|, %s" % (MINPIV, tP, tD2, MINPIV), writes=(MINPIV,), reads=(tP, tD2, MINPIV))
-            P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, tD2, tRD), writes=(tT,), reads=(tD2, tRD))
-            P.v("v_fmac_f32_e32 %s, %s, %s" % (tRD, tT, tRD), writes=(tRD,), reads=(tT, tRD))
+            if X_NEWTON:
+                P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, tD2, tRD), writes=(tT,), reads=(tD2, tRD))
+                P.v("v_fmac_f32_e32 %s, %s, %s" % (tRD, tT, tRD), writes=(tRD,), reads=(tT, tRD))
             P.raw("s_mov_b64 exec, " + S_KM)
             P.v("v_mul_f32_e64 %s, %s, -%s" % (Kt[1], tY1, tRD), writes=(Kt[1],), reads=(tY1, tRD))
             P.v("v_fma_f32 %s, %s, %s, %s" % (tT2, tPQ, Kt[1], tRA), writes=(tT2,), reads=(tPQ, Kt[1], tRA))
@@ -378,9 +385,14 @@ def gen_kernel(nx, nu, write_k, stash):
         for m in range(nu):
             for i in range(nx):
                 P.fmac_dpp(Qs[i], Qs[i], Kt[m], nx + m)
-        for m in range(nu):
-            for i in range(nx):
-                P.fmac_dpp(Qs[i], Kt[m], Rr[m], i)
+        if mfma:      # V~ += K^T R: the A^T B shape again (A = K~ row m, block i/4)
+            for m in range(nu):
+                for I in range(nx // 4):
+                    P.mfma(Qs[4 * I:4 * I + 4], Kt[m], Rr[m], Qs[4 * I:4 * I + 4], I)
+        else:
+            for m in range(nu):
+                for i in range(nx):
+                    P.fmac_dpp(Qs[i], Kt[m], Rr[m], i)
 
     def bstep(s, first, extra_outstanding=0):
         p, n = (s + 2) % 3, (s + 1) % 3
@@ -394,13 +406,19 @@ def gen_kernel(nx, nu, write_k, stash):
             #   G[b][j]  = sum_a V[a][b] F~[a][j]      rows b = x columns: tiles of 4, A = V[a] block b/4, B = F~[a]
             #   g1[j]    = sum_a v[a] F~[a][j]         the row of the homogeneous coordinate (8 DPP FMAs)
             # This is the reference's own association, (F^T V) F  (lqr_recursion.py:89,96).
-            P.mul_dpp(G10, V[0], F[s][0], aff)
-            for a_ in range(1, nx):
-                P.fmac_dpp(G10, V[a_], F[s][a_], aff)
+            if not X_G10_MIX:
+                P.mul_dpp(G10, V[0], F[s][0], aff)
+                for a_ in range(1, nx):
+                    P.fmac_dpp(G10, V[a_], F[s][a_], aff)
             for a_ in range(nx):
                 for I in range(nx // 4):
                     Gt = W[4 * I:4 * I + 4]
                     P.mfma(Gt, V[a_], F[s][a_], Gt if a_ else None, I)
+                if X_G10_MIX:     # the g1 FMAs sit between dependent accumulations of the same tile
+                    if a_ == 0:
+                        P.mul_dpp(G10, V[0], F[s][0], aff)
+                    else:
+                        P.fmac_dpp(G10, V[a_], F[s][a_], aff)
         elif not first:
             # W~ = V~ F~  (+ v in column aff):  W[i] = sum_k bcast<k>(V[i]) F[k] + bcast<aff>(V[i]) e_aff
             for i in range(nx):
@@ -415,8 +433,17 @@ def gen_kernel(nx, nu, write_k, stash):
         if stash:
             # F of the NEXT step goes from its ring slot into this step's stash registers: the register numbers
             # differ per step, so the two reads live in a table of stubs (one per step) that is called here
-            P.raw("s_swappc_b64 %s, %s" % (S_RET, S_STUB))
             lo = int(S_STUB[2:S_STUB.index(":")])
+            if X_RET_DIRECT:
+                callsite[0] += 1
+                P.raw("s_setpc_b64 " + S_STUB)
+                P.lines.append(".p2align 6")
+                P.label("Lret%d_%%=" % callsite[0], reset=False)
+                bret.setdefault(s, callsite[0]) if not first else None
+                if first:
+                    bret["first"] = callsite[0]
+            else:
+                P.raw("s_swappc_b64 %s, %s" % (S_RET, S_STUB))
             P.raw("s_add_u32 s%d, s%d, %d" % (lo, lo, BSTUB))
             P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
         if not first and mfma:
@@ -437,6 +464,8 @@ def gen_kernel(nx, nu, write_k, stash):
         gains(s)
         vupdate(s)
 
+    callsite = [0]
+    bret = {}      # register set (or "first") -> return label number of its call site
     BSTUB = 32     # bytes per backward stub (two LDS reads + s_setpc_b64 = 20)
     assert 8 * len(L.stash_reads) + 4 <= BSTUB
 
@@ -698,7 +727,10 @@ def gen_kernel(nx, nu, write_k, stash):
             for p, (w, off) in enumerate(L.stash_reads):
                 op = {4: "ds_read_b32", 8: "ds_read_b64", 16: "ds_read_b128"}[w]
                 P.raw("%s %s, %%[fr%d] offset:%d" % (op, stash_reg(p, n - 1), w, (n % 3) * L.SLOT_B + L.OFF_F + off))
-            P.raw("s_setpc_b64 " + S_RET)
+            if X_RET_DIRECT:   # stub n is called from step n-1: the peeled first step, then register sets 1, 2, 0, ...
+                P.raw("s_branch Lret%d_%%=" % (bret["first"] if n == 1 else bret[(n - 1) % 3]))
+            else:
+                P.raw("s_setpc_b64 " + S_RET)
     P.label("Ldone_%=")
     P.v("v_mov_b32_e32 %%[minpiv], %s" % MINPIV)
     P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")

@@ -37,6 +37,26 @@ static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch
   return off;
 }
 
+// 4 / 3: generated stream with / without the F stash; 2: LDS-DMA HIP kernel; 1: register-prefetch HIP kernel
+template <int NX, int NU, int L>
+static int solve_path(int T, int B) {
+  if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
+    if (B >= 4 && T >= 2 && !asm_path_disabled()) {
+      if constexpr (LqrAsm<NX, NU, false, true>::kAvailable) {
+        if (T <= LqrAsm<NX, NU, false, true>::NSTASH && lqr_asm_lds_bytes<NX, NU, true>(T) <= kAsmLdsBudget &&
+            !stash_disabled())
+          return 4;
+      }
+      if (lqr_asm_lds_bytes<NX, NU, false>(T) <= kAsmLdsBudget) return 3;
+    }
+  }
+  if constexpr (L == 16) {
+    using Lay = LqrDmaLayout<NX, NU, kDmaDepthB, kDmaDepthF>;
+    if (B >= 4 && T >= 2 && Lay::lds_bytes(T) <= kDmaLdsBudget && !dma_path_disabled()) return 2;
+  }
+  return 1;
+}
+
 template <int NX, int NU, int L>
 static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   constexpr int GPB = 256 / L;
@@ -48,7 +68,8 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
     // fastest path: the whole solve as one generated instruction stream (lqr_asm_kernel.hpp); with the F stash
     // (no second read of F) when the horizon fits the stash registers
-    if (mode == kSolve && !masked && a.B >= 4 && a.T >= 2 && !asm_path_disabled()) {
+    const int path = (mode == kSolve && !masked) ? solve_path<NX, NU, L>(a.T, a.B) : 0;
+    if (path >= 3) {
       const int waves = (a.B + 3) / 4;
       const dim3 g((waves + 3) / 4);
       const bool has_f = a.f != nullptr, write_k = a.Ks != nullptr;
@@ -62,11 +83,9 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
     return (int)hipGetLastError();                                                                               \
   } while (0)
       if constexpr (LqrAsm<NX, NU, false, true>::kAvailable) {
-        if (a.T <= LqrAsm<NX, NU, false, true>::NSTASH && lqr_asm_lds_bytes<NX, NU, true>(a.T) <= kAsmLdsBudget &&
-            !stash_disabled())
-          DMPC_ASM_LAUNCH(true);
+        if (path == 4) DMPC_ASM_LAUNCH(true);
       }
-      if (lqr_asm_lds_bytes<NX, NU, false>(a.T) <= kAsmLdsBudget) DMPC_ASM_LAUNCH(false);
+      DMPC_ASM_LAUNCH(false);
 #undef DMPC_ASM_LAUNCH
     }
   }
@@ -142,6 +161,15 @@ extern "C" {
 int dmpc_version(void) { return DMPC_VERSION; }
 
 int dmpc_lqr_kernel_family(int nx, int nu) { return lqr_family(nx, nu); }
+
+int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
+  if (T <= 0 || B <= 0) return DMPC_E_BADARG;
+#define X(NX_, NU_, L_) \
+  if (nx == NX_ && nu == NU_) return solve_path<NX_, NU_, L_>(T, B);
+  DMPC_LQR_SHAPES(X)
+#undef X
+  return lqr_family(nx, nu) == 3 ? 0 : DMPC_E_UNSUPPORTED;
+}
 
 size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;

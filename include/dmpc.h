@@ -45,6 +45,12 @@ int dmpc_version(void);
  * 2 = wave kernel (64 lanes / trajectory), 3 = generic LDS kernel, <0 unsupported. */
 int dmpc_lqr_kernel_family(int nx, int nu);
 
+/* Which kernel a plain (unmasked) dmpc_lqr_solve of this size runs (diagnostics, benchmark labelling):
+ *   0 lqr_generic_kernel (runtime dims, LDS)      1 lqr_kernel (HIP, register prefetch)
+ *   2 lqr_dma_kernel (HIP, LDS-DMA ring)          3 lqr_asm_kernel, ring (generated stream, F fetched twice)
+ *   4 lqr_asm_kernel, stash (generated stream, F kept in accumulation registers)   <0 unsupported */
+int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
+
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active
  *         (mpc/active_constrained_lqr.py:67-202 when `u_zero_mask` != NULL) ------------ */
 

@@ -41,6 +41,23 @@ def test_dispatch_table_and_workspace_queries():
     assert lib.dmpc_lqr_workspace_bytes(0, 1, 1, 1) == 0
 
 
+def test_solve_path_selection_is_host_logic():
+    """which kernel a plain solve runs: generated stream with the F stash while the horizon fits the stash
+    registers (51 at (8,2)), its ring variant while the gains fit in LDS, then the HIP kernels"""
+    lib = _lib.load()
+    assert lib.dmpc_lqr_solve_path(50, 4096, 8, 2) == 4
+    assert lib.dmpc_lqr_solve_path(51, 4096, 8, 2) == 4
+    assert lib.dmpc_lqr_solve_path(52, 4096, 8, 2) == 3
+    assert lib.dmpc_lqr_solve_path(74, 4096, 8, 2) == 3   # the last horizon whose gain rows fit in LDS beside the rings
+    assert lib.dmpc_lqr_solve_path(75, 4096, 8, 2) == 2
+    assert lib.dmpc_lqr_solve_path(80, 4096, 8, 2) == 1
+    assert lib.dmpc_lqr_solve_path(50, 3, 8, 2) == 1      # less than one wavefront of trajectories
+    assert lib.dmpc_lqr_solve_path(20, 1024, 3, 1) == 3   # nx = 3 does not tile the f area: ring variant
+    assert lib.dmpc_lqr_solve_path(50, 65536, 32, 8) == 1
+    assert lib.dmpc_lqr_solve_path(10, 16, 5, 3) == 0
+    assert lib.dmpc_lqr_solve_path(10, 16, 60, 10) == _lib.E_UNSUPPORTED
+
+
 def test_argument_errors_are_reported_before_any_launch():
     lib = _lib.load()
     assert lib.dmpc_lqr_solve(0, 1, 1, 1, *([None] * 10), None, 0, None, None) == _lib.E_BADARG
