@@ -73,7 +73,8 @@ def kernel_name(T, B, nx, nu):
     return {0: "dmpc::lqr_generic_kernel", 1: "dmpc::lqr_kernel<%d, %d, ...>" % (nx, nu),
             2: "dmpc::lqr_dma_kernel<%d, %d, ...>" % (nx, nu),
             3: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=false>" % (nx, nu),
-            4: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=true>" % (nx, nu)}.get(path, "?")
+            4: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=true>" % (nx, nu),
+            5: "dmpc::lqr_wave_mfma_backward<%d, %d> (+ forward-only dmpc::lqr_kernel)" % (nx, nu)}.get(path, "?")
 
 
 def cpu_baseline(p, T, nx, nu, budget_s=12.0):

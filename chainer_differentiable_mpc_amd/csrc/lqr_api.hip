@@ -11,6 +11,7 @@
 #include "lqr_dma_kernel.hpp"
 #include "lqr_generic.hpp"
 #include "lqr_kernels.hpp"
+#include "lqr_wave_mfma.hpp"
 
 namespace dmpc {
 
@@ -30,6 +31,10 @@ static bool asm_path_disabled() {  // DMPC_NO_ASM=1 forces the HIP kernels (A/B 
 }
 static bool stash_disabled() {  // DMPC_NO_STASH=1: forward sweep re-reads F by LDS-DMA (A/B timing)
   static const bool off = [] { const char *e = getenv("DMPC_NO_STASH"); return e && e[0] == '1'; }();
+  return off;
+}
+static bool wave_mfma_disabled() {  // DMPC_NO_WAVE_MFMA=1: large shapes on the readlane HIP kernel (A/B timing)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_WAVE_MFMA"); return e && e[0] == '1'; }();
   return off;
 }
 static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
@@ -53,6 +58,9 @@ static int solve_path(int T, int B) {
   if constexpr (L == 16) {
     using Lay = LqrDmaLayout<NX, NU, kDmaDepthB, kDmaDepthF>;
     if (B >= 4 && T >= 2 && Lay::lds_bytes(T) <= kDmaLdsBudget && !dma_path_disabled()) return 2;
+  }
+  if constexpr (L == 64 && NX % 4 == 0 && (NX + NU) % 4 == 0) {
+    if (!wave_mfma_disabled()) return 5;
   }
   return 1;
 }
@@ -87,6 +95,19 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       }
       DMPC_ASM_LAUNCH(false);
 #undef DMPC_ASM_LAUNCH
+    }
+  }
+  if constexpr (L == 64 && NX % 4 == 0 && (NX + NU) % 4 == 0) {
+    // large shapes: backward sweep on the matrix cores (lqr_wave_mfma.hpp), gains through HBM, then the
+    // bandwidth-bound forward-only kernel
+    if (!masked && mode != kForwardOnly && !wave_mfma_disabled()) {
+      LqrArgs s = a;
+      if (s.Ks == nullptr && s.wsK == nullptr) return DMPC_E_WORKSPACE;
+      hipLaunchKernelGGL((lqr_wave_mfma_backward<NX, NU>), dim3((a.B + 3) / 4), block, 0, stream, s);
+      if (mode == kBackwardOnly) return (int)hipGetLastError();
+      if (s.Ks == nullptr) { s.Ks = s.wsK; s.ks = s.wsk; }
+      hipLaunchKernelGGL((lqr_kernel<NX, NU, L, false, kForwardOnly, false>), grid, block, 0, stream, s);
+      return (int)hipGetLastError();
     }
   }
   if constexpr (L == 16) {

@@ -53,7 +53,7 @@ def test_solve_path_selection_is_host_logic():
     assert lib.dmpc_lqr_solve_path(80, 4096, 8, 2) == 1
     assert lib.dmpc_lqr_solve_path(50, 3, 8, 2) == 1      # less than one wavefront of trajectories
     assert lib.dmpc_lqr_solve_path(20, 1024, 3, 1) == 3   # nx = 3 does not tile the f area: ring variant
-    assert lib.dmpc_lqr_solve_path(50, 65536, 32, 8) == 1
+    assert lib.dmpc_lqr_solve_path(50, 65536, 32, 8) == 5   # one wavefront per trajectory, MFMA backward sweep
     assert lib.dmpc_lqr_solve_path(10, 16, 5, 3) == 0
     assert lib.dmpc_lqr_solve_path(10, 16, 60, 10) == _lib.E_UNSUPPORTED
 

@@ -102,3 +102,29 @@ def test_repeated_launches_are_bitwise_reproducible():
     torch.cuda.synchronize()
     for x, u in outs[1:]:
         assert torch.equal(x, outs[0][0]) and torch.equal(u, outs[0][1])
+
+
+@pytest.mark.parametrize("shape", [(6, 7, 32, 8), (9, 6, 8, 2), (5, 5, 12, 4)])
+def test_quu_that_needs_row_interchanges(shape):
+    """an SPD Quu whose leading entries are small, so that partial pivoting really moves rows (LAPACK getf2
+    semantics of torch.lu / F.batch_inv, util.py:481, lqr_recursion.py:118) - at (32,8) this is the uniform-branch
+    interchange of lqr_wave_mfma.hpp, at (8,2) the spelled-out 2x2 of the generated stream"""
+    B, T, nx, nu = shape
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=13)
+    rng = np.random.RandomState(7)
+    scale = np.diag(np.linspace(0.3, 3.0, nu))          # later controls weigh more: |S[i][0]| > |S[0][0]| for some i
+    for t in range(T):
+        for b in range(B):
+            G = rng.standard_normal((nu, nu))
+            S = scale @ (G @ G.T + 0.5 * np.eye(nu)) @ scale
+            p["C"][t, b, nx:, nx:] = S
+            # keep the whole cost matrix positive definite
+            p["C"][t, b, :nx, nx:] *= 0.1
+            p["C"][t, b, nx:, :nx] *= 0.1
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    d = to_dev(p)
+    rec = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu)
+    x, u = rec.solve_recursion()
+    assert int(rec.info.abs().max().item()) == 0
+    assert_close(npy(x), xr, 5e-4, "x")
+    assert_close(npy(u), ur, 5e-4, "u")
