@@ -8,6 +8,6 @@ namespace dmpc {
 // Vector loads (float2/float4) assume 16-byte aligned array bases; NULL is "absent", hence fine.
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static constexpr size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace dmpc

@@ -243,13 +243,14 @@ def gen_kernel(nx, nu, write_k, stash):
     NQ = 4 * ((ns + 3) // 4)            # MFMA accumulator tiles are 4 consecutive rows
     Q = [R.take(NQ if mfma else ns, align=4) for _ in range(3)]
     F = [R.take(nx) for _ in range(3)]
-    W = R.take(nx, align=4)             # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V)
+    W = R.take(max(nx, 4), align=4)     # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V)
     G10 = R.take(1)[0]                  # MFMA path: row "1" of G^ = F^T v
     A = [R.take(nu) for _ in range(nu)]
     Kt = R.take(nu)
     Rr = R.take(nu)
     tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = R.take(13)
     MINPIV = R.take(1)[0]
+    XV0 = R.take(1)[0]                  # x_init (lanes < nx), loaded by the stream itself
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
     RF = Regs(VBASE)
     M = [RF.take(ns, align=4), RF.take(ns, align=4), RF.take(ns, align=4)]
@@ -269,8 +270,8 @@ def gen_kernel(nx, nu, write_k, stash):
     n_agpr = L.stash_regs * L.NSTASH if stash else 0
     assert n_agpr <= 256
 
-    S_N, S_TF = "s70", "s71"
-    S_KM, S_SM, S_UM = "s[72:73]", "s[74:75]", "s[76:77]"
+    S_N, S_TF = "s70", "%[tf]"   # tf: time strides the DMA pointers may still take (an operand: it crosses the two asm blocks)
+    S_KM, S_SM, S_UM, S_XM = "s[72:73]", "s[74:75]", "s[76:77]", "s[88:89]"
     S_RET, S_STUB, S_JMP, S_TMP = "s[78:79]", "s[80:81]", "s[82:83]", "s84"
 
     def mask64(lanes):
@@ -280,6 +281,7 @@ def gen_kernel(nx, nu, write_k, stash):
     km = mask64(list(range(nx)) + [aff])
     sm = mask64(range(ns))
     um = mask64(range(nx, ns))
+    xm = mask64(range(nx))
     in_loop = [False]
 
     def issue_group(ptrs, slot, slot_bytes):
@@ -479,10 +481,10 @@ def gen_kernel(nx, nu, write_k, stash):
             P.v("v_mov_b32_e32 %s, s86" % TS[i], writes=(TS[i],))
 
     # =============================================================== backward sweep
-    P.comment("---- prologue")
-    P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    P.comment("---- prologue (the first DMA groups are already in flight)")
+    P.raw("s_waitcnt lgkmcnt(0)")
     stamp(0)
-    for name, val in ((S_KM, km), (S_SM, sm), (S_UM, um)):
+    for name, val in ((S_KM, km), (S_SM, sm), (S_UM, um), (S_XM, xm)):
         lo = int(name[2:name.index(":")])
         P.raw("s_mov_b32 s%d, 0x%x" % (lo, val & 0xffffffff))
         P.raw("s_mov_b32 s%d, 0x%x" % (lo + 1, val & 0xffffffff))
@@ -495,12 +497,18 @@ def gen_kernel(nx, nu, write_k, stash):
         P.label("Lpcb_%=", reset=False)
         P.raw("s_add_u32 s%d, s%d, Lbstub_%%=-Lpcb_%%=" % (lo, lo))
         P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+    # The first DB groups are issued by a SEPARATE asm block (issue_first) that the C++ side runs as soon as the
+    # DMA pointers exist - the rest of the operand set-up then overlaps their flight.
+    P_main = P
+    P = Prog()
     P.raw("s_sub_i32 %s, %%[T], 1" % S_TF)
     issue_group(ptr, 0, L.SLOT_B)
     advance(ptr, str1)
     for j in range(1, DB):
         issue_group(ptr, j, L.SLOT_B)
         advance(ptr, strd)
+    P_first = P
+    P = P_main
     n_extra = 0
     if stash:
         # all of f (the forward sweep's only input from memory) goes to LDS now, BEHIND the first groups: the
@@ -513,6 +521,19 @@ def gen_kernel(nx, nu, write_k, stash):
                 P.raw("s_add_u32 m0, %%[farea], %d" % (q * 1024))
             P.nop(1)
             P.raw("global_load_lds_dwordx4 %s, off" % fp[q])
+    P.raw("global_load_dword %s, %%[pxi], off" % XV0)
+    n_extra += 1
+    # zero this wave's gain rows while the first slots are in flight (columns nx..ns-1 and the pad of every row
+    # are never written afterwards; the region is padded to whole 1 KB pieces by lqr_asm_kernel.hpp)
+    for i in range(4):
+        P.v("v_mov_b32_e32 %s, 0" % W[i], writes=(W[i],))
+    P.raw("s_mov_b32 %s, %%[nz]" % S_TMP)
+    P.label("Lzero_%=", reset=False)
+    P.raw("ds_write_b128 %%[gz], %s" % vrange(W[0:4]))
+    P.v("v_add_u32_e32 %[gz], 0x400, %[gz]")
+    P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
+    P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
+    P.raw("s_cbranch_scc1 Lzero_%=")
     P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * L.ndma_b + n_extra))
     read_set(0, 0)
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
@@ -582,6 +603,10 @@ def gen_kernel(nx, nu, write_k, stash):
     P.comment("---- forward rollout")
     stamp(2)
     P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    P.raw("s_mov_b64 exec, " + S_XM)                       # x_0 = x_init
+    P.raw("global_store_dword %%[px0], %s, off" % XV0)
+    P.raw("s_mov_b64 exec, -1")
+    P.exec_written()
     if not stash:
         P.raw("s_sub_i32 %s, %%[T], 2" % S_TF)
         for j in range(DF):
@@ -589,7 +614,7 @@ def gen_kernel(nx, nu, write_k, stash):
             advance(fptr, fstr)
         P.raw("s_waitcnt vmcnt(%d)" % ((DF - 1) * L.ndma_f))
         read_rows(0, 0)
-        P.v("v_mov_b32_e32 %s, %%[xv]" % ACC[2], writes=(ACC[2],))
+        P.v("v_mov_b32_e32 %s, %s" % (ACC[2], XV0), writes=(ACC[2],))
         P.raw("s_sub_i32 %s, %%[T], 1" % S_N)      # full steps t = 0 .. T-2
         P.raw("s_cmp_lg_u32 %s, 0" % S_N)
         P.raw("s_cbranch_scc0 Lfin0_%=")
@@ -717,7 +742,7 @@ def gen_kernel(nx, nu, write_k, stash):
             P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
             prefetch(n, move=False)
             prefetch(n - 1)
-            P.v("v_mov_b32_e32 %s, %%[xv]" % ACC[ap], writes=(ACC[ap],))
+            P.v("v_mov_b32_e32 %s, %s" % (ACC[ap], XV0), writes=(ACC[ap],))
             P.raw("s_branch Lfs%d_%%=" % n)
         # ---- backward stubs: F block of ring slot (n % 3) -> stash slot n-1
         P.lines.append(".p2align 5")
@@ -748,7 +773,7 @@ def gen_kernel(nx, nu, write_k, stash):
     if not stash:
         for q in range(L.ndma_f):
             rw.append(("fptr%d" % q, '"+v"(in.fptr[%d])' % q))
-    rw += [("ak", '"+v"(in.ak)'), ("arow", '"+v"(in.arow)'), ("aaff", '"+v"(in.aaff)'), ("pst", '"+v"(in.pst)')]
+    rw += [("tf", '"+s"(in.tf)'), ("gz", '"+v"(in.gz)'), ("ak", '"+v"(in.ak)'), ("arow", '"+v"(in.arow)'), ("aaff", '"+v"(in.aaff)'), ("pst", '"+v"(in.pst)')]
     if write_k:
         for m in range(nu):
             rw.append(("pk%d" % m, '"+v"(in.pk[%d])' % m))
@@ -760,7 +785,7 @@ def gen_kernel(nx, nu, write_k, stash):
         ins.append(("aq%d" % i, '"v"(in.aq[%d])' % i))
     for k in range(nx):
         ins.append(("af%d" % k, '"v"(in.af[%d])' % k))
-    ins += [("eaff", '"v"(in.eaff)'), ("dst", '"v"(in.dst)'), ("xv", '"v"(in.xv)')]
+    ins += [("eaff", '"v"(in.eaff)'), ("dst", '"v"(in.dst)'), ("pxi", '"v"(in.pxi)'), ("px0", '"v"(in.px0)')]
     if stash:
         for q in range(L.NFD):
             ins.append(("fp%d" % q, '"v"(in.fp[%d])' % q))
@@ -774,9 +799,9 @@ def gen_kernel(nx, nu, write_k, stash):
         ins += [("drow", '"v"(in.drow)'), ("drow2", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'), ("daff2", '"v"(in.daff2)')]
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
-    ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)')]
+    ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)')]
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
-        ['"s%d"' % i for i in range(70, 88)] + ['"vcc"', '"scc"', '"memory"']
+        ['"s%d"' % i for i in ([70] + list(range(72, 90)))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
     name = "LqrAsm<%d, %d, %s, %s>" % (nx, nu, tf(write_k), tf(stash))
@@ -791,6 +816,21 @@ def gen_kernel(nx, nu, write_k, stash):
              % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
     o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, STAGE = %d, SPD = %d;\n"
              % (L.NSTASH, L.NFD, L.FAREA, L.STAGE, L.SPD))
+    # block 1: the first DB groups
+    rw1 = [("ptr%d" % q, '"+v"(in.ptr[%d])' % q) for q in range(L.ndma_b)] + [("tf", '"+s"(in.tf)')]
+    ins1 = []
+    for q in range(L.ndma_b):
+        ins1.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
+        ins1.append(("str%d" % q, '"v"(in.str[%d])' % q))
+    ins1 += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)')]
+    o.append("  static __device__ __forceinline__ void issue_first(LqrAsmIn<%d, %d> &in) {\n" % (nx, nu))
+    o.append("    asm volatile(\n")
+    for ln in P_first.text():
+        o.append('        "%s\\n\\t"\n' % ln)
+    o.append("        : " + ", ".join("[%s] %s" % x for x in rw1) + "\n")
+    o.append("        : " + ", ".join("[%s] %s" % x for x in ins1) + "\n")
+    o.append('        : "scc", "memory");\n')
+    o.append("  }\n")
     o.append("  static __device__ __forceinline__ void run(LqrAsmIn<%d, %d> &in, float &xvout, float &minpiv) {\n" % (nx, nu))
     o.append("    asm volatile(\n")
     for ln in P.text():
@@ -819,6 +859,9 @@ struct LqrAsmIn {
   uint64_t ptr[4], str1[4], str[4];  // LDS-DMA source of this lane's chunk (t = T-1), first / later time strides
   unsigned aq[NS], af[NX];           // LDS byte addresses (ring slot 0) of this lane's [C|c] rows and [F|f] rows
   unsigned ak;                       // LDS byte address of gain row (T-1, 0), this lane's column
+  unsigned gz;                       // LDS byte address of this wave's gain rows + lane64 * 16 (zero fill)
+  int nz;                            // wave-uniform: 1 KB pieces of the gain rows of one wave
+  int tf;                            // wave-uniform: time strides the DMA pointers may still take (set by issue_first)
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
   // forward sweep
@@ -828,7 +871,7 @@ struct LqrAsmIn {
   unsigned farea;                    // stash variant (wave-uniform): LDS byte address of this wave's f area
   unsigned arow, aaff, drow, drow2, daff, daff2;
   uint64_t pst, dst;                 // [x_{t+1} | u_t] store pointer and time stride
-  float xv;                          // x_init in lanes < nx
+  uint64_t pxi, px0;                 // &x_init[b][lane] (every lane valid), &x[0][b][lane] (lanes < nx store)
   // wave-uniform
   unsigned ring;                     // LDS byte address of this wave's ring
   int T;

@@ -20,6 +20,7 @@
 //   [.., + 4*FAREA)                stash only: f of all timesteps of the wave's 4 trajectories
 //   [.., + 16*T*NU*KROW*4)         gain rows [K_m | 0 | k_m | pad] per trajectory, time-major, zero-initialised
 #pragma once
+#include "api_util.hpp"
 #include "colwise.hpp"
 #include "lqr_asm_gen.hpp"
 #include "lqr_dma_kernel.hpp"
@@ -34,7 +35,8 @@ __device__ const float4 dmpc_zero_chunks[16] = {};
 template <int NX, int NU, bool STASH>
 constexpr size_t lqr_asm_lds_bytes(int T) {
   using G = LqrAsm<NX, NU, false, STASH>;
-  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) + (size_t)16 * T * NU * G::KROW * 4;
+  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) +
+         4 * round_up((size_t)4 * T * NU * G::KROW * 4, 1024);  // per wave: whole 1 KB pieces (zero fill)
 }
 
 template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH>
@@ -45,6 +47,9 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
   // (M0 carries the LDS-DMA target; it reaches all 160 KB - scripts/microbench/m0_range.hip)
 
+#ifdef DMPC_ASM_TIMING_GEN
+  const unsigned t_entry = (unsigned)__builtin_amdgcn_s_memtime();
+#endif
   const int T = a.T;
   const size_t B = (size_t)a.B;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -60,19 +65,14 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   const unsigned lds0 = lds_byte_address(lds);
   const unsigned ring = lds0 + (unsigned)wave * G::RING_BYTES;
   const unsigned farea = lds0 + 4u * G::RING_BYTES + (unsigned)wave * (STASH ? G::FAREA_BYTES : 0);
-  const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + (STASH ? 4u * G::FAREA_BYTES : 0u) +
-                             (unsigned)(wave * 4) * (unsigned)(T * NU * KROW * 4);
+  const unsigned gain_wave_bytes = (unsigned)round_up((size_t)4 * T * NU * KROW * 4, 1024);
+  const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + (STASH ? 4u * G::FAREA_BYTES : 0u) + (unsigned)wave * gain_wave_bytes;
   const unsigned gain_traj = gain_wave + (unsigned)r * (unsigned)(T * NU * KROW * 4);
-
-  {  // zero this wave's gain rows (columns nx..ns-1 and the pad are never written afterwards)
-    float4 *g4 = reinterpret_cast<float4 *>(reinterpret_cast<char *>(lds) + (gain_wave - lds0));
-    const int n4 = T * NU * KROW;  // float4 per wave: 4 trajectories * T*NU*KROW floats / 4
-    for (int i = lane64; i < n4; i += 64) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
 
   LqrAsmIn<NX, NU> in;
   in.ring = __builtin_amdgcn_readfirstlane(ring);
   in.T = T;
+  in.tf = 0;
 
   // ---- backward DMA: chunk g = q*64 + lane64 of the slot [C | c | F | f]
   const char *Cb = reinterpret_cast<const char *>(a.C), *cb = reinterpret_cast<const char *>(a.c);
@@ -86,37 +86,41 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
       in.ptr[q] = in.str1[q] = in.str[q] = 0;
       continue;
     }
+    // which array does chunk g of the slot [C | c | F | f | padding] belong to?  (selects, no branches: this
+    // set-up runs once per wave but sits on the critical path of the first DMA)
     const int g = q * 64 + lane64;
-    const char *base = Cb;
-    size_t per = (size_t)NS * NS * 4;  // bytes per trajectory and timestep
-    size_t off = 0;
-    int t0 = T - 1;
-    bool dyn = false;
-    if (g < nC) {
-      off = (size_t)g * 16;
-    } else if (g < nC + nc) {
-      base = cb; per = (size_t)NS * 4; off = (size_t)(g - nC) * 16;
-    } else if (g < nC + nc + nF) {
-      base = Fb; per = (size_t)NX * NS * 4; off = (size_t)(g - nC - nc) * 16; t0 = T - 2; dyn = true;
-    } else if (g < nC + nc + nF + nf) {
-      base = fb; per = per_f; off = (size_t)(g - nC - nc - nF) * 16; t0 = T - 2; dyn = true;
-    }  // else: padding lanes fetch chunk 0 of C again - never read
-    const uint64_t p = reinterpret_cast<uint64_t>(base) + ((size_t)t0 * B + (size_t)b0) * per + off;
+    const bool isC = g < nC, isc = !isC && g < nC + nc, isF = !isC && !isc && g < nC + nc + nF;
+    const bool isf = !isC && !isc && !isF && g < nC + nc + nF + nf;
+    const bool dyn = isF || isf;  // arrays without a slice T-1
+    const uint64_t base = isc ? reinterpret_cast<uint64_t>(cb) : isF ? reinterpret_cast<uint64_t>(Fb)
+                          : isf ? reinterpret_cast<uint64_t>(fb) : reinterpret_cast<uint64_t>(Cb);
+    const size_t per = isc ? (size_t)NS * 4 : isF ? (size_t)NX * NS * 4 : isf ? per_f : (size_t)NS * NS * 4;
+    const int g0 = isC ? 0 : isc ? nC : isF ? nC + nc : isf ? nC + nc + nF : g;  // padding lanes: chunk 0 of C again
+    const size_t off = (size_t)(g - g0) * 16;
+    const int t0 = dyn ? T - 2 : T - 1;
+    const uint64_t p = base + ((size_t)t0 * B + (size_t)b0) * per + off;
     in.ptr[q] = p - (uint64_t)q * 1024u;  // the instruction offset q*1024 moves the global address as well
     const uint64_t s = (uint64_t)0 - (uint64_t)(B * per);
     in.str[q] = s;
     in.str1[q] = dyn ? 0 : s;  // there is no F_{T-1}: the first group fetches F_{T-2} (unused), as does the second
   }
+  // The first DB groups leave NOW; everything below (LDS read addresses, store pointers, the forward sweep's
+  // operands) is computed while they are in flight.  No memory operation of this C++ code may follow: x_init
+  // is loaded and x_0 stored by the stream itself.
+  G::issue_first(in);
+  in.gz = gain_wave + (unsigned)lane64 * 16u;  // the stream zero-fills the gain rows behind its first DMAs
+  in.nz = (int)(gain_wave_bytes / 1024u);
   const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
   const bool col_aff = lane == AFF;
+  {  // lane j < ns: column j of the rows of [C] / [F] (stride ns floats); lane ns: c / f themselves (stride 1)
+    const unsigned q0 = ring + (col_aff ? (unsigned)(G::OFF_c + r * NS * 4) : (unsigned)(G::OFF_C + (r * NS * NS + lane_c) * 4));
+    const unsigned f0 = ring + (col_aff ? (unsigned)(G::OFF_f + r * NX * 4) : (unsigned)(G::OFF_F + (r * NX * NS + lane_c) * 4));
+    const unsigned st = col_aff ? 4u : (unsigned)(NS * 4);
 #pragma unroll
-  for (int i = 0; i < NS; ++i)
-    in.aq[i] = ring + (col_aff ? (unsigned)(G::OFF_c + (r * NS + i) * 4)
-                               : (unsigned)(G::OFF_C + ((r * NS + i) * NS + lane_c) * 4));
+    for (int i = 0; i < NS; ++i) in.aq[i] = q0 + (unsigned)i * st;
 #pragma unroll
-  for (int k = 0; k < NX; ++k)
-    in.af[k] = col_aff ? ring + (unsigned)(G::OFF_f + (r * NX + k) * 4)
-                       : ring + (unsigned)(G::OFF_F + ((r * NX + k) * NS + lane_c) * 4);
+    for (int k = 0; k < NX; ++k) in.af[k] = f0 + (unsigned)k * st;
+  }
   in.ak = gain_traj + (unsigned)((T - 1) * NU * KROW * 4) + (unsigned)lane * 4u;
   in.eaff = col_aff ? 1.f : 0.f;
   if constexpr (WRITE_K) {
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.pst = row_x ? reinterpret_cast<uint64_t>(a.x + (B + (size_t)b) * NX + lane)
                  : reinterpret_cast<uint64_t>(a.u + (size_t)b * NU + m_own);
   in.dst = row_x ? (uint64_t)(B * NX * 4) : (uint64_t)(B * NU * 4);
-  in.xv = row_x ? a.x_init[(size_t)b * NX + lane] : 0.f;
-  if (row_x) a.x[(size_t)b * NX + lane] = in.xv;  // x_0
+  in.pxi = reinterpret_cast<uint64_t>(a.x_init + (size_t)b * NX + (row_x ? lane : NX - 1));
+  in.px0 = reinterpret_cast<uint64_t>(a.x + (size_t)b * NX + (row_x ? lane : NX - 1));
 
   float xvout, minpiv;
   G::run(in, xvout, minpiv);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   if (a.info != nullptr && lane64 == 0) {
     const int w = (int)blockIdx.x * 4 + wave;
     if (4 * w + 3 < a.B) {
-      a.info[4 * w + 0] = (int)in.ts[0];
+      a.info[4 * w + 0] = (int)(in.ts[0] - t_entry);  // operand set-up before the stream
       for (int i = 1; i < 4; ++i) a.info[4 * w + i] = (int)(in.ts[i] - in.ts[0]);
     }
   }
