@@ -77,23 +77,20 @@ class Layout:
         self.RING = max(DB * self.SLOT_B, DF * self.SLOT_F)
         assert self.ndma_b * 1024 - 1024 <= 4095 and ns + 1 <= 12 and nu in (1, 2)
         assert (DB - 1) * self.ndma_b <= 63 and (DF - 1) * self.ndma_f <= 63
-        # ---- F stash (registers instead of a second HBM read of F): per wave-step the F block of the slot
-        # (16*nF bytes) is read linearly, lane l taking bytes [w*l, w*l + w) of each piece
-        self.stash_ok = (64 % nx == 0)
-        fb = 16 * self.nF
-        self.stash_reads = []          # (bytes per lane, byte offset inside the F block)
-        off = 0
-        while fb - off >= 1024:
-            self.stash_reads.append((16, off))
-            off += 1024
-        rem = fb - off
-        if rem > 0:
-            w = 4 if rem <= 256 else (8 if rem <= 512 else 16)
-            self.stash_reads.append((w, off))
-        self.stash_regs = sum(w // 4 for w, _ in self.stash_reads)
+        # ---- F stash (registers instead of a second HBM read of F), in the layout the forward sweep consumes:
+        # lane i < 8 of a 16-lane row keeps columns [0, H) of row i of F_t, lane 8 + i columns [H, ns) - H
+        # accumulation registers per timestep, read from the ring slot as pairs (ds_read2_b32) + a single
+        self.stash_ok = (64 % nx == 0) and nx <= 8
+        self.H = (ns + 1) // 2
+        self.stash_pieces = []         # (registers, dword offset inside the half row)
+        o = 0
+        while self.H - o >= 2:
+            self.stash_pieces.append((2, o))
+            o += 2
+        if self.H - o == 1:
+            self.stash_pieces.append((1, o))
+        self.stash_regs = self.H
         self.NSTASH = min(256 // self.stash_regs - (1 if 256 % self.stash_regs == 0 else 0), 64)
-        self.STAGE = sum(64 * w for w, _ in self.stash_reads)   # bytes per forward staging buffer (two, in the ring)
-        self.RING = max(self.RING, 2 * self.STAGE)
         self.SPD = 64 // nx                              # timesteps of f per DMA instruction
         self.NFD = (self.NSTASH + 1 + self.SPD - 1) // self.SPD
         self.FAREA = self.NFD * 1024                     # bytes of f per wave: f[tt] at tt * nx * 16
@@ -137,8 +134,8 @@ class Prog:
 
     def exec_written(self):
         # SALU write of EXEC -> DPP: not a documented hazard (the documented one is a VALU write, 5 wait states);
-        # four wait states are kept anyway
-        self.age = {"*": -2}
+        # two wait states are kept anyway
+        self.age = {"*": 0}
 
     def _need(self, table, reg, states):
         have = table.get(reg, table.get("*", 99))
@@ -260,18 +257,19 @@ def gen_kernel(nx, nu, write_k, stash):
     assert last_vgpr <= 255
 
     # stash registers (AGPRs): piece p of stash slot j
-    def stash_reg(p, j):
+    def stash_regs_of(p, j):
+        """AGPR numbers of piece p of stash slot j (pairs are 64-bit aligned: all pair regions come first)"""
         base = 0
         for pp in range(p):
-            base += (L.stash_reads[pp][0] // 4) * L.NSTASH
-        w = L.stash_reads[p][0] // 4
-        lo = base + j * w
-        return "a%d" % lo if w == 1 else "a[%d:%d]" % (lo, lo + w - 1)
+            base += L.stash_pieces[pp][0] * L.NSTASH
+        w = L.stash_pieces[p][0]
+        return [base + j * w + k for k in range(w)]
+
     n_agpr = L.stash_regs * L.NSTASH if stash else 0
     assert n_agpr <= 256
 
     S_N, S_TF = "s70", "%[tf]"   # tf: time strides the DMA pointers may still take (an operand: it crosses the two asm blocks)
-    S_KM, S_SM, S_UM, S_XM = "s[72:73]", "s[74:75]", "s[76:77]", "s[88:89]"
+    S_KM, S_SM, S_UM, S_XM, S_HI = "s[72:73]", "s[74:75]", "s[76:77]", "s[88:89]", "s[90:91]"
     S_RET, S_STUB, S_JMP, S_TMP = "s[78:79]", "s[80:81]", "s[82:83]", "s84"
 
     def mask64(lanes):
@@ -282,6 +280,7 @@ def gen_kernel(nx, nu, write_k, stash):
     sm = mask64(range(ns))
     um = mask64(range(nx, ns))
     xm = mask64(range(nx))
+    hi = mask64(range(nx, 16))   # the lanes whose row registers take gain rows (lanes < nx take F rows)
     in_loop = [False]
 
     def issue_group(ptrs, slot, slot_bytes):
@@ -469,7 +468,7 @@ def gen_kernel(nx, nu, write_k, stash):
     callsite = [0]
     bret = {}      # register set (or "first") -> return label number of its call site
     BSTUB = 32     # bytes per backward stub (two LDS reads + s_setpc_b64 = 20)
-    assert 8 * len(L.stash_reads) + 4 <= BSTUB
+    assert 8 * len(L.stash_pieces) + 4 <= BSTUB
 
     TS = R.take(4) if X_TIMING else []
     last_vgpr = R.next - 1
@@ -484,7 +483,7 @@ def gen_kernel(nx, nu, write_k, stash):
     P.comment("---- prologue (the first DMA groups are already in flight)")
     P.raw("s_waitcnt lgkmcnt(0)")
     stamp(0)
-    for name, val in ((S_KM, km), (S_SM, sm), (S_UM, um), (S_XM, xm)):
+    for name, val in ((S_KM, km), (S_SM, sm), (S_UM, um), (S_XM, xm), (S_HI, hi)):
         lo = int(name[2:name.index(":")])
         P.raw("s_mov_b32 s%d, 0x%x" % (lo, val & 0xffffffff))
         P.raw("s_mov_b32 s%d, 0x%x" % (lo + 1, val & 0xffffffff))
@@ -557,7 +556,7 @@ def gen_kernel(nx, nu, write_k, stash):
     n_bwd = P.n_instr
 
     # =============================================================== forward rollout
-    def read_rows(c, a):
+    def read_rows(c, a, aff_too=True):
         if X_NO_LDSREAD and in_loop[0]:
             return
         Mc = M[c]
@@ -575,7 +574,8 @@ def gen_kernel(nx, nu, write_k, stash):
                 i += 2
             if i < ns:
                 P.raw("ds_read_b32 %s, %%[arow] offset:%d" % (Mc[i], i * 4))
-        P.raw("ds_read_b32 %s, %%[aaff]" % ACC[a])
+        if aff_too:
+            P.raw("ds_read_b32 %s, %%[aaff]" % ACC[a])
 
     def fcompute(c, a, ap, mask, last, fillers=()):
         """fillers: independent work emitted in the wait states between the dependent control FMAs"""
@@ -663,28 +663,33 @@ def gen_kernel(nx, nu, write_k, stash):
         def sets(n):
             return n % 3, n % 4, (n + 1) % 4     # row set, accumulator, x_t register of step n
 
-        def stage_write(n):
-            """stash slot n-1 (F of step n) -> staging buffer n % 2"""
-            if "stage" in X_FWD and in_loop[0]:
-                return
-            for p, (w, off) in enumerate(L.stash_reads):
-                op = {4: "ds_write_b32", 8: "ds_write_b64", 16: "ds_write_b128"}[w]
-                P.raw("%s %%[fr%d], %s offset:%d" % (op, w, stash_reg(p, n - 1), (n % 2) * L.STAGE + off))
-
-        n_rowreads = (ns + 3) // 4 + (1 if ns % 4 in (1, 2, 3) and ns % 2 == 0 and ns % 4 else 0)
-
         def prefetch_a(m, move=True):
-            """first half of the preparation of step m (>= 0): stage F, move the row pointers"""
-            if m >= 1:
-                stage_write(m)
-            if move:   # the row pointers go from step m+1 to step m
-                P.v("v_add_u32_e32 %%[arow], %%[drow%s], %%[arow]" % ("o" if (m + 1) % 2 else "e"))
+            """first half of the preparation of step m (>= 0): F_t rows out of the stash registers (lanes < 8 get
+            columns [0, H) directly and columns [H, ns) from lane + 8 by a row rotation), row pointers moved"""
+            Mc = M[sets(m)[0]]
+            if m >= 1 and not ("stage" in X_FWD and in_loop[0]):
+                regs = [r for p in range(len(L.stash_pieces)) for r in stash_regs_of(p, m - 1)]
+                for jj in range(L.H):
+                    P.v("v_accvgpr_read_b32 %s, a%d" % (Mc[jj], regs[jj]), writes=(Mc[jj],))
+                for jj in range(L.H):
+                    if L.H + jj < ns:
+                        P.valu("v_mov_b32_dpp %s, %s row_ror:8 row_mask:0xf bank_mask:0xf" % (Mc[L.H + jj], Mc[jj]),
+                               writes=(Mc[L.H + jj],), dpp=Mc[jj])
+            if move:   # the gain-row / f pointers go from step m+1 to step m
+                P.v("v_add_u32_e32 %[arow], %[drowo], %[arow]")
                 P.v("v_add_u32_e32 %[aaff], %[daff], %[aaff]")
 
         def prefetch_b(m):
+            """second half: the gain rows of step m into lanes nx..15 of the same registers (AFTER the VALU writes
+            above - a later VALU write would clobber them), then f_t / k_t into the accumulator of step m"""
             c, a, _ = sets(m)
-            if not ("read" in X_FWD and in_loop[0]):
-                read_rows(c, a)
+            if "read" in X_FWD and in_loop[0]:
+                return
+            P.raw("s_mov_b64 exec, " + S_HI)
+            read_rows(c, a, aff_too=False)
+            P.raw("s_mov_b64 exec, -1")
+            P.exec_written()
+            P.raw("ds_read_b32 %s, %%[aaff]" % ACC[a])
 
         def prefetch(m, move=True):
             """stage + read the rows of step m (>= 0); returns the number of LDS operations issued"""
@@ -702,7 +707,7 @@ def gen_kernel(nx, nu, write_k, stash):
             return k
 
         FSTUB = 64
-        while FSTUB < 8 * (2 * (len(L.stash_reads) + ns // 2 + 2) + 4):
+        while FSTUB < 8 * (2 * (2 * L.H + ns // 2 + 6) + 4):
             FSTUB *= 2
         lo = int(S_JMP[2:S_JMP.index(":")])
         P.raw("s_getpc_b64 " + S_JMP)
@@ -749,9 +754,12 @@ def gen_kernel(nx, nu, write_k, stash):
         P.label("Lbstub_%=")
         for n in range(1, L.NSTASH + 1):
             P.lines.append(".p2align 5")
-            for p, (w, off) in enumerate(L.stash_reads):
-                op = {4: "ds_read_b32", 8: "ds_read_b64", 16: "ds_read_b128"}[w]
-                P.raw("%s %s, %%[fr%d] offset:%d" % (op, stash_reg(p, n - 1), w, (n % 3) * L.SLOT_B + L.OFF_F + off))
+            for p, (w, off) in enumerate(L.stash_pieces):
+                regs = stash_regs_of(p, n - 1)
+                if w == 2:
+                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], n % 3, off, off + 1))
+                else:
+                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], n % 3, off * 4))
             if X_RET_DIRECT:   # stub n is called from step n-1: the peeled first step, then register sets 1, 2, 0, ...
                 P.raw("s_branch Lret%d_%%=" % (bret["first"] if n == 1 else bret[(n - 1) % 3]))
             else:
@@ -789,9 +797,9 @@ def gen_kernel(nx, nu, write_k, stash):
     if stash:
         for q in range(L.NFD):
             ins.append(("fp%d" % q, '"v"(in.fp[%d])' % q))
-        for w in sorted(set(w for w, _ in L.stash_reads)):
-            ins.append(("fr%d" % w, '"v"(in.fr%d)' % w))
-        ins += [("drowo", '"v"(in.drow)'), ("drowe", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'),
+        for q in range(3):
+            ins.append(("sr%d" % q, '"v"(in.sr[%d])' % q))
+        ins += [("drowo", '"v"(in.drow)'), ("daff", '"v"(in.daff)'),
                 ("farea", '"s"(in.farea)')]
     else:
         for q in range(L.ndma_f):
@@ -801,7 +809,7 @@ def gen_kernel(nx, nu, write_k, stash):
         ins.append(("dk", '"v"(in.dk)'))
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)')]
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
-        ['"s%d"' % i for i in ([70] + list(range(72, 90)))] + ['"vcc"', '"scc"', '"memory"']
+        ['"s%d"' % i for i in ([70] + list(range(72, 92)))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
     name = "LqrAsm<%d, %d, %s, %s>" % (nx, nu, tf(write_k), tf(stash))
@@ -814,8 +822,8 @@ def gen_kernel(nx, nu, write_k, stash):
              % (L.ndma_b, L.ndma_f, L.SLOT_B, L.SLOT_F, L.RING, KROW, DF))
     o.append("  static constexpr int OFF_C = %d, OFF_c = %d, OFF_F = %d, OFF_f = %d, FOFF_f = %d;\n"
              % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
-    o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, STAGE = %d, SPD = %d;\n"
-             % (L.NSTASH, L.NFD, L.FAREA, L.STAGE, L.SPD))
+    o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, HROW = %d, SPD = %d;\n"
+             % (L.NSTASH, L.NFD, L.FAREA, L.H, L.SPD))
     # block 1: the first DB groups
     rw1 = [("ptr%d" % q, '"+v"(in.ptr[%d])' % q) for q in range(L.ndma_b)] + [("tf", '"+s"(in.tf)')]
     ins1 = []
@@ -867,7 +875,7 @@ struct LqrAsmIn {
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
   uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
-  unsigned fr4, fr8, fr16;           // stash variant: ring + lane64 * {4, 8, 16} (linear piece addresses)
+  unsigned sr[3];                    // stash variant: LDS byte address of this lane's half row of F in ring slot 0, 1, 2
   unsigned farea;                    // stash variant (wave-uniform): LDS byte address of this wave's f area
   unsigned arow, aaff, drow, drow2, daff, daff2;
   uint64_t pst, dst;                 // [x_{t+1} | u_t] store pointer and time stride

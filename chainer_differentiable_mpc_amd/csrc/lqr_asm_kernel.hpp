@@ -10,13 +10,14 @@
 //
 // Two variants of the forward sweep.  Ring: F and f are fetched a second time by LDS-DMA (any T whose gains fit
 // in LDS).  Stash (T <= NSTASH): while the backward sweep has F_t in its ring slot it also parks the block in
-// accumulation registers (AGPRs, 5 per step at (8,2) - the one on-chip store large enough: 251 KB per CU), f is
+// accumulation registers (AGPRs, 5 per step at (8,2) - the one on-chip store large enough: 251 KB per CU) in the half-row layout the
+// forward sweep consumes (lane i: columns [0, H) of row i, lane 8+i: the rest, brought over by a DPP row rotation), f is
 // fetched once more into LDS by a handful of DMAs in the prologue, and the forward sweep reads no F from memory at
 // all - it is bandwidth bound otherwise (70 MB at the headline shape, a third of the kernel's traffic).
 //
 // LDS (dynamic), per 256-thread workgroup:
 //   [0, 4*RING)                    one ring per wave: DB backward slots [C|c|F|f] of the wave's 4 trajectories,
-//                                  later DF forward slots [F|f] (ring) or two F staging buffers (stash)
+//                                  later DF forward slots [F|f] (ring variant only)
 //   [.., + 4*FAREA)                stash only: f of all timesteps of the wave's 4 trajectories
 //   [.., + 16*T*NU*KROW*4)         gain rows [K_m | 0 | k_m | pad] per trajectory, time-major, zero-initialised
 #pragma once
@@ -144,9 +145,12 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   for (int q = 0; q < 2; ++q) in.fptr[q] = in.fstr[q] = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) in.fp[q] = 0;
-  in.fr4 = ring + (unsigned)lane64 * 4u;
-  in.fr8 = ring + (unsigned)lane64 * 8u;
-  in.fr16 = ring + (unsigned)lane64 * 16u;
+  {  // stash: lane i < 8 of a row parks columns [0, H) of row i of F_t, lane 8 + i columns [H, ns)
+    const int i8 = (lane & 7) < NX ? (lane & 7) : NX - 1;
+    const unsigned half_row = (unsigned)(G::OFF_F + ((r * NX + i8) * NS + (lane >> 3) * G::HROW) * 4);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) in.sr[q] = ring + (unsigned)(q * G::SLOT_B) + half_row;
+  }
   in.farea = __builtin_amdgcn_readfirstlane(farea);
   if constexpr (STASH) {
     // f of timestep tt (the wave's 4 trajectories, nx chunks) lives at farea + tt*nx*16: DMA q brings SPD steps
@@ -157,11 +161,12 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
       if (tt > T - 2) tt = T - 2;  // nothing past f_{T-2} exists (or is read)
       in.fp[q] = reinterpret_cast<uint64_t>(fb) + ((size_t)tt * B + (size_t)b0) * per_f + (size_t)(lane64 % NX) * 16;
     }
-    // F of step n = T-1-t is staged in buffer n % 2 of the ring; the first step is t = 0, n = T-1
-    in.arow = row_x ? ring + (unsigned)(((T - 1) & 1) * G::STAGE + (r * NX + lane) * NS * 4) : arow_u;
+    // F comes out of the stash registers; LDS serves the gain rows (lanes nx..15 only - lanes < nx carry an address
+    // they never use) and f_t / k_t
+    in.arow = arow_u;
     in.aaff = row_x ? farea + (unsigned)((r * NX + lane) * 4) : arow_u + (unsigned)(NS * 4);
-    in.drow = row_x ? 0u - (unsigned)G::STAGE : (unsigned)(NU * KROW * 4);   // leaving an odd n
-    in.drow2 = row_x ? (unsigned)G::STAGE : (unsigned)(NU * KROW * 4);       // leaving an even n
+    in.drow = (unsigned)(NU * KROW * 4);
+    in.drow2 = in.drow;
     in.daff = row_x ? (unsigned)(NX * 16) : (unsigned)(NU * KROW * 4);
     in.daff2 = in.daff;
   } else {
