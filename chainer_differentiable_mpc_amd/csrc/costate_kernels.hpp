@@ -55,16 +55,30 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   const float wa = 0.5f, wb = a.dC_mode == 0 ? 1.0f : 0.5f;
 
   float lam = 0.f, dlam = 0.f;  // lambda_{t+1}[lane], d_lambda_{t+1}[lane]  (lanes < NX)
-  for (int t = T - 1; t >= 0; --t) {
-    const size_t tb = (size_t)t * B + b;
-    // tau_t, dtau_t: element per lane
-    const float tau = lane_t < NX ? a.x[tb * NX + lane_t] : a.u[tb * NU + (lane_t - NX)];
-    const float dtau = lane_t < NX ? a.dx[tb * NX + lane_t] : a.du[tb * NU + (lane_t - NX)];
-    float Crow[NS];
-    load_contig<NS>(a.C + (tb * NS + lane_x) * NS, Crow);
-    const float ci = a.c[tb * NS + lane_x];
-    const float ri = a.r[tb * NS + lane_x];
 
+  // Inputs of one timestep.  With one wavefront per SIMD nothing else hides HBM latency, so the loads of step
+  // t-1 are issued before step t is computed (two banks, statically ping-ponged - hipcc drains vmcnt at a loop
+  // header, so the prefetch has to sit in the same iteration as the compute it overlaps).
+  struct Slot {
+    float tau, dtau, ci, ri;
+    float Crow[NS], Fcol[NX];
+  };
+  auto load = [&](int t, Slot &s) {
+    t = t < 0 ? 0 : t;  // the prefetch past t = 0 re-reads step 0 (never consumed)
+    const size_t tb = (size_t)t * B + b;
+    s.tau = lane_t < NX ? a.x[tb * NX + lane_t] : a.u[tb * NU + (lane_t - NX)];
+    s.dtau = lane_t < NX ? a.dx[tb * NX + lane_t] : a.du[tb * NU + (lane_t - NX)];
+    load_contig<NS>(a.C + (tb * NS + lane_x) * NS, s.Crow);
+    s.ci = a.c[tb * NS + lane_x];
+    s.ri = a.r[tb * NS + lane_x];
+    const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);  // there is no F_{T-1}
+    const float *Fp = a.F + ((size_t)tF * B + b) * NX * NS + lane_x;  // column lane_x of F_t[:, :NX]
+#pragma unroll
+    for (int k = 0; k < NX; ++k) s.Fcol[k] = Fp[k * NS];
+  };
+  auto step = [&](int t, const Slot &s) {
+    const size_t tb = (size_t)t * B + b;
+    const float tau = s.tau, dtau = s.dtau;
     // ---- dF_t and df (they use lambda_{t+1}, d_lambda_{t+1})             differentiable_lqr.py:130-133
     if (t < T - 1) {
       if (a.dF != nullptr) {
@@ -88,24 +102,31 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
     if (a.dc != nullptr && live && is_tau) a.dc[tb * NS + lane] = a.out_sign * dtau;
 
     // ---- lambda_t, d_lambda_t                                                 :92,102 / :115,124
-    float nl = ci, ndl = a.r_sign * ri;
+    float nl = s.ci, ndl = a.r_sign * s.ri;
     static_for<0, NS>([&](auto j) {
-      nl = fmaf(Crow[j.value], G::template bcast<j.value>(tau), nl);
-      ndl = fmaf(Crow[j.value], G::template bcast<j.value>(dtau), ndl);
+      nl = fmaf(s.Crow[j.value], G::template bcast<j.value>(tau), nl);
+      ndl = fmaf(s.Crow[j.value], G::template bcast<j.value>(dtau), ndl);
     });
     if (t < T - 1) {
-      const float *Fp = a.F + tb * NX * NS + lane_x;  // column lane_x of F_t[:, :NX]
-      float Fcol[NX];
-#pragma unroll
-      for (int k = 0; k < NX; ++k) Fcol[k] = Fp[k * NS];
       static_for<0, NX>([&](auto k) {
-        nl = fmaf(Fcol[k.value], G::template bcast<k.value>(lam), nl);
-        ndl = fmaf(Fcol[k.value], G::template bcast<k.value>(dlam), ndl);
+        nl = fmaf(s.Fcol[k.value], G::template bcast<k.value>(lam), nl);
+        ndl = fmaf(s.Fcol[k.value], G::template bcast<k.value>(dlam), ndl);
       });
     }
     lam = nl;
     dlam = ndl;
     if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+  };
+
+  Slot sa, sb;
+  load(T - 1, sa);
+  for (int t = T - 1; t >= 0; t -= 2) {
+    load(t - 1, sb);
+    step(t, sa);
+    if (t - 1 >= 0) {
+      load(t - 2, sa);
+      step(t - 1, sb);
+    }
   }
   if (a.dx0 != nullptr && live && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
 }
