@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   float lam = 0.f, dlam = 0.f;  // lambda_{t+1}[lane], d_lambda_{t+1}[lane]  (lanes < NX)
 
   // Inputs of one timestep.  With one wavefront per SIMD nothing else hides HBM latency, so the loads of step
-  // t-1 are issued before step t is computed (two banks, statically ping-ponged - hipcc drains vmcnt at a loop
+  // t-2 are issued before step t is computed (three banks, statically rotated - hipcc drains vmcnt at a loop
   // header, so the prefetch has to sit in the same iteration as the compute it overlaps).
   struct Slot {
     float tau, dtau, ci, ri;
@@ -118,14 +118,19 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
     if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
   };
 
-  Slot sa, sb;
+  Slot sa, sb, sc;  // two steps of loads in flight
   load(T - 1, sa);
-  for (int t = T - 1; t >= 0; t -= 2) {
-    load(t - 1, sb);
+  load(T - 2, sb);
+  for (int t = T - 1; t >= 0; t -= 3) {
+    load(t - 2, sc);
     step(t, sa);
     if (t - 1 >= 0) {
-      load(t - 2, sa);
+      load(t - 3, sa);
       step(t - 1, sb);
+    }
+    if (t - 2 >= 0) {
+      load(t - 4, sb);
+      step(t - 2, sc);
     }
   }
   if (a.dx0 != nullptr && live && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
