@@ -218,7 +218,10 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash):
+def gen_kernel(nx, nu, write_k, stash, masked=False):
+    """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
+    is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
+    rollout needs no change); the value update keeps the unmasked blocks (:143-145)."""
     L = Layout(nx, nu)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
@@ -248,6 +251,10 @@ def gen_kernel(nx, nu, write_k, stash):
     tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = R.take(13)
     MINPIV = R.take(1)[0]
     XV0 = R.take(1)[0]                  # x_init (lanes < nx), loaded by the stream itself
+    ACT = [R.take(nu) for _ in range(3)] if masked else None   # clamped-control flags of the slot in each register set
+    EPS = R.take(1)[0] if masked else None
+    Am = [R.take(nu) for _ in range(nu)] if masked else None   # masked Quu
+    Rm = R.take(nu) if masked else None                        # masked right-hand side rows
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
     RF = Regs(VBASE)
     M = [RF.take(ns, align=4), RF.take(ns, align=4), RF.take(ns, align=4)]
@@ -283,6 +290,10 @@ def gen_kernel(nx, nu, write_k, stash):
     hi = mask64(range(nx, 16))   # the lanes whose row registers take gain rows (lanes < nx take F rows)
     in_loop = [False]
 
+    PADM = 16 * L.nchunk_b              # masked: the flags of the wave's 4 trajectories land in the slot's padding
+    assert not masked or L.SLOT_B - PADM >= 256
+    NDB_ALL = L.ndma_b + (1 if masked else 0)   # VMEM operations per backward group
+
     def issue_group(ptrs, slot, slot_bytes):
         if X_NO_DMA and in_loop[0]:
             return
@@ -294,6 +305,8 @@ def gen_kernel(nx, nu, write_k, stash):
         for q, p in enumerate(ptrs):
             off = (" offset:%d" % (q * 1024)) if q else ""
             P.raw("global_load_lds_dwordx4 %s, off%s" % (p, off))
+        if masked and ptrs is ptr:   # 4 * nu flag bytes = nu dwords, one per lane (the other lanes repeat dword 0)
+            P.raw("global_load_lds_dword %%[pm], off offset:%d" % PADM)
 
     uniq = [0]
 
@@ -304,6 +317,8 @@ def gen_kernel(nx, nu, write_k, stash):
         P.raw("s_cbranch_scc0 " + lab)
         for p, s in zip(ptrs, strides):
             P.v("v_lshl_add_u64 %s, %s, 0, %s" % (p, p, s))
+        if masked and ptrs is ptr:
+            P.v("v_lshl_add_u64 %[pm], %[pm], 0, %[dm]")
         P.raw("s_sub_i32 %s, %s, 1" % (S_TF, S_TF))
         P.label(lab, reset=False)   # only pointer registers are written on the fall-through path
 
@@ -320,6 +335,9 @@ def gen_kernel(nx, nu, write_k, stash):
             P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][i], aq[i], off))
         for k in range(nx):
             P.raw("ds_read_b32 %s, %s offset:%d" % (F[s][k], af[k], off))
+        if masked:
+            for m in range(nu):
+                P.raw("ds_read_u8 %s, %%[am] offset:%d" % (ACT[s][m], off + PADM + m))
 
     def gains(s):
         """K~ = -Quu^-1 [Qux | Quu | qu] per lane (lqr_recursion.py:112-120); leaves A (Quu), Kt, and MINPIV"""
@@ -327,25 +345,43 @@ def gen_kernel(nx, nu, write_k, stash):
         for m in range(nu):
             for l in range(nu):
                 P.mov_dpp(A[m][l], Qs[nx + m], nx + l)
+        rhs = [Qs[nx + m] for m in range(nu)]
+        Au = A
+        if masked:
+            S_ACT = ["s[92:93]", "s[94:95]"]
+            for m in range(nu):
+                P.v("v_cmp_ne_u32_e64 %s, 0, %s" % (S_ACT[m], ACT[s][m]), reads=(ACT[s][m],))
+            if nu == 2:
+                P.raw("s_or_b64 s[96:97], s[92:93], s[94:95]")
+            for m in range(nu):
+                P.v("v_cndmask_b32_e64 %s, %s, 0, %s" % (Rm[m], Qs[nx + m], S_ACT[m]), writes=(Rm[m],), reads=(Qs[nx + m],))
+                for l in range(nu):
+                    if m == l:
+                        P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (Am[m][l], A[m][l], EPS, S_ACT[m]), writes=(Am[m][l],),
+                            reads=(A[m][l], EPS))
+                    else:
+                        P.v("v_cndmask_b32_e64 %s, %s, 0, s[96:97]" % (Am[m][l], A[m][l]), writes=(Am[m][l],), reads=(A[m][l],))
+            rhs = Rm
+            Au = Am
         if nu == 1:
-            P.v("v_rcp_f32_e32 %s, %s" % (tRP, A[0][0]), writes=(tRP,), reads=(A[0][0],), trans=True)
-            P.v("v_min_f32_e64 %s, |%s|, %s" % (MINPIV, A[0][0], MINPIV), writes=(MINPIV,), reads=(A[0][0], MINPIV))
+            P.v("v_rcp_f32_e32 %s, %s" % (tRP, Au[0][0]), writes=(tRP,), reads=(Au[0][0],), trans=True)
+            P.v("v_min_f32_e64 %s, |%s|, %s" % (MINPIV, Au[0][0], MINPIV), writes=(MINPIV,), reads=(Au[0][0], MINPIV))
             P.nop(1)
             if X_NEWTON:
-                P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, A[0][0], tRP), writes=(tT,), reads=(A[0][0], tRP))
+                P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, Au[0][0], tRP), writes=(tT,), reads=(Au[0][0], tRP))
                 P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP))
             P.raw("s_mov_b64 exec, " + S_KM)
-            P.v("v_mul_f32_e64 %s, %s, -%s" % (Kt[0], Qs[nx], tRP), writes=(Kt[0],), reads=(Qs[nx], tRP))
+            P.v("v_mul_f32_e64 %s, %s, -%s" % (Kt[0], rhs[0], tRP), writes=(Kt[0],), reads=(rhs[0], tRP))
         else:
-            a00, a01, a10, a11 = A[0][0], A[0][1], A[1][0], A[1][1]
+            a00, a01, a10, a11 = Au[0][0], Au[0][1], Au[1][0], Au[1][1]
             P.v("v_cmp_gt_f32_e64 vcc, |%s|, |%s|" % (a10, a00), reads=(a10, a00))
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tP, a00, a10), writes=(tP,), reads=(a00, a10))
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tL0, a10, a00), writes=(tL0,), reads=(a00, a10))
             P.v("v_rcp_f32_e32 %s, %s" % (tRP, tP), writes=(tRP,), reads=(tP,), trans=True)
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tPQ, a01, a11), writes=(tPQ,), reads=(a01, a11))
             P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tM1, a11, a01), writes=(tM1,), reads=(a01, a11))
-            P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRA, Qs[nx], Qs[nx + 1]), writes=(tRA,), reads=(Qs[nx], Qs[nx + 1]))
-            P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRB, Qs[nx + 1], Qs[nx]), writes=(tRB,), reads=(Qs[nx], Qs[nx + 1]))
+            P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRA, rhs[0], rhs[1]), writes=(tRA,), reads=(rhs[0], rhs[1]))
+            P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRB, rhs[1], rhs[0]), writes=(tRB,), reads=(rhs[0], rhs[1]))
             if X_NEWTON:
                 P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, tP, tRP), writes=(tT,), reads=(tP, tRP))
                 P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP))
@@ -429,7 +465,7 @@ def gen_kernel(nx, nu, write_k, stash):
                     P.fmac_dpp(W[i], V[i], F[s][k], k)
             for i in range(nx):
                 P.fmac_dpp(W[i], V[i], "%[eaff]", aff)
-        vmwait((DB - 1) * L.ndma_b + extra_outstanding)
+        vmwait((DB - 1) * NDB_ALL + extra_outstanding)
         read_set(n, n)
         if stash:
             # F of the NEXT step goes from its ring slot into this step's stash registers: the register numbers
@@ -490,6 +526,8 @@ def gen_kernel(nx, nu, write_k, stash):
     for m in range(nu):
         P.v("v_mov_b32_e32 %s, 0" % Kt[m], writes=(Kt[m],))
     P.v("v_mov_b32_e32 %s, 0x7f7fffff" % MINPIV, writes=(MINPIV,))
+    if masked:
+        P.v("v_mov_b32_e32 %s, 0x322bcc77" % EPS, writes=(EPS,))   # 1e-8f (active_constrained_lqr.py:121-122)
     if stash:
         lo = int(S_STUB[2:S_STUB.index(":")])
         P.raw("s_getpc_b64 " + S_STUB)
@@ -533,7 +571,7 @@ def gen_kernel(nx, nu, write_k, stash):
     P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
     P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
     P.raw("s_cbranch_scc1 Lzero_%=")
-    P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * L.ndma_b + n_extra))
+    P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * NDB_ALL + n_extra))
     read_set(0, 0)
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
     P.comment("---- t = T-1")
@@ -785,6 +823,8 @@ def gen_kernel(nx, nu, write_k, stash):
     if write_k:
         for m in range(nu):
             rw.append(("pk%d" % m, '"+v"(in.pk[%d])' % m))
+    if masked:
+        rw.append(("pm", '"+v"(in.pm)'))
     ins = []
     for q in range(L.ndma_b):
         ins.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
@@ -807,29 +847,35 @@ def gen_kernel(nx, nu, write_k, stash):
         ins += [("drow", '"v"(in.drow)'), ("drow2", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'), ("daff2", '"v"(in.daff2)')]
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
+    if masked:
+        ins += [("dm", '"v"(in.dm)'), ("am", '"v"(in.am)')]
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)')]
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
-        ['"s%d"' % i for i in ([70] + list(range(72, 92)))] + ['"vcc"', '"scc"', '"memory"']
+        ['"s%d"' % i for i in ([70] + list(range(72, 98)))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
-    name = "LqrAsm<%d, %d, %s, %s>" % (nx, nu, tf(write_k), tf(stash))
+    name = "LqrAsm<%d, %d, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked))
     o = []
-    o.append("// (%d,%d) write_k=%d stash=%d: %d instructions in prologue + 4 backward steps, %d in %d unrolled forward steps\n"
-             % (nx, nu, write_k, stash, n_bwd, n_fwd, n_fwd_steps))
+    o.append("// (%d,%d) write_k=%d stash=%d masked=%d: %d instructions in prologue + 4 backward steps, %d in %d unrolled forward steps\n"
+             % (nx, nu, write_k, stash, masked, n_bwd, n_fwd, n_fwd_steps))
     o.append("template <>\nstruct %s {\n" % name)
     o.append("  static constexpr bool kAvailable = true;\n")
     o.append("  static constexpr int NDB = %d, NDF = %d, SLOT_B = %d, SLOT_F = %d, RING_BYTES = %d, KROW = %d, DEPTH_F = %d;\n"
              % (L.ndma_b, L.ndma_f, L.SLOT_B, L.SLOT_F, L.RING, KROW, DF))
     o.append("  static constexpr int OFF_C = %d, OFF_c = %d, OFF_F = %d, OFF_f = %d, FOFF_f = %d;\n"
              % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
-    o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, HROW = %d, SPD = %d;\n"
-             % (L.NSTASH, L.NFD, L.FAREA, L.H, L.SPD))
+    o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, HROW = %d, SPD = %d, PADM = %d;\n"
+             % (L.NSTASH, L.NFD, L.FAREA, L.H, L.SPD, 16 * L.nchunk_b))
     # block 1: the first DB groups
     rw1 = [("ptr%d" % q, '"+v"(in.ptr[%d])' % q) for q in range(L.ndma_b)] + [("tf", '"+s"(in.tf)')]
+    if masked:
+        rw1.append(("pm", '"+v"(in.pm)'))
     ins1 = []
     for q in range(L.ndma_b):
         ins1.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
         ins1.append(("str%d" % q, '"v"(in.str[%d])' % q))
+    if masked:
+        ins1.append(("dm", '"v"(in.dm)'))
     ins1 += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)')]
     o.append("  static __device__ __forceinline__ void issue_first(LqrAsmIn<%d, %d> &in) {\n" % (nx, nu))
     o.append("    asm volatile(\n")
@@ -872,6 +918,8 @@ struct LqrAsmIn {
   int tf;                            // wave-uniform: time strides the DMA pointers may still take (set by issue_first)
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
+  uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
+  unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
   uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
@@ -886,7 +934,7 @@ struct LqrAsmIn {
   unsigned ts[4];                    // GEN_TIMING builds only: s_memtime at the phase boundaries
 };
 
-template <int NX, int NU, bool WRITE_K, bool STASH>
+template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false>
 struct LqrAsm {
   static constexpr bool kAvailable = false;
 };
@@ -903,9 +951,12 @@ def main():
     for nx, nu in SHAPES:
         for write_k in (False, True):
             for stash in (False, True):
-                if stash and not Layout(nx, nu).stash_ok:
+                L0 = Layout(nx, nu)
+                if stash and not L0.stash_ok:
                     continue
                 out.append(gen_kernel(nx, nu, write_k, stash))
+                if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding
+                    out.append(gen_kernel(nx, nu, write_k, stash, masked=True))
     out.append("}  // namespace dmpc\n")
     with open(OUT, "w") as fh:
         fh.write("".join(out))

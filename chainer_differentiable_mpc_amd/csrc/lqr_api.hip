@@ -76,6 +76,29 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
     // fastest path: the whole solve as one generated instruction stream (lqr_asm_kernel.hpp); with the F stash
     // (no second read of F) when the horizon fits the stash registers
+    if constexpr (LqrAsm<NX, NU, false, false, true>::kAvailable) {
+      // LQR_active on the generated stream: same paths, flags fetched as dwords (B * nu must be a multiple of 4)
+      const int mpath = (mode == kSolve && masked && a.Ks == nullptr && (a.B * NU) % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(a.mask) & 3u) == 0)
+                            ? solve_path<NX, NU, L>(a.T, a.B) : 0;
+      if (mpath >= 3) {
+        const int waves = (a.B + 3) / 4;
+        const dim3 g((waves + 3) / 4);
+        const bool has_f = a.f != nullptr;
+#define DMPC_ASM_LAUNCH_M(STASH)                                                                                        \
+  do {                                                                                                                  \
+    const size_t shmem = lqr_asm_lds_bytes<NX, NU, STASH>(a.T);                                                         \
+    if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, STASH, true>), g, block, shmem, stream, a);      \
+    else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, STASH, true>), g, block, shmem, stream, a);           \
+    return (int)hipGetLastError();                                                                                      \
+  } while (0)
+        if constexpr (LqrAsm<NX, NU, false, true, true>::kAvailable) {
+          if (mpath == 4) DMPC_ASM_LAUNCH_M(true);
+        }
+        DMPC_ASM_LAUNCH_M(false);
+#undef DMPC_ASM_LAUNCH_M
+      }
+    }
     const int path = (mode == kSolve && !masked) ? solve_path<NX, NU, L>(a.T, a.B) : 0;
     if (path >= 3) {
       const int waves = (a.B + 3) / 4;

@@ -40,9 +40,11 @@ constexpr size_t lqr_asm_lds_bytes(int T) {
          4 * round_up((size_t)4 * T * NU * G::KROW * 4, 1024);  // per wave: whole 1 KB pieces (zero fill)
 }
 
-template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH>
+// MASKED: LQR_active (mpc/active_constrained_lqr.py) - a.mask [T,B,nu] uint8 marks the clamped controls; needs
+// B * nu to be a multiple of 4 (the flags of a wave's four trajectories are fetched as whole dwords).
+template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
-  using G = LqrAsm<NX, NU, WRITE_K, STASH>;
+  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED>;
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU, AFF = NS, KROW = G::KROW;
   constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
@@ -104,6 +106,15 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     const uint64_t s = (uint64_t)0 - (uint64_t)(B * per);
     in.str[q] = s;
     in.str1[q] = dyn ? 0 : s;  // there is no F_{T-1}: the first group fetches F_{T-2} (unused), as does the second
+  }
+  if constexpr (MASKED) {  // dword i < nu of the 4 * nu flag bytes of this wave and timestep; the other lanes repeat dword 0
+    in.pm = reinterpret_cast<uint64_t>(a.mask) + ((size_t)(T - 1) * B + (size_t)b0) * NU + (size_t)(lane64 < NU ? lane64 : 0) * 4 -
+            (uint64_t)G::PADM;  // the instruction offset that places the dwords in the slot padding moves the source too
+    in.dm = (uint64_t)0 - (uint64_t)(B * NU);
+    in.am = ring + (unsigned)(r * NU);
+  } else {
+    in.pm = in.dm = 0;
+    in.am = 0;
   }
   // The first DB groups leave NOW; everything below (LDS read addresses, store pointers, the forward sweep's
   // operands) is computed while they are in flight.  No memory operation of this C++ code may follow: x_init

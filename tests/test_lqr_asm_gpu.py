@@ -128,3 +128,24 @@ def test_quu_that_needs_row_interchanges(shape):
     assert int(rec.info.abs().max().item()) == 0
     assert_close(npy(x), xr, 5e-4, "x")
     assert_close(npy(u), ur, 5e-4, "u")
+
+
+@pytest.mark.parametrize("shape", [(64, 50, 8, 2), (8, 10, 8, 2), (12, 52, 8, 2), (16, 20, 3, 1), (8, 9, 4, 2),
+                                   (8, 6, 2, 2), (8, 6, 1, 1), (8, 7, 2, 1), (6, 9, 8, 2), (7, 9, 8, 2)])
+@pytest.mark.parametrize("with_f", [False, True])
+def test_active_set_lqr_on_the_generated_stream(shape, with_f):
+    """LQR_active (mpc/active_constrained_lqr.py:67-202): clamped controls get exactly-zero gain rows and controls.
+    B * nu a multiple of 4 runs the masked generated stream, the last two shapes fall back to the HIP kernel."""
+    from chainer_differentiable_mpc_amd import LQR_active
+    from oracle import mpc as ompc
+    B, T, nx, nu = shape
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=31, with_f=with_f)
+    rng = np.random.RandomState(9)
+    act = rng.rand(T, B, nu) < 0.4
+    xr, ur = ompc.lqr_active_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], act, T, nx, nu)
+    d = to_dev(p)
+    rec = LQR_active(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu, u_zero_Index=torch.as_tensor(act).cuda())
+    x, u = rec.solve_recursion()
+    assert_close(npy(x), xr, 2e-4, "x")
+    assert_close(npy(u), ur, 2e-4, "u")
+    assert np.all(npy(u)[act] == 0)
