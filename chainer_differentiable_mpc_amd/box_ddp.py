@@ -112,8 +112,13 @@ class BoxDDP(torch.nn.Module):
         for_out = None
         for i in range(self.max_iter):
             with torch.no_grad():
-                x = get_traj(T, u, x_init.detach(), detached_dyn())
-                Cm, cm, Fm, fm = models(x, u)
+                if hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x_init, u) and isinstance(cost, QuadCost):
+                    # pendulum: rollout and linearisation in one launch (get_traj + linearize_dynamics, :123-136)
+                    x, Fm, fm = dynamics.rollout_linearize(x_init.detach(), u)
+                    Cm, cm = cost.C, cost.c
+                else:
+                    x = get_traj(T, u, x_init.detach(), detached_dyn())
+                    Cm, cm, Fm, fm = models(x, u)
                 step = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu,
                                current_states=x, true_cost=detached_cost(), true_dynamics=detached_dyn(),
                                ls_decay=self.ls_decay, max_ls_iter=self.max_ls_iter, verbose=self.ilqr_verbose,
@@ -149,7 +154,11 @@ class BoxDDP(torch.nn.Module):
         x, u = best['x'], best['u']
         costs = best['costs']
         # Taylor models at the best point and a no-op MPCstep node that carries the gradient (:234-259)
-        Cm, cm, Fm, fm = models(x, u)
+        if hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x[0], u) and isinstance(cost, QuadCost):
+            _, Fm, fm = dynamics.rollout_linearize(x[0], u)   # constants of the graph: the pendulum is not learnt
+            Cm, cm = cost.C, cost.c
+        else:
+            Cm, cm, Fm, fm = models(x, u)
         if self.update_dynamics:
             Cm, cm = Cm.detach(), cm.detach()
         else:

@@ -162,6 +162,34 @@ int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const fl
   return launch_mpc_fwd(nx, nu, fa, static_cast<hipStream_t>(stream_));
 }
 
+int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks, const float *controls,
+                                  const float *states, const float *u_lower, const float *u_upper,
+                                  const float *C_true, const float *c_true, float g, float m, float l, float dt,
+                                  float max_torque, float ls_decay, int max_ls_iter, float *x_out, float *u_out,
+                                  float *costs, float *old_costs, float *alphas, float *objs, float *u_first,
+                                  int32_t *n_ls_iter, int32_t *info, dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0) return DMPC_E_BADARG;
+  if (!Ks || !ks || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !x_out || !u_out || !costs ||
+      !alphas || !n_ls_iter)
+    return DMPC_E_BADARG;
+  if (!aligned16(C_true)) return DMPC_E_BADARG;
+  MpcFwdArgs fa{T, B, Ks, ks, controls, states, u_lower, u_upper, C_true, c_true, nullptr, nullptr, ls_decay,
+                max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info,
+                /*dyn_kind=*/1, g, m, l, dt, max_torque};
+  return launch_mpc_fwd(3, 1, fa, static_cast<hipStream_t>(stream_));
+}
+
+int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const float *u, float g, float m, float l,
+                                    float dt, float max_torque, float *x_out, float *F_out, float *f_out,
+                                    dmpc_stream_t stream_) {
+  if (T <= 0 || B <= 0 || !x_init || !u || !x_out) return DMPC_E_BADARG;
+  if (f_out != nullptr && F_out == nullptr) return DMPC_E_BADARG;
+  PendulumArgs pa{T, B, x_init, u, g, m, l, dt, max_torque, x_out, F_out, f_out};
+  hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0,
+                     static_cast<hipStream_t>(stream_), pa);
+  return (int)hipGetLastError();
+}
+
 size_t dmpc_mpc_step_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
   return mpc_layout(T, B, nx, nu).total;

@@ -171,6 +171,10 @@ struct MpcFwdArgs {
   float *objs;                           // [T,B] per-step cost of the accepted pass, or nullptr
   int32_t *n_ls;                         // [B] passes run
   int32_t *info;
+  // TRUE dynamics other than LinDx, evaluated inside the line search (mpc_step.py:237-240 calls a Python callable):
+  //   0 LinDx (F, f above)   1 the pendulum of env_dx/pendulum.py:65-102, simple model (nx = 3, nu = 1)
+  int dyn_kind;
+  float pend_g, pend_m, pend_l, pend_dt, pend_max_torque;
 };
 
 template <int NX, int NU, int L>
@@ -246,7 +250,17 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
         if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
         if (a.u_first != nullptr && n_pass == 0 && lane >= NX && lane < NS) a.u_first[tb * NU + (lane - NX)] = tau;
       }
-      if (t < T - 1) {  // new_x_{t+1} = F_t [new_x;new_u] + f_t under the TRUE dynamics   :229-236
+      if (t < T - 1 && a.dyn_kind == 1) {  // built-in pendulum (cos th, sin th, dth), torque -> next   pendulum.py:84-98
+        if constexpr (NX == 3 && NU == 1) {
+          const float cs = G::template bcast<0>(tau), sn = G::template bcast<1>(tau), dth = G::template bcast<2>(tau);
+          float uu = G::template bcast<3>(tau);
+          uu = fminf(fmaxf(uu, -a.pend_max_torque), a.pend_max_torque);
+          const float th = atan2f(sn, cs);
+          const float newdth = dth + a.pend_dt * (-3.f * a.pend_g / (2.f * a.pend_l) * (-sn) + 3.f * uu / (a.pend_m * (a.pend_l * a.pend_l)));
+          const float newth = th + newdth * a.pend_dt;
+          xh = lane == 0 ? cosf(newth) : (lane == 1 ? sinf(newth) : (lane == 2 ? newdth : 0.f));
+        }
+      } else if (t < T - 1) {  // new_x_{t+1} = F_t [new_x;new_u] + f_t under the TRUE dynamics   :229-236
         float Frow[NS];
         load_contig<NS>(a.F + (tb * NX + lane_x) * NS, Frow);
         float acc = has_f ? a.f[tb * NX + lane_x] : 0.f;
@@ -270,6 +284,65 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
     a.alphas[b] = alpha;
     a.n_ls[b] = n_pass;
     if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+  }
+}
+
+// Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
+// (env_dx/pendulum.py:84-98, simple model), F_t = d x_{t+1} / d [x_t; u_t], f_t = x_{t+1} - F_t [x_t; u_t] - what
+// BoxDDP obtains from get_traj (util.py:201-277) followed by linearize_dynamics (mpc/approximate.py:77-119, there
+// through chainer.grad).  The torque clamp has derivative 1 strictly inside (-max_torque, max_torque), else 0.
+struct PendulumArgs {
+  int T, B;
+  const float *x_init, *u;   // [B,3], [T,B,1]
+  float g, m, l, dt, max_torque;
+  float *x, *F, *f;          // [T,B,3], [T-1,B,3,4] or nullptr, [T-1,B,3] or nullptr
+};
+
+__global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const PendulumArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const size_t B = (size_t)a.B;
+  float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
+  const float kg = 3.f * a.g / (2.f * a.l), ku = 3.f / (a.m * (a.l * a.l));
+  for (int t = 0; t < a.T; ++t) {
+    const size_t tb = (size_t)t * B + b;
+    a.x[tb * 3 + 0] = c;
+    a.x[tb * 3 + 1] = s;
+    a.x[tb * 3 + 2] = w;
+    if (t == a.T - 1) break;
+    const float ur = a.u[tb];
+    const float uc = fminf(fmaxf(ur, -a.max_torque), a.max_torque);
+    const float inside = (ur > -a.max_torque && ur < a.max_torque) ? 1.f : 0.f;
+    const float r2 = c * c + s * s;
+    const float th = atan2f(s, c);
+    const float nw = w + a.dt * (kg * s + ku * uc);
+    const float nth = th + nw * a.dt;
+    const float sn = sinf(nth), cn = cosf(nth);
+    if (a.F != nullptr) {
+      const float dnw[4] = {0.f, a.dt * kg, 1.f, a.dt * ku * inside};
+      const float dnth[4] = {-s / r2 + a.dt * dnw[0], c / r2 + a.dt * dnw[1], a.dt * dnw[2], a.dt * dnw[3]};
+      float *Fp = a.F + tb * 12;
+      const float xin[4] = {c, s, w, ur};
+      float f0 = cn, f1 = sn, f2 = nw;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float r0 = -sn * dnth[j], r1 = cn * dnth[j], r2_ = dnw[j];
+        Fp[j] = r0;
+        Fp[4 + j] = r1;
+        Fp[8 + j] = r2_;
+        f0 = fmaf(-r0, xin[j], f0);
+        f1 = fmaf(-r1, xin[j], f1);
+        f2 = fmaf(-r2_, xin[j], f2);
+      }
+      if (a.f != nullptr) {
+        a.f[tb * 3 + 0] = f0;
+        a.f[tb * 3 + 1] = f1;
+        a.f[tb * 3 + 2] = f2;
+      }
+    }
+    c = cn;
+    s = sn;
+    w = nw;
   }
 }
 

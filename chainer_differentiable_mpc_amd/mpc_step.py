@@ -29,6 +29,12 @@ LqrBackOut = namedtuple("lqrBackOut", "n_total_qp_iter")
 LqrForOut = namedtuple("lqrForOut", "objs full_du_norm alpha_du_norm mean_alphas costs")
 
 
+def _is_simple_pendulum(dyn):
+    """PendulumDx with the 3-parameter model (the one the imitation experiments use, env_dx/pendulum.py:40-63)"""
+    from .pendulum import PendulumDx
+    return isinstance(dyn, PendulumDx) and dyn.simple
+
+
 def du_norm(u_old, u_new, scrambled=True):
     du = u_old - u_new
     T, B, nu = du.shape
@@ -171,6 +177,26 @@ class MPCstep:
                                               _lib.ptr(u1), _lib.ptr(nls), _lib.ptr(info), _lib.stream_ptr(d))
             _lib.check(rc, "dmpc_mpc_forward_rec")
             raise_info(info, "MPCstep.forward_rec")                                   # mpc_step.py:284-285
+        elif isinstance(true_cost, QuadCost) and _is_simple_pendulum(true_dynamics) and (nx, nu) == (3, 1):
+            # the pendulum of env_dx/pendulum.py evaluated inside the kernel's line search (mpc_step.py:237-240)
+            lib = _lib.load()
+            Ct, ct = _lib.f32c(_as_tensor(true_cost.C), d), _lib.f32c(_as_tensor(true_cost.c), d)
+            g_, m_, l_ = (float(v) for v in true_dynamics.params.detach().cpu().tolist())
+            f32 = dict(dtype=torch.float32, device=d)
+            x, u, u1 = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32), torch.empty((T, B, nu), **f32)
+            costs, old, alphas = torch.empty((B,), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
+            objs = torch.empty((T, B), **f32)
+            nls = torch.empty((B,), dtype=torch.int32, device=d)
+            info = torch.zeros(B, dtype=torch.int32, device=d)
+            with torch.cuda.device(d):
+                rc = lib.dmpc_mpc_forward_rec_pendulum(
+                    T, B, _lib.ptr(Kd), _lib.ptr(kd), _lib.ptr(self._u), _lib.ptr(self._xs), _lib.ptr(self._lo),
+                    _lib.ptr(self._hi), _lib.ptr(Ct), _lib.ptr(ct), g_, m_, l_, float(true_dynamics.dt),
+                    float(true_dynamics.max_torque), float(ls_decay), int(max_ls_iter), _lib.ptr(x), _lib.ptr(u),
+                    _lib.ptr(costs), _lib.ptr(old), _lib.ptr(alphas), _lib.ptr(objs), _lib.ptr(u1), _lib.ptr(nls),
+                    _lib.ptr(info), _lib.stream_ptr(d))
+            _lib.check(rc, "dmpc_mpc_forward_rec_pendulum")
+            raise_info(info, "MPCstep.forward_rec")
         else:
             x, u, u1, costs, alphas, objs, nls = self._forward_rec_callable(Kd, kd, true_cost, true_dynamics,
                                                                             ls_decay, max_ls_iter)

@@ -79,6 +79,31 @@ class PendulumDx(torch.nn.Module):
             xs.append(new_x)
         return torch.stack(Fs, 0), torch.stack(fs, 0)
 
+    def fused_ok(self, x_init, u):
+        """the one-launch rollout + linearisation applies: simple model, float tensors on the GPU, no gradient
+        wanted through the parameters"""
+        return (self.simple and isinstance(x_init, torch.Tensor) and x_init.is_cuda and u.is_cuda and
+                not self.params.requires_grad and not x_init.requires_grad and not u.requires_grad)
+
+    def rollout_linearize(self, x_init, u, want_model=True):
+        """(x [T,B,3], F [T-1,B,3,4], f [T-1,B,3]) from x_init [B,3], u [T,B,1] in one kernel launch
+        (`dmpc_pendulum_rollout_linearize`): get_traj + linearize_dynamics of the reference's BoxDDP loop"""
+        from . import _lib
+        lib = _lib.load()
+        T, B = u.shape[0], u.shape[1]
+        d = x_init.device
+        x0, ud = _lib.f32c(x_init.detach(), d), _lib.f32c(u.detach(), d)
+        x = torch.empty((T, B, 3), dtype=torch.float32, device=d)
+        F = torch.empty((max(T - 1, 0), B, 3, 4), dtype=torch.float32, device=d) if want_model else None
+        f = torch.empty((max(T - 1, 0), B, 3), dtype=torch.float32, device=d) if want_model else None
+        g_, m_, l_ = (float(v) for v in self.params.detach().cpu().tolist())
+        with torch.cuda.device(d):
+            rc = lib.dmpc_pendulum_rollout_linearize(T, B, _lib.ptr(x0), _lib.ptr(ud), g_, m_, l_, float(self.dt),
+                                                     float(self.max_torque), _lib.ptr(x), _lib.ptr(F), _lib.ptr(f),
+                                                     _lib.stream_ptr(d))
+        _lib.check(rc, "dmpc_pendulum_rollout_linearize")
+        return x.to(x_init.dtype), (None if F is None else F.to(x_init.dtype)), (None if f is None else f.to(x_init.dtype))
+
     def get_true_obj(self):
         """(q, p): diagonal of Q and linear term of the true quadratic cost   (pendulum.py:122-145)"""
         q = torch.cat((self.goal_weights, self.ctrl_penalty * torch.ones(self.n_ctrl)))

@@ -140,6 +140,24 @@ int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const fl
                          float *alphas, float *objs, float *u_first, int32_t *n_ls_iter, int32_t *info,
                          dmpc_stream_t stream);
 
+/* forward_rec with the TRUE dynamics of the pendulum (env_dx/pendulum.py:65-102, simple model: parameters g, m, l;
+ * time step dt; torque clamp max_torque) evaluated inside the kernel's line search - the reference calls the
+ * Python callable once per timestep and pass (mpc_step.py:237-240).  nx = 3 (cos th, sin th, dth), nu = 1. */
+int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks, const float *controls,
+                                  const float *states, const float *u_lower, const float *u_upper,
+                                  const float *C_true, const float *c_true, float g, float m, float l, float dt,
+                                  float max_torque, float ls_decay, int max_ls_iter, float *x_out, float *u_out,
+                                  float *costs, float *old_costs, float *alphas, float *objs, float *u_first,
+                                  int32_t *n_ls_iter, int32_t *info, dmpc_stream_t stream);
+
+/* Caller-side helper of the pendulum experiments: rollout x_{t+1} = pendulum(x_t, u_t)
+ * (util.py:201-277 get_traj with env_dx/pendulum.py:65-102) and its analytic linearisation
+ * F_t [x_t;u_t] + f_t = pendulum(x_t, u_t) (mpc/approximate.py:77-119, there by chainer.grad) in one launch.
+ *   x_out [T,B,3];  F_out [T-1,B,3,4] or NULL;  f_out [T-1,B,3] or NULL */
+int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const float *u, float g, float m, float l,
+                                    float dt, float max_torque, float *x_out, float *F_out, float *f_out,
+                                    dmpc_stream_t stream);
+
 /* backward(): active-set LQR on (-d_tau) + co-state sweeps + outer products (mpc_step.py:330-460).
  *   outputs carry the reference's signs: dC = -1/2(dtau'(x)tau + tau(x)dtau'), dc = -dtau',
  *   dF = -(dlam(x)tau + lam(x)dtau'), df = -dlam[1:] (NULL to skip), dx_init = -dlam[0].  */

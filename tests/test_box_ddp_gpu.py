@@ -167,3 +167,24 @@ def test_mpcnet_gradient_flows_to_dynamics_parameters():
         assert_close(got, dF, 2e-3, "d(A|B)")
     else:   # unconverged samples are detached (box_ddp.py:263-289): only check the gradient is finite and non-zero
         assert np.isfinite(got).all() and np.abs(got).max() > 0
+
+
+def test_fused_pendulum_rollout_and_linearisation():
+    """dmpc_pendulum_rollout_linearize against the torch restatement of env_dx/pendulum.py:84-98 and its analytic
+    Jacobian (PendulumDx.forward / .linearize, themselves pinned to the oracle by the BoxDDP tests above), incl.
+    saturated torques (derivative 0 outside the clamp)"""
+    B, T = 37, 20
+    dx = PendulumDx()
+    x0 = dev(sample_xinit(B, seed=3))
+    rng = np.random.RandomState(4)
+    u = dev(rng.uniform(-3.0, 3.0, size=(T, B, 1)))     # a third of the torques beyond +-2
+    x, F, f = dx.rollout_linearize(x0, u)
+    xr = get_traj(T, u, x0, dx)
+    Fr, fr = dx.linearize(xr, u)
+    assert_close(npy(x), npy(xr), 2e-5, "x")
+    assert_close(npy(F), npy(Fr), 2e-5, "F")
+    assert_close(npy(f), npy(fr), 5e-5, "f")
+    # the model reproduces the step it was taken around
+    tau = torch.cat((x[:-1], u[:-1]), dim=2)
+    nxt = torch.einsum("tbij,tbj->tbi", F, tau) + f
+    assert_close(npy(nxt), npy(x[1:]), 2e-5, "F tau + f")
