@@ -188,3 +188,18 @@ def test_fused_pendulum_rollout_and_linearisation():
     tau = torch.cat((x[:-1], u[:-1]), dim=2)
     nxt = torch.einsum("tbij,tbj->tbi", F, tau) + f
     assert_close(npy(nxt), npy(x[1:]), 2e-5, "F tau + f")
+
+
+def test_imitation_step_config4_gradients_reach_the_cost_parameters():
+    """BASELINE.json configs[3] (env_dx/il_env.py:104-158, il_exp.py:213-302), small batch: learnable cost
+    q = sigmoid(logit), p = sqrt(q) * learn_p, true pendulum, update_dynamics=False - the imitation loss must send a
+    finite, non-zero gradient through MPCstep.backward (dC, dc) to both parameter vectors"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "imitation_step", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "imitation_step.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.imitation_step(B=64, T=20, max_iter=6, seed=1)
+    assert np.isfinite(r["loss"]) and r["loss"] > 0
+    for g in (r["g_logit"], r["g_p"]):
+        assert np.isfinite(g).all() and np.abs(g).max() > 0
