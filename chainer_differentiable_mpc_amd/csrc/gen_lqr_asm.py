@@ -52,6 +52,7 @@ X_SKIP_BWD = os.environ.get("GEN_SKIP_BWD") == "1"
 X_FWD = set(os.environ.get("GEN_FWD_SKIP", "").split(","))   # forward-sweep parts to drop: store,pst,stage,read,xpart,upart
 X_TIMING = os.environ.get("GEN_TIMING") == "1"
 X_NEWTON = os.environ.get("GEN_NEWTON") == "1"          # one Newton step on each v_rcp_f32 (1 ulp -> ~0.5 ulp)
+X_WARM_STUBS = os.environ.get("GEN_WARM_STUBS") == "1"  # experiment: run every stash stub once during the prologue wait
 X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by a direct s_branch (else s_setpc_b64)
 MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
 X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
@@ -294,14 +295,20 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     assert not masked or L.SLOT_B - PADM >= 256
     NDB_ALL = L.ndma_b + (1 if masked else 0)   # VMEM operations per backward group
 
-    def issue_group(ptrs, slot, slot_bytes):
+    def issue_group(ptrs, slot, slot_bytes, gap=None):
+        """gap: an instruction to emit in the wait state between the M0 write and the first LDS-DMA (else s_nop)"""
         if X_NO_DMA and in_loop[0]:
+            if gap:
+                P.raw(gap)
             return
         if slot == 0:
             P.raw("s_mov_b32 m0, %[ring]")
         else:
             P.raw("s_add_u32 m0, %%[ring], %d" % (slot * slot_bytes))
-        P.nop(1)
+        if gap:
+            P.raw(gap)
+        else:
+            P.nop(1)
         for q, p in enumerate(ptrs):
             off = (" offset:%d" % (q * 1024)) if q else ""
             P.raw("global_load_lds_dwordx4 %s, off%s" % (p, off))
@@ -310,9 +317,22 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
 
     uniq = [0]
 
-    def advance(ptrs, strides):
+    def advance(ptrs, strides, by_steps_left=None):
+        """move the DMA pointers one timestep back unless they already sit on the first timestep.  In the prologue
+        that is counted in tf.  Inside the backward sweep the strides left are a fixed distance from the loop counter
+        S_N (step n of the sweep, n = 0 peeled: tf = T-1-DB-n, S_N = T-2 for n = 0 and T-1-n after), so the sweep
+        tests S_N against by_steps_left (DB for the peeled step, DB+1 in the loop) and tf is not maintained there."""
         uniq[0] += 1
         lab = "Ladv%d_%%=" % uniq[0]
+        if by_steps_left is not None:
+            P.raw("s_cmp_ge_i32 %s, %d" % (S_N, by_steps_left))
+            P.raw("s_cbranch_scc0 " + lab)
+            for p, s in zip(ptrs, strides):
+                P.v("v_lshl_add_u64 %s, %s, 0, %s" % (p, p, s))
+            if masked and ptrs is ptr:
+                P.v("v_lshl_add_u64 %[pm], %[pm], 0, %[dm]")
+            P.label(lab, reset=False)
+            return
         P.raw("s_cmp_gt_i32 %s, 0" % S_TF)
         P.raw("s_cbranch_scc0 " + lab)
         for p, s in zip(ptrs, strides):
@@ -434,9 +454,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     def bstep(s, first, extra_outstanding=0):
         p, n = (s + 2) % 3, (s + 1) % 3
         V = Q[p]
-        P.raw("s_waitcnt lgkmcnt(0)")
-        issue_group(ptr, s, L.SLOT_B)
-        advance(ptr, strd)
+        issue_group(ptr, s, L.SLOT_B, gap="s_waitcnt lgkmcnt(0)")   # the slot's last reads are in before it is refilled
+        advance(ptr, strd, by_steps_left=DB if first else DB + 1)
         if not first and mfma:
             # Q~ += F~^T V^ F^ as (V^^T F^)^T F^ - both products have the A^T B shape that an outer-product MFMA
             # computes from column-per-lane registers (A operand = 4 lanes of a register = 4 rows of A^T):
@@ -571,6 +590,17 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
     P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
     P.raw("s_cbranch_scc1 Lzero_%=")
+    if stash and X_WARM_STUBS and not X_RET_DIRECT:
+        lo = int(S_STUB[2:S_STUB.index(":")])
+        P.raw("s_mov_b64 s[82:83], %s" % S_STUB)
+        P.raw("s_mov_b32 %s, %d" % (S_TMP, L.NSTASH))
+        P.label("Lwarm_%=", reset=False)
+        P.raw("s_swappc_b64 %s, s[82:83]" % S_RET)
+        P.raw("s_add_u32 s82, s82, %d" % BSTUB)
+        P.raw("s_addc_u32 s83, s83, 0")
+        P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
+        P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
+        P.raw("s_cbranch_scc1 Lwarm_%=")
     P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * NDB_ALL + n_extra))
     read_set(0, 0)
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
