@@ -70,11 +70,13 @@ def kernel_name(T, B, nx, nu):
     """the kernel dmpc_lqr_solve dispatches to at this size (what rocprofv3 --kernel-trace lists)"""
     from chainer_differentiable_mpc_amd import _lib
     path = _lib.load().dmpc_lqr_solve_path(T, B, nx, nu)
-    return {0: "dmpc::lqr_generic_kernel", 1: "dmpc::lqr_kernel<%d, %d, ...>" % (nx, nu),
-            2: "dmpc::lqr_dma_kernel<%d, %d, ...>" % (nx, nu),
-            3: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=false>" % (nx, nu),
-            4: "dmpc::lqr_asm_kernel<%d, %d, has_f, write_k, stash=true>" % (nx, nu),
-            5: "dmpc::lqr_wave_mfma_backward<%d, %d> (+ forward-only dmpc::lqr_kernel)" % (nx, nu)}.get(path, "?")
+    # template arguments as rocprofv3 prints them: <nx, nu, has_f, write_k, stash, masked>; the bench passes f, no gains
+    return {0: "dmpc::lqr_generic_kernel", 1: "void dmpc::lqr_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
+            2: "void dmpc::lqr_dma_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
+            3: "void dmpc::lqr_asm_kernel<%d, %d, true, false, false, false>(dmpc::LqrArgs)" % (nx, nu),
+            4: "void dmpc::lqr_asm_kernel<%d, %d, true, false, true, false>(dmpc::LqrArgs)" % (nx, nu),
+            5: "void dmpc::lqr_wave_mfma_backward<%d, %d>(dmpc::LqrArgs) + forward-only dmpc::lqr_kernel" % (nx, nu)
+            }.get(path, "?")
 
 
 def cpu_baseline(p, T, nx, nu, budget_s=12.0):
