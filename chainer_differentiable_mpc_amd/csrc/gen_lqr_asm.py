@@ -671,6 +671,10 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     P.comment("---- forward rollout")
     stamp(2)
     P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    P.v("v_mov_b32_e32 %[xvout], 0")
+    P.raw("v_readfirstlane_b32 %s, %%[bwd_only]" % S_TMP)   # (a VGPR operand: hipcc ran out of SGPRs for an "s" one at (1,1))
+    P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)                    # LqrRecursion.backward(): gains only
+    P.raw("s_cbranch_scc1 Ldone_%=")
     P.raw("s_mov_b64 exec, " + S_XM)                       # x_0 = x_init
     P.raw("global_store_dword %%[px0], %s, off" % XV0)
     P.raw("s_mov_b64 exec, -1")
@@ -879,7 +883,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
         ins.append(("dk", '"v"(in.dk)'))
     if masked:
         ins += [("dm", '"v"(in.dm)'), ("am", '"v"(in.am)')]
-    ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)')]
+    ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)'), ("bwd_only", '"v"(in.bwd_only)')]
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
         ['"s%d"' % i for i in ([70] + list(range(72, 98)))] + ['"vcc"', '"scc"', '"memory"']
 
@@ -946,6 +950,7 @@ struct LqrAsmIn {
   unsigned gz;                       // LDS byte address of this wave's gain rows + lane64 * 16 (zero fill)
   int nz;                            // wave-uniform: 1 KB pieces of the gain rows of one wave
   int tf;                            // wave-uniform: time strides the DMA pointers may still take (set by issue_first)
+  int bwd_only;                      // 1 = stop after the backward sweep (LqrRecursion.backward()); same in every lane
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride

@@ -99,6 +99,17 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #undef DMPC_ASM_LAUNCH_M
       }
     }
+    if (mode == kBackwardOnly && !masked && solve_path<NX, NU, L>(a.T, a.B) >= 3 &&
+        lqr_asm_lds_bytes<NX, NU, false>(a.T) <= kAsmLdsBudget) {
+      // LqrRecursion.backward(): the generated stream's backward sweep with the gains written to HBM (x == nullptr)
+      const int waves = (a.B + 3) / 4;
+      const size_t shmem = lqr_asm_lds_bytes<NX, NU, false>(a.T);
+      if (a.f != nullptr)
+        hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, false>), dim3((waves + 3) / 4), block, shmem, stream, a);
+      else
+        hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, false>), dim3((waves + 3) / 4), block, shmem, stream, a);
+      return (int)hipGetLastError();
+    }
     const int path = (mode == kSolve && !masked) ? solve_path<NX, NU, L>(a.T, a.B) : 0;
     if (path >= 3) {
       const int waves = (a.B + 3) / 4;

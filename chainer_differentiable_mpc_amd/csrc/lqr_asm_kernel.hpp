@@ -42,6 +42,7 @@ constexpr size_t lqr_asm_lds_bytes(int T) {
 
 // MASKED: LQR_active (mpc/active_constrained_lqr.py) - a.mask [T,B,nu] uint8 marks the clamped controls; needs
 // B * nu to be a multiple of 4 (the flags of a wave's four trajectories are fetched as whole dwords).
+// a.x == nullptr: backward sweep only (LqrRecursion.backward(), gains to a.Ks / a.ks - WRITE_K).
 template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED>;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.ring = __builtin_amdgcn_readfirstlane(ring);
   in.T = T;
   in.tf = 0;
+  in.bwd_only = a.x == nullptr ? 1 : 0;
 
   // ---- backward DMA: chunk g = q*64 + lane64 of the slot [C | c | F | f]
   const char *Cb = reinterpret_cast<const char *>(a.C), *cb = reinterpret_cast<const char *>(a.c);
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.pst = row_x ? reinterpret_cast<uint64_t>(a.x + (B + (size_t)b) * NX + lane)
                  : reinterpret_cast<uint64_t>(a.u + (size_t)b * NU + m_own);
   in.dst = row_x ? (uint64_t)(B * NX * 4) : (uint64_t)(B * NU * 4);
-  in.pxi = reinterpret_cast<uint64_t>(a.x_init + (size_t)b * NX + (row_x ? lane : NX - 1));
+  in.pxi = a.x_init != nullptr ? reinterpret_cast<uint64_t>(a.x_init + (size_t)b * NX + (row_x ? lane : NX - 1))
+                               : reinterpret_cast<uint64_t>(a.C);  // backward only: any readable word
   in.px0 = reinterpret_cast<uint64_t>(a.x + (size_t)b * NX + (row_x ? lane : NX - 1));
 
   float xvout, minpiv;
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     int bits = 0;
     if (minpiv == 0.f) bits |= 1;                       // a zero pivot in some Quu (uniform over the row)
     if (lane < NS && !is_finite(xvout)) bits |= 2;      // NaN/Inf propagate to u_{T-1} through the recursion
+    if (a.x == nullptr && !is_finite(minpiv)) bits |= 2;  // backward only: a NaN pivot is all there is to see
     if (bits != 0) atomicOr(&a.info[b], bits);
   }
 }
