@@ -1,6 +1,7 @@
-"""Quick parity check of the fused solve against the numpy oracle over shapes / options (diagnostic, GPU)."""
+"""Quick parity check of the fused solve against the numpy oracle over shapes / options (diagnostic, GPU).
+Lives under tests/ because it uses the oracle (test infrastructure); run as `python tests/tools/asm_check.py`."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from chainer_differentiable_mpc_amd import synthetic, _lib

@@ -1,6 +1,6 @@
 """Timing and sampled oracle parity of the fused solve at B = 65536 (16 rounds of workgroups, 2.7 GB of inputs)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from chainer_differentiable_mpc_amd import synthetic
 from chainer_differentiable_mpc_amd.lqr_recursion import solve_device
