@@ -206,7 +206,7 @@ def main():
                          "kernel": kernel_name(T, B, nx, nu),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3},
         }
-        if not args.no_cpu_baseline and p is not None:
+        if not args.no_cpu_baseline and p is not None and world == 1:   # the CPU leg runs on rank 0 at N = 1 only
             cb, xr, ur = cpu_baseline(p, T, nx, nu, args.cpu_seconds)
             out["cpu_baseline"] = cb
             xe = float(np.max(np.abs(x.cpu().numpy() - xr) / np.maximum(1.0, np.abs(xr))))
