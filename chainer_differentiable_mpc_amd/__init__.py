@@ -20,5 +20,6 @@ from .approximate import approximate_cost, linearize_dynamics  # noqa: F401
 from .box_ddp import BoxDDP  # noqa: F401
 from .mpc_net import MpcNet_cost, MpcNet_dx  # noqa: F401
 from .pendulum import PendulumDx  # noqa: F401
+from .il_env import IL_Env, Pendulum_Net_cost_logit  # noqa: F401
 
 __version__ = "0.1.0"

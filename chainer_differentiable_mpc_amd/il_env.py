@@ -1,0 +1,92 @@
+"""`IL_Env` and `Pendulum_Net_cost_logit` - host-side callers of the hot path for the imitation-learning experiment
+(SURVEY.md 8f rank 3), with the constructors and methods of env_dx/il_env.py:22-213 and env_dx/pendulum_net.py:12-39
+of the reference.  Plain torch over `BoxDDP` / `PendulumDx` / `QuadCost`: data set generation with the true cost,
+`mpc` / `mpc_Q` with a tiled diagonal / full cost, and the learnable cost q = sigmoid(logit), p = sqrt(q) * learn_p.
+The interactive training driver (il_exp.py), its CSV logs and pickles are out of scope."""
+import numpy as np
+import torch
+
+from .box_ddp import BoxDDP
+from .pendulum import PendulumDx
+from .util import QuadCost
+
+
+class IL_Env:
+    """Imitation-learning environment (il_env.py:22).  `device` is where the trajectories are computed."""
+
+    def __init__(self, env, lqr_iter=500, mpc_T=20, device="cuda", dtype=torch.float32, quiet=True):
+        assert env == 'pendulum'                                     # il_env.py:35-38
+        self.env = env
+        self.true_dx = PendulumDx()
+        self.lqr_iter = lqr_iter
+        self.mpc_T = mpc_T
+        self.device, self.dtype, self.quiet = torch.device(device), dtype, quiet
+        self.train_data = self.val_data = self.test_data = None
+
+    @staticmethod
+    def sample_xinit(n_batch=1):
+        """(cos th, sin th, dth), th ~ U(-pi/2, pi/2), dth ~ U(-1, 1): two successive numpy draws (il_env.py:55-69)"""
+        th = np.random.rand(n_batch) * np.pi - 0.5 * np.pi
+        thdot = np.random.rand(n_batch) * 2.0 - 1.0
+        return np.stack((np.cos(th), np.sin(th), thdot), axis=1)
+
+    def populate_data(self, n_train, n_val, n_test, seed=0):
+        """expert trajectories [n, T, n_sc] under the true cost, split into train / val / test (il_env.py:71-102)"""
+        np.random.seed(seed)
+        xinit = self.sample_xinit(n_batch=n_train + n_val + n_test)
+        true_q, true_p = self.true_dx.get_true_obj()
+        with torch.no_grad():
+            x_mpc, u_mpc = self.mpc(self.true_dx, xinit, true_q, true_p, update_dynamics=True)
+        tau = torch.cat((x_mpc, u_mpc), dim=2).transpose(0, 1).contiguous()
+        self.train_data = tau[:n_train]
+        self.val_data = tau[n_train:n_train + n_val]
+        self.test_data = tau[tau.shape[0] - n_test:]
+
+    def _solve(self, dx, xinit, Q, p, u_init, eps_override, lqr_iter_override, update_dynamics):
+        xinit = torch.as_tensor(xinit, dtype=self.dtype, device=self.device)
+        n_batch = xinit.shape[0]
+        Q = Q.to(device=self.device, dtype=self.dtype)
+        p = p.to(device=self.device, dtype=self.dtype)
+        Qt = Q[None, None].expand(self.mpc_T, n_batch, -1, -1).contiguous()          # il_env.py:119-129
+        pt = p[None, None].expand(self.mpc_T, n_batch, -1).contiguous()
+        assert Qt.dim() == 4 and pt.dim() == 3
+        if u_init is not None:
+            u_init = torch.as_tensor(u_init, dtype=self.dtype, device=self.device)
+        solver = BoxDDP(T=self.mpc_T, u_lower=self.true_dx.lower, u_upper=self.true_dx.upper, n_batch=n_batch,
+                        n_state=self.true_dx.n_state, n_ctrl=self.true_dx.n_ctrl, u_init=u_init,
+                        eps=eps_override if eps_override else self.true_dx.mpc_eps,
+                        max_iter=lqr_iter_override if lqr_iter_override else self.lqr_iter, verbose=False,
+                        exit_unconverged=False, detach_unconverged=True,
+                        line_search_decay=self.true_dx.linesearch_decay,
+                        max_line_search_iter=self.true_dx.max_linesearch_iter, update_dynamics=update_dynamics,
+                        quiet=self.quiet)
+        x_mpc, u_mpc, _ = solver((xinit, QuadCost(Qt, pt), dx))
+        return x_mpc, u_mpc
+
+    def mpc(self, dx, xinit, q, p, u_init=None, eps_override=None, lqr_iter_override=None, update_dynamics=False):
+        """box-DDP under the diagonal cost diag(q), p tiled over time and batch -> (x [T,B,3], u [T,B,1])  (:104-158)"""
+        return self._solve(dx, xinit, torch.diag(torch.as_tensor(q)), torch.as_tensor(p), u_init, eps_override,
+                           lqr_iter_override, update_dynamics)
+
+    def mpc_Q(self, dx, xinit, Q, p, u_init=None, eps_override=None, lqr_iter_override=None, update_dynamics=False):
+        """the same with a full cost matrix Q [n_sc, n_sc]  (:160-213)"""
+        return self._solve(dx, xinit, torch.as_tensor(Q), torch.as_tensor(p), u_init, eps_override,
+                           lqr_iter_override, update_dynamics)
+
+
+class Pendulum_Net_cost_logit(torch.nn.Module):
+    """learnable pendulum cost: q = sigmoid(learn_q_logit), p = sqrt(q) * learn_p  (pendulum_net.py:12-39)"""
+
+    def __init__(self, n_sc, device="cuda", dtype=torch.float32):
+        super().__init__()
+        self.n_sc = n_sc
+        self.learn_q_logit = torch.nn.Parameter(torch.zeros(n_sc, device=device, dtype=dtype))
+        self.learn_p = torch.nn.Parameter(torch.zeros(n_sc, device=device, dtype=dtype))
+
+    def forward(self, xinit, env, train_warm_start_idxs=None):
+        q = torch.sigmoid(self.learn_q_logit)
+        p = torch.sqrt(q) * self.learn_p
+        u_init = None
+        if train_warm_start_idxs is not None:     # [B,T,nu] warm-start controls -> time-major (pendulum_net.py:36-37)
+            u_init = torch.as_tensor(train_warm_start_idxs).transpose(0, 1)
+        return env.mpc(env.true_dx, xinit, q, p, u_init=u_init)

@@ -203,3 +203,31 @@ def test_imitation_step_config4_gradients_reach_the_cost_parameters():
     assert np.isfinite(r["loss"]) and r["loss"] > 0
     for g in (r["g_logit"], r["g_p"]):
         assert np.isfinite(g).all() and np.abs(g).max() > 0
+
+
+def test_il_env_and_cost_net_one_rmsprop_step():
+    """IL_Env.populate_data / .mpc (env_dx/il_env.py:71-158) and Pendulum_Net_cost_logit (pendulum_net.py:12-39):
+    expert data under the true cost, one imitation update with the experiment's optimiser (RMSprop, lr 1e-2,
+    alpha 0.5 - il_exp.py:230-240) moves both parameter vectors with finite values"""
+    from chainer_differentiable_mpc_amd import IL_Env, Pendulum_Net_cost_logit
+    env = IL_Env('pendulum', lqr_iter=6, mpc_T=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env.populate_data(n_train=24, n_val=4, n_test=4, seed=0)
+        assert list(env.train_data.shape) == [24, 20, 4] and list(env.test_data.shape) == [4, 20, 4]
+        # the data set starts where sample_xinit said and respects the torque limit
+        np.random.seed(0)
+        x0 = IL_Env.sample_xinit(32)
+        assert_close(npy(env.train_data[:, 0, :3]), x0[:24], 1e-6, "x_init of the data set")
+        assert float(env.train_data[:, :, 3].abs().max()) <= 2.0 + 1e-6
+        net = Pendulum_Net_cost_logit(4)
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-2, alpha=0.5)
+        xinit = env.train_data[:, 0, :3]
+        x_mpc, u_mpc = net(xinit, env)
+        loss = ((torch.cat((x_mpc, u_mpc), dim=2).transpose(0, 1) - env.train_data) ** 2).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    for prm in (net.learn_q_logit, net.learn_p):
+        assert torch.isfinite(prm).all() and torch.isfinite(prm.grad).all()
+    assert float(net.learn_q_logit.grad.abs().max()) > 0
