@@ -50,8 +50,19 @@ def compile_one(src, force):
     return obj
 
 
+def generate(force=False):
+    """lqr_asm_gen.hpp (3.8 MB of generated instruction streams) is not kept in git: gen_lqr_asm.py writes it here"""
+    gen = os.path.join(HERE, "gen_lqr_asm.py")
+    out = os.path.join(HERE, "lqr_asm_gen.hpp")
+    if force or newer(out, [gen]):
+        r = subprocess.run([sys.executable, gen], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gen_lqr_asm.py failed:\n%s\n%s" % (r.stdout, r.stderr))
+
+
 def build(force=False, jobs=None, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
+    generate(force)
     srcs = sorted(glob.glob(os.path.join(HERE, "*.hip")))
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
