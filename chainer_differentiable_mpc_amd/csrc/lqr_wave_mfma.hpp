@@ -94,7 +94,7 @@ __device__ __forceinline__ bool lu_factor_solve_uniform(float (&A)[N][N], float 
 }
 
 template <int NX, int NU>
-__global__ __launch_bounds__(256) void lqr_wave_mfma_backward(const LqrArgs a) {
+__global__ __launch_bounds__(256, 2) void lqr_wave_mfma_backward(const LqrArgs a) {  // 2 waves per SIMD: <= 256 registers
   constexpr int NS = NX + NU, AFF = NS;
   static_assert(NX % 4 == 0 && NS % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
   constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4;  // tiles: x rows, all rows, the tile whose row 0 is `aff`
@@ -123,13 +123,17 @@ __global__ __launch_bounds__(256) void lqr_wave_mfma_backward(const LqrArgs a) {
     const size_t tb = (size_t)t * B + b;
     // ---- [C_t | c_t] rows, column-per-lane
     f4v Q4[TS];
-    {
-      const float *Cp = a.C + tb * NS * NS + lane_c;
-      const float *cp = a.c + tb * NS;
+    {  // one load per row through a per-lane base and stride (lane ns walks c, the others a column of C) - a
+       // `col_aff ? c[i] : C[i][j]` per element makes hipcc emit an exec-masked branch diamond for every load
+      const char *qp = reinterpret_cast<const char *>(col_aff ? a.c + tb * NS : a.C + tb * NS * NS + lane_c);
+      const size_t qs = col_aff ? 4 : NS * 4;  // bytes to the next row (a running pointer: one 64-bit add per load)
 #pragma unroll
       for (int I = 0; I < TS; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Q4[I][r] = col_aff ? cp[4 * I + r] : Cp[(4 * I + r) * NS];
+        for (int r = 0; r < 4; ++r) {
+          Q4[I][r] = *reinterpret_cast<const float *>(qp);
+          qp += qs;
+        }
     }
     // ---- XU[m] = column nx+m of Q~x. as a ROW (lane i = Q[i][nx+m]): the A operand of Qxu K~ in the value update
     constexpr bool kXU = NU % 4 == 0;
@@ -144,12 +148,18 @@ __global__ __launch_bounds__(256) void lqr_wave_mfma_backward(const LqrArgs a) {
     if (t < T - 1) {
       float Fc[NX];
       {
-        const float *Fp = a.F + tb * NX * NS + lane_c;
-        const float *fp = has_f ? a.f + tb * NX : a.c + tb * NS;  // any valid address when f is absent
+        const bool f_lane = col_aff && has_f;
+        // lane ns without f: any column, zeroed below
+        const char *fp = reinterpret_cast<const char *>(f_lane ? a.f + tb * NX : a.F + tb * NX * NS + lane_c);
+        const size_t fs = f_lane ? 4 : NS * 4;
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-          const float fv = has_f ? fp[k] : 0.f;
-          Fc[k] = col_aff ? fv : Fp[k * NS];
+          Fc[k] = *reinterpret_cast<const float *>(fp);
+          fp += fs;
+        }
+        if (!has_f) {
+#pragma unroll
+          for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? 0.f : Fc[k];
         }
       }
       // ---- G = [V|v]^T F~ : tiles 0..TX-1 (x columns of V) and TA (row 0 = v^T F~)
