@@ -66,8 +66,11 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   auto load = [&](int t, Slot &s) {
     t = t < 0 ? 0 : t;  // the prefetch past t = 0 re-reads step 0 (never consumed)
     const size_t tb = (size_t)t * B + b;
-    s.tau = lane_t < NX ? a.x[tb * NX + lane_t] : a.u[tb * NU + (lane_t - NX)];
-    s.dtau = lane_t < NX ? a.dx[tb * NX + lane_t] : a.du[tb * NU + (lane_t - NX)];
+    // (pointer selects, then ONE load each: `cond ? x[i] : u[j]` makes hipcc emit an exec-masked branch per load)
+    const float *tp = lane_t < NX ? a.x + tb * NX + lane_t : a.u + tb * NU + (lane_t - NX);
+    const float *dp = lane_t < NX ? a.dx + tb * NX + lane_t : a.du + tb * NU + (lane_t - NX);
+    s.tau = *tp;
+    s.dtau = *dp;
     load_contig<NS>(a.C + (tb * NS + lane_x) * NS, s.Crow);
     s.ci = a.c[tb * NS + lane_x];
     s.ri = a.r[tb * NS + lane_x];
