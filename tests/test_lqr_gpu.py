@@ -245,3 +245,17 @@ def test_batched_lu_large_n_generic_path():
     np.testing.assert_array_equal(piv.cpu().numpy(), pivr)
     x = batch_lu_solve((LU, piv), torch.as_tensor(b, dtype=torch.float32).cuda())
     assert_close(npy(x), xr, 1e-3, "x")
+
+
+@pytest.mark.parametrize("shape", [(5, 1, 8, 2), (1, 1, 3, 1), (2, 1, 32, 8)])
+def test_single_timestep_horizon(shape):
+    """T = 1: no dynamics at all (F has zero slices), x_0 = x_init, u_0 = K_0 x_0 + k_0 from the last-step cost"""
+    B, T, nx, nu = shape
+    p = synthetic.make_lqr_problem(B, 2, nx, nu, seed=6)
+    C, c = p["C"][:1], p["c"][:1]
+    xr, ur = olqr.lqr_solve(p["x_init"], C, c, p["F"][:0], None, 1, nx, nu)
+    d = to_dev(dict(C=C, c=c, x_init=p["x_init"]))
+    F0 = torch.empty((0, B, nx, nx + nu), dtype=torch.float32, device="cuda")
+    x, u = LqrRecursion(d["x_init"], d["C"], d["c"], F0, None, 1, nx, nu).solve_recursion()
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
