@@ -14,7 +14,9 @@
 #pragma once
 #include "colwise.hpp"
 #include "costate_args.hpp"
+#include "dpp_blocks_gen.hpp"
 #include "lqr_kernels.hpp"
+#include "riccati_blocks.hpp"
 
 namespace dmpc {
 
@@ -39,6 +41,7 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   static_assert(NS <= L, "tau must fit the lane group");
   constexpr int GPB = 256 / L;
   using G = Group<L>;
+  using Blk = RiccatiBlocks<NX, NU, L>;  // fused DPP broadcast-FMA blocks for the 16-lane shapes (dpp_blocks_gen.hpp)
 
   const int lane = threadIdx.x % L;
   const int grp = threadIdx.x / L;
@@ -85,37 +88,24 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
     // ---- dF_t and df (they use lambda_{t+1}, d_lambda_{t+1})             differentiable_lqr.py:130-133
     if (t < T - 1) {
       if (a.dF != nullptr) {
-        float row[NS];
-        static_for<0, NS>([&](auto j) {
-          row[j.value] = a.out_sign * fmaf(dlam, G::template bcast<j.value>(tau), lam * G::template bcast<j.value>(dtau));
-        });
+        float row[NS];  // out_sign * (dlam (x) tau + lam (x) dtau), row `lane`
+        Blk::outer2(row, tau, dtau, a.out_sign * dlam, a.out_sign * lam);
         if (live && is_x) store_contig<NS>(a.dF + (tb * NX + lane) * NS, row);
       }
       if (a.df != nullptr && a.df_shift == 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
     }
     // ---- dC_t, dc_t                                                          :128-129
     if (a.dC != nullptr) {
-      float row[NS];
-      static_for<0, NS>([&](auto j) {
-        row[j.value] = a.out_sign * fmaf(wa * dtau, G::template bcast<j.value>(tau),
-                                         (wb * tau) * G::template bcast<j.value>(dtau));
-      });
+      float row[NS];  // out_sign * (wa dtau (x) tau + wb tau (x) dtau), row `lane`
+      Blk::outer2(row, tau, dtau, a.out_sign * wa * dtau, a.out_sign * wb * tau);
       if (live && is_tau) store_contig<NS>(a.dC + (tb * NS + lane) * NS, row);
     }
     if (a.dc != nullptr && live && is_tau) a.dc[tb * NS + lane] = a.out_sign * dtau;
 
     // ---- lambda_t, d_lambda_t                                                 :92,102 / :115,124
     float nl = s.ci, ndl = a.r_sign * s.ri;
-    static_for<0, NS>([&](auto j) {
-      nl = fmaf(s.Crow[j.value], G::template bcast<j.value>(tau), nl);
-      ndl = fmaf(s.Crow[j.value], G::template bcast<j.value>(dtau), ndl);
-    });
-    if (t < T - 1) {
-      static_for<0, NX>([&](auto k) {
-        nl = fmaf(s.Fcol[k.value], G::template bcast<k.value>(lam), nl);
-        ndl = fmaf(s.Fcol[k.value], G::template bcast<k.value>(dlam), ndl);
-      });
-    }
+    Blk::dots2_ns(nl, ndl, s.Crow, tau, dtau);
+    if (t < T - 1) Blk::dots2_nx(nl, ndl, s.Fcol, lam, dlam);
     lam = nl;
     dlam = ndl;
     if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;

@@ -107,6 +107,36 @@ def gen_rowdot(n, name, lane0):
     return out
 
 
+def mul_dpp(dst, a, b, lane):
+    return '"v_mul_f32_dpp %%[%s], %%[%s], %%[%s] row_newbcast:%d row_mask:0xf bank_mask:0xf\\n\\t"' % (
+        dst, a, b, lane)
+
+
+def gen_outer2(n):
+    """row[j] = bcast<j>(x) * a + bcast<j>(y) * b   (j < n): the rows of dC / dF in the co-state kernel"""
+    out = ""
+    for js in chunks(list(range(n)), MAX_OPERANDS - 4):
+        lines = [mul_dpp("r%d" % j, "x", "a", j) for j in js] + [fmac("r%d" % j, "y", "b", j) for j in js]
+        outs = [("r%d" % j, "row[%d]" % j) for j in js]
+        ins = [("x", "x"), ("y", "y"), ("a", "a"), ("b", "b")]
+        body = statement(lines, outs, ins, tail_nop=False)
+        out += body.replace('"+&v"', '"=&v"')
+    return out
+
+
+def gen_dots2(n):
+    """p += sum_j bcast<j>(x) * M[j] ; q += sum_j bcast<j>(y) * M[j]   (two interleaved accumulator chains)"""
+    out = ""
+    for js in chunks(list(range(n)), MAX_OPERANDS - 4):
+        lines = []
+        for j in js:
+            lines += [fmac("p", "x", "m%d" % j, j), fmac("q", "y", "m%d" % j, j)]
+        outs = [("p", "p"), ("q", "q")]
+        ins = [("x", "x"), ("y", "y")] + [("m%d" % j, "M[%d]" % j) for j in js]
+        out += statement(lines, outs, ins, tail_nop=False)
+    return out
+
+
 def main():
     s = ["// GENERATED by gen_dpp_blocks.py - do not edit; regenerate and commit.",
          "// Fused broadcast-FMA (v_fmac_f32_dpp row_newbcast) blocks for the 16-lane row kernels.",
@@ -129,6 +159,14 @@ def main():
         body = gen_rowdot(nu, "dot_u", nx).replace("M[", "M[%d + " % nx)
         s.append("  static __device__ __forceinline__ void dot_u(float &acc, const float xu, const float (&M)[%d]) "
                  "{\n%s  }" % (ns + 1, body))
+        s.append("  // row[j] = bcast<j>(x) * a + bcast<j>(y) * b, j < ns")
+        s.append("  static __device__ __forceinline__ void outer2(float (&row)[%d], const float x, const float y, "
+                 "const float a, const float b) {\n%s  }" % (ns, gen_outer2(ns)))
+        s.append("  // p += sum_j bcast<j>(x) M[j], q += sum_j bcast<j>(y) M[j]")
+        s.append("  static __device__ __forceinline__ void dots2_ns(float &p, float &q, const float (&M)[%d], const float x, "
+                 "const float y) {\n%s  }" % (ns, gen_dots2(ns)))
+        s.append("  static __device__ __forceinline__ void dots2_nx(float &p, float &q, const float (&M)[%d], const float x, "
+                 "const float y) {\n%s  }" % (nx, gen_dots2(nx)))
         s.append("};\n")
     s.append("}  // namespace dmpc")
     open(OUT, "w").write("\n".join(s) + "\n")
