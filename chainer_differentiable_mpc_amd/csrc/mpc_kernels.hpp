@@ -62,32 +62,51 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   int n_total = 0;
   int info_bits = 0;
 
-  for (int t = T - 1; t >= 0; --t) {
+  // Inputs of one timestep, column-per-lane.  One wavefront per SIMD: nothing else hides HBM latency, so the loads
+  // of step t-2 are issued before step t is computed (three banks rotated statically - hipcc drains vmcnt at a loop
+  // header, so the prefetch sits in the same iteration as the compute it overlaps).
+  struct Slot {
+    float Q[NS], Fc[NX];      // [C_t | c_t] rows, [F_t | f_t] rows
+    float uc[NU], lb[NU], ub[NU];
+  };
+  auto load = [&](int t, Slot &sl) {
+    t = t < 0 ? 0 : t;  // prefetch past t = 0: step 0 again (never consumed)
+    const size_t tb = (size_t)t * B + b;
+    // per-lane base and stride: lane ns walks c / f, the others a column of C / F (one load per element, no branches)
+    const char *qp = reinterpret_cast<const char *>(col_aff ? a.c + tb * NS : a.C + tb * NS * NS + lane_c);
+    const size_t qs = col_aff ? 4 : NS * 4;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      sl.Q[i] = *reinterpret_cast<const float *>(qp);
+      qp += qs;
+    }
+    const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);  // there is no F_{T-1}
+    const size_t tbF = (size_t)tF * B + b;
+    const bool f_lane = col_aff && has_f;
+    const char *fp = reinterpret_cast<const char *>(f_lane ? a.f + tbF * NX : (T > 1 ? a.F : a.C) + tbF * NX * NS + lane_c);
+    const size_t fs = f_lane ? 4 : NS * 4;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+      sl.Fc[k] = *reinterpret_cast<const float *>(fp);
+      fp += fs;
+    }
+#pragma unroll
+    for (int m = 0; m < NU; ++m) {
+      sl.uc[m] = a.controls[tb * NU + m];
+      sl.lb[m] = a.lower[tb * NU + m];
+      sl.ub[m] = a.upper[tb * NU + m];
+    }
+  };
+
+  auto step = [&](int t, const Slot &sl) {
     const size_t tb = (size_t)t * B + b;
     float Q[NS];
-    {
-      const float *Cp = a.C + tb * NS * NS + lane_c;
-      float cn[NS];
 #pragma unroll
-      for (int i = 0; i < NS; ++i) Q[i] = Cp[i * NS];
-      load_contig<NS>(a.c + tb * NS, cn);
-#pragma unroll
-      for (int i = 0; i < NS; ++i) Q[i] = col_aff ? cn[i] : Q[i];
-    }
+    for (int i = 0; i < NS; ++i) Q[i] = sl.Q[i];
     if (t < T - 1) {
       float Fc[NX];
-      const float *Fp = a.F + tb * NX * NS + lane_c;
 #pragma unroll
-      for (int k = 0; k < NX; ++k) Fc[k] = Fp[k * NS];
-      if (has_f) {
-        float fn[NX];
-        load_contig<NX>(a.f + tb * NX, fn);
-#pragma unroll
-        for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? fn[k] : Fc[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? 0.f : Fc[k];
-      }
+      for (int k = 0; k < NX; ++k) Fc[k] = (col_aff && !has_f) ? 0.f : sl.Fc[k];
       float W[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) W[i] = col_aff ? V[i] : 0.f;
@@ -103,9 +122,8 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
 #pragma unroll
     for (int m = 0; m < NU; ++m) {
       qu[m] = G::template bcast<NS>(Q[NX + m]);
-      const float uc = a.controls[tb * NU + m];
-      lo[m] = a.lower[tb * NU + m] - uc;  // :136-138
-      hi[m] = a.upper[tb * NU + m] - uc;
+      lo[m] = sl.lb[m] - sl.uc[m];  // :136-138
+      hi[m] = sl.ub[m] - sl.uc[m];
     }
     // k_t: box QP, warm-started from the later timestep                        :141-146
     PnqpResult<NU> qp;
@@ -148,6 +166,22 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
 #pragma unroll
       for (int i = 0; i < NX; ++i) V[i] = Q[i];
       Blk::vupd(V, Q, Kt, R);
+    }
+  };
+
+  Slot sa, sb, sc;
+  load(T - 1, sa);
+  load(T - 2, sb);
+  for (int t = T - 1; t >= 0; t -= 3) {
+    load(t - 2, sc);
+    step(t, sa);
+    if (t - 1 >= 0) {
+      load(t - 3, sa);
+      step(t - 1, sb);
+    }
+    if (t - 2 >= 0) {
+      load(t - 4, sb);
+      step(t - 2, sc);
     }
   }
   if (live && lane == 0) {
