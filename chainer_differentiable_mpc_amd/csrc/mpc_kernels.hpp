@@ -250,6 +250,40 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
     old_cost += step_cost(tb, tau);
   }
 
+  // Inputs of one timestep of a pass; the loads of step t+2 are issued before step t is computed (see the backward
+  // kernel above).  A pass that is no longer needed by this trajectory still runs masked while wave-mates search.
+  struct Slot {
+    float xt, kv[NU], uc[NU], lb[NU], ub[NU];
+    float Crow[NS], ci, Frow[NS], fi;
+  };
+  const bool lin = a.dyn_kind == 0;
+  auto load = [&](int t, Slot &sl) {
+    t = t < T ? t : T - 1;  // prefetch past the horizon: the last step again (never consumed)
+    const size_t tb = (size_t)t * B + b;
+    sl.xt = a.states[tb * NX + lane_x];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) {
+      const float *kp = col_aff ? (a.ks + tb * NU + m) : (a.Ks + (tb * NU + m) * NX + lane_x);
+      sl.kv[m] = *kp;
+      sl.uc[m] = a.controls[tb * NU + m];
+      sl.lb[m] = a.lower[tb * NU + m];
+      sl.ub[m] = a.upper[tb * NU + m];
+    }
+    load_contig<NS>(a.C + (tb * NS + lane_t) * NS, sl.Crow);
+    sl.ci = a.c[tb * NS + lane_t];
+    if (lin) {
+      const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);  // there is no F_{T-1}
+      const size_t tbF = (size_t)tF * B + b;
+      load_contig<NS>(a.F + (tbF * NX + lane_x) * NS, sl.Frow);
+      sl.fi = has_f ? a.f[tbF * NX + lane_x] : 0.f;
+    }
+  };
+  auto slot_cost = [&](const Slot &sl, float tau) {  // 1/2 tau'C tau + c'tau of one timestep          util.py:162-198
+    float qi = 0.f;
+    static_for<0, NS>([&](auto j) { qi = fmaf(sl.Crow[j.value], G::template bcast<j.value>(tau), qi); });
+    return group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f);
+  };
+
   float alpha = 1.0f;
   float cost = 0.f;
   int n_pass = 0;
@@ -257,18 +291,15 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   while (worse && n_pass < a.ls_cap) {  // :196 - until this trajectory is not worse than before
     float xh = is_x ? a.states[(size_t)b * NX + lane] : 0.f;  // new_x[0] = states[0]     :198
     cost = 0.f;
-    for (int t = 0; t < T; ++t) {
+    auto step = [&](int t, const Slot &sl) {
       const size_t tb = (size_t)t * B + b;
-      const float xt = is_x ? a.states[tb * NX + lane] : 0.f;
+      const float xt = is_x ? sl.xt : 0.f;
       const float z = is_x ? (xh - xt) : (col_aff ? alpha : 0.f);  // [dx ; alpha] against [K_t | k_t]
       float un[NU];
 #pragma unroll
       for (int m = 0; m < NU; ++m) {
-        const float *kp = col_aff ? (a.ks + tb * NU + m) : (a.Ks + (tb * NU + m) * NX + lane_x);
-        const float kv = *kp;
-        const float uc = a.controls[tb * NU + m];
-        float v = group_sum<L>(k_lane ? kv * z : 0.f) + uc;                           // :209-219
-        const float lb = a.lower[tb * NU + m], ub = a.upper[tb * NU + m];
+        float v = group_sum<L>(k_lane ? sl.kv[m] * z : 0.f) + sl.uc[m];               // :209-219
+        const float lb = sl.lb[m], ub = sl.ub[m];
         v = fminf(fmaxf(v, lb), ub);                                                  // :221
         v = (v - lb <= bound_tol(lb)) ? lb : v;
         un[m] = (ub - v <= bound_tol(ub)) ? ub : v;
@@ -276,7 +307,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       float tau = xh;  // [new_x_t ; new_u_t], element per lane
 #pragma unroll
       for (int m = 0; m < NU; ++m) tau = (lane == NX + m) ? un[m] : tau;
-      const float obj = step_cost(tb, tau);                                          // :246-251
+      const float obj = slot_cost(sl, tau);                                          // :246-251
       cost += obj;
       if (live) {  // outputs are overwritten by later passes; the last one is the accepted one
         if (is_x) a.x[tb * NX + lane] = xh;
@@ -284,7 +315,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
         if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
         if (a.u_first != nullptr && n_pass == 0 && lane >= NX && lane < NS) a.u_first[tb * NU + (lane - NX)] = tau;
       }
-      if (t < T - 1 && a.dyn_kind == 1) {  // built-in pendulum (cos th, sin th, dth), torque -> next   pendulum.py:84-98
+      if (t < T - 1 && !lin) {  // built-in pendulum (cos th, sin th, dth), torque -> next   pendulum.py:84-98
         if constexpr (NX == 3 && NU == 1) {
           const float cs = G::template bcast<0>(tau), sn = G::template bcast<1>(tau), dth = G::template bcast<2>(tau);
           float uu = G::template bcast<3>(tau);
@@ -295,11 +326,24 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
           xh = lane == 0 ? cosf(newth) : (lane == 1 ? sinf(newth) : (lane == 2 ? newdth : 0.f));
         }
       } else if (t < T - 1) {  // new_x_{t+1} = F_t [new_x;new_u] + f_t under the TRUE dynamics   :229-236
-        float Frow[NS];
-        load_contig<NS>(a.F + (tb * NX + lane_x) * NS, Frow);
-        float acc = has_f ? a.f[tb * NX + lane_x] : 0.f;
-        static_for<0, NS>([&](auto j) { acc = fmaf(Frow[j.value], G::template bcast<j.value>(tau), acc); });
+        float acc = sl.fi;
+        static_for<0, NS>([&](auto j) { acc = fmaf(sl.Frow[j.value], G::template bcast<j.value>(tau), acc); });
         xh = is_x ? acc : 0.f;
+      }
+    };
+    Slot sa, sb, sc;
+    load(0, sa);
+    load(1, sb);
+    for (int t = 0; t < T; t += 3) {
+      load(t + 2, sc);
+      step(t, sa);
+      if (t + 1 < T) {
+        load(t + 3, sa);
+        step(t + 1, sb);
+      }
+      if (t + 2 < T) {
+        load(t + 4, sb);
+        step(t + 2, sc);
       }
     }
     ++n_pass;
