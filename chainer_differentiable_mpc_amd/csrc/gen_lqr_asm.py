@@ -54,6 +54,7 @@ X_TIMING = os.environ.get("GEN_TIMING") == "1"
 X_NEWTON = os.environ.get("GEN_NEWTON") == "1"          # one Newton step on each v_rcp_f32 (1 ulp -> ~0.5 ulp)
 X_WARM_STUBS = os.environ.get("GEN_WARM_STUBS") == "1"  # experiment: run every stash stub once during the prologue wait
 X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by a direct s_branch (else s_setpc_b64)
+MFMA_USE = int(os.environ.get("GEN_MFMA_USE", "5"))     # wait states kept before a non-accumulating use of an MFMA result
 MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
 X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
 USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
@@ -145,13 +146,13 @@ class Prog:
 
     def mfma(self, dst, a, b, c, abid):
         """v_mfma_f32_4x4x1_16b_f32 dst[4], a, b, c[4] | 0, A broadcast from block `abid` of each 16-lane row.
-        Wait states kept (the ISA's own numbers for this 2-pass, non-XDL op are smaller: passes + 2 for a VALU
-        read of the result, passes for a dependent SrcC): 8 before anything but an accumulating MFMA reads an MFMA
-        result, 2 before a dependent accumulation, 2 after a VALU write of any source."""
+        Wait states kept: MFMA_USE (5; the ISA asks passes + 2 = 4 for this 2-pass, non-XDL op) before anything
+        but an accumulating MFMA reads an MFMA result, MFMA_DEP (2 = passes) before a dependent accumulation, 2 after
+        a VALU write of any source.  GEN_MFMA_USE=4 / 8 give bit-identical results (scripts/asm_variant_check.sh)."""
         for r in (a, b):
             self._need(self.age, r, 2)
             self._need(self.trans, r, 2)
-            self._need(self.mf, r, 8)
+            self._need(self.mf, r, MFMA_USE)
         if c:
             for r in c:
                 self._need(self.age, r, 2)
@@ -163,11 +164,11 @@ class Prog:
     def uses(self, regs):
         """a non-VALU instruction (LDS / memory) is about to read or overwrite these VGPRs"""
         for r in regs:
-            self._need(self.mf, r, 8)
+            self._need(self.mf, r, MFMA_USE)
 
     def valu(self, text, writes=(), reads=(), dpp=None, trans=False):
         for r in tuple(reads) + tuple(writes) + ((dpp,) if dpp else ()):
-            self._need(self.mf, r, 8)
+            self._need(self.mf, r, MFMA_USE)
         if dpp is not None:
             self._need(self.age, dpp, 2)
         for r in tuple(reads) + ((dpp,) if dpp else ()):
