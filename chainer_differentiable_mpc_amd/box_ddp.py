@@ -9,12 +9,14 @@ Per-sample "best so far" bookkeeping is a masked `torch.where` instead of the re
 the batch (:200-209); stop tests, the final no-op MPCstep node that carries the gradient (:247-259) and the
 detach mask for unconverged samples (:263-289) follow the reference.
 """
+import ctypes
 import warnings
 
 import torch
 
+from . import _lib
 from .approximate import approximate_cost, linearize_dynamics
-from .lqr_recursion import _as_tensor
+from .lqr_recursion import _as_tensor, _device_of, _workspace, raise_info
 from .mpc_step import MPCstep
 from .util import LinDx, QuadCost, get_cost, get_traj
 
@@ -34,7 +36,7 @@ class BoxDDP(torch.nn.Module):
     def __init__(self, T, u_lower, u_upper, n_batch, n_state, n_ctrl, u_init, eps=1e-5, not_improved_lim=5,
                  line_search_decay=0.2, max_line_search_iter=10, best_cost_eps=1e-4, max_iter=10,
                  detach_unconverged=True, exit_unconverged=True, verbose=False, ilqr_verbose=False,
-                 update_dynamics=True, quiet=False):
+                 update_dynamics=True, quiet=False, device_loop=True):
         super().__init__()
         self.T, self.n_batch, self.n_state, self.n_ctrl = T, n_batch, n_state, n_ctrl
         self.n_sc = n_state + n_ctrl
@@ -51,7 +53,11 @@ class BoxDDP(torch.nn.Module):
         self.exit_unconverged = exit_unconverged
         self.update_dynamics = update_dynamics
         self.quiet = quiet          # suppress the reference's "Converged" / "Not improved lim" prints
+        # QuadCost with a LinDx or the built-in pendulum: the whole loop is one chain of launches with the
+        # stop tests on the device (`dmpc_box_ddp`); False keeps the host loop over MPCstep objects
+        self.device_loop = device_loop
         self.status = None
+        self.info = None            # MPC step flags of the device loop, per trajectory
         self.n_iter = 0
         if isinstance(u_lower, (int, float)):       # scalar bounds are broadcast to [T,B,nu] (:68-90)
             u_lower = torch.full((T, n_batch, n_ctrl), float(u_lower))
@@ -65,6 +71,66 @@ class BoxDDP(torch.nn.Module):
         self.status = msg.strip()
         if not self.quiet:
             print(msg)
+
+    _STATUS = {1: "Converged", 2: "Not improved lim", 3: "Not Converged "}
+
+    def _device_loop(self, x_init, cost, dynamics, u, lo, hi):
+        """box_ddp.py:123-230 behind one C call; returns (best, last full_du_norm) or None when the problem is not
+        of the supported kind (then the host loop runs)."""
+        T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
+        ns = nx + nu
+        if isinstance(dynamics, LinDx):
+            kind, params, Fd, fd = 0, None, dynamics.F, dynamics.f
+        elif hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x_init, u) and (nx, nu) == (3, 1):
+            g_, m_, l_ = (float(v) for v in dynamics.params.detach().cpu().tolist())
+            params = (ctypes.c_float * 5)(g_, m_, l_, float(dynamics.dt), float(dynamics.max_torque))
+            kind, Fd, fd = 1, None, None
+        else:
+            return None
+        lib = _lib.load()
+        _lib.require_gpu()
+        d = _device_of(x_init, cost.C, u)
+        x0 = _lib.f32c(x_init.detach(), d)
+        C, c = _lib.f32c(_as_tensor(cost.C).detach(), d), _lib.f32c(_as_tensor(cost.c).detach(), d)
+        F = None if Fd is None else _lib.f32c(_as_tensor(Fd).detach(), d)
+        f = None if fd is None else _lib.f32c(_as_tensor(fd).detach(), d)
+        if list(C.shape) != [T, B, ns, ns] or list(c.shape) != [T, B, ns]:
+            return None
+        if F is not None and (F.shape[0] not in (T - 1, T) or list(F.shape[1:]) != [B, nx, ns]):
+            return None
+        if f is not None and list(f.shape) != [T - 1, B, nx]:
+            return None
+        u0, lo_, hi_ = _lib.f32c(u, d), _lib.f32c(lo, d), _lib.f32c(hi, d)
+        assert not bool(torch.isnan(u0).any())
+        assert bool((lo_ <= hi_).all()), " lower is larger than upper"
+        f32 = dict(dtype=torch.float32, device=d)
+        bx, bu = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32)
+        bc, bn, ln = torch.empty((B,), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
+        state = torch.empty((8,), dtype=torch.int32, device=d)
+        info = torch.zeros((B,), dtype=torch.int32, device=d)
+        need = lib.dmpc_box_ddp_workspace_bytes(T, B, nx, nu)
+        ws = _workspace(need, d)
+        with torch.cuda.device(d):
+            rc = lib.dmpc_box_ddp(T, B, nx, nu, _lib.ptr(x0), _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), kind,
+                                  None if params is None else ctypes.cast(params, ctypes.c_void_p), _lib.ptr(u0),
+                                  _lib.ptr(lo_), _lib.ptr(hi_), float(self.eps), int(self.not_improved_lim),
+                                  float(self.ls_decay), int(self.max_ls_iter), float(self.best_cost_eps),
+                                  int(self.max_iter), 20, 1, _lib.ptr(bx), _lib.ptr(bu), _lib.ptr(bc), _lib.ptr(bn),
+                                  _lib.ptr(ln), _lib.ptr(state), _lib.ptr(ws), need, _lib.ptr(info),
+                                  _lib.stream_ptr(d))
+        if rc == _lib.E_UNSUPPORTED:
+            return None
+        _lib.check(rc, "dmpc_box_ddp")
+        st = state.cpu().tolist()                 # the one synchronisation of the loop
+        raise_info(info, "BoxDDP")                # the reference asserts on NaN inside every MPC step
+        self.info = info
+        self.n_iter = st[1]
+        if st[2] in self._STATUS:
+            self._say(self._STATUS[st[2]])
+        dev, dt = x_init.device, x_init.dtype
+        best = {'x': bx.to(device=dev, dtype=dt), 'u': bu.to(device=dev, dtype=dt),
+                'costs': bc.to(device=dev, dtype=dt), 'full_du_norm': bn.to(device=dev, dtype=dt)}
+        return best, ln.to(device=dev, dtype=dt)
 
     def forward(self, inputs):
         x_init, cost, dynamics = inputs
@@ -110,7 +176,12 @@ class BoxDDP(torch.nn.Module):
         best = None
         n_not_improved = 0
         for_out = None
-        for i in range(self.max_iter):
+        last_norm = None
+        if self.device_loop and not self.verbose and not self.ilqr_verbose and isinstance(cost, QuadCost):
+            looped = self._device_loop(x_init, cost, dynamics, u, lo, hi)
+            if looped is not None:
+                best, last_norm = looped
+        for i in range(self.max_iter if best is None else 0):
             with torch.no_grad():
                 if hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x_init, u) and isinstance(cost, QuadCost):
                     # pendulum: rollout and linearisation in one launch (get_traj + linearize_dynamics, :123-136)
@@ -175,7 +246,9 @@ class BoxDDP(torch.nn.Module):
                 print("LQR Warning: All examples did not converge to a fixed point.")
                 print("Detaching and *not* backpropping through the bad examples.")
             warnings.warn("LQR Warning: All examples did not converge to a fixed point.")
-            keep = (for_out.full_du_norm < self.eps).to(x.dtype)[None, :, None]
+            if last_norm is None:
+                last_norm = for_out.full_du_norm
+            keep = (last_norm < self.eps).to(x.dtype)[None, :, None]
             x = x * keep + x.detach() * (1. - keep)
             u = u * keep + u.detach() * (1. - keep)
         return x, u, costs

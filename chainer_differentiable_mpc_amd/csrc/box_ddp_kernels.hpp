@@ -1,0 +1,133 @@
+// box_ddp_kernels.hpp - the bookkeeping of the outer box-DDP loop (BoxDDP.forward, mpc/box_ddp.py:93-291) on the
+// device, so that a whole solve (max_iter MPC steps) is one chain of launches without a host round trip:
+//
+//   lin_rollout_kernel       get_traj under a LinDx (util.py:239-277): x_{t+1} = F_t [x_t; u_t] + f_t
+//   box_ddp_select_kernel    one workgroup: full_du_norm of the step (mpc_step.py:260-263, with the reference's
+//                            reshape of a [T,nu,B] array to [B, T*nu] unless strict), per-sample "best so far" test
+//                            (box_ddp.py:200-209), the stop tests (:223-230) and the loop state
+//   box_ddp_keep_kernel      best x / u <- the step's x / u where the sample improved
+//
+// The loop state lives in `state[8]` (int32): [0] done, [1] n_iter, [2] status (1 Converged, 2 Not improved lim,
+// 3 Not Converged), [3] n_not_improved.  Once `done` is set every later launch of the chain returns at once (the
+// MPC kernels test the same flag), so the host may enqueue max_iter iterations blindly and synchronise once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dmpc {
+
+enum { kDdpDone = 0, kDdpIter = 1, kDdpStatus = 2, kDdpNotImproved = 3 };
+
+__global__ __launch_bounds__(64) void lin_rollout_kernel(int T, int B, int nx, int nu, const float *__restrict__ x_init,
+                                                         const float *__restrict__ u, const float *__restrict__ F,
+                                                         const float *__restrict__ f, float *__restrict__ x,
+                                                         const int32_t *__restrict__ done) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (done != nullptr && *done != 0) return;
+  const int ns = nx + nu;
+  const size_t Bs = (size_t)B;
+  for (int i = 0; i < nx; ++i) x[(size_t)b * nx + i] = x_init[(size_t)b * nx + i];
+  for (int t = 0; t + 1 < T; ++t) {
+    const size_t tb = (size_t)t * Bs + b;
+    const float *xt = x + tb * nx, *ut = u + tb * nu, *Ft = F + tb * nx * ns;
+    float *xn = x + (tb + Bs) * nx;
+    for (int i = 0; i < nx; ++i) {
+      float acc = f != nullptr ? f[tb * nx + i] : 0.f;
+      for (int j = 0; j < nx; ++j) acc = fmaf(Ft[i * ns + j], xt[j], acc);
+      for (int j = 0; j < nu; ++j) acc = fmaf(Ft[i * ns + nx + j], ut[j], acc);
+      xn[i] = acc;
+    }
+  }
+}
+
+struct DdpSelectArgs {
+  int it, T, B, nu;
+  int max_iter, not_improved_lim, scrambled;
+  float eps, best_cost_eps;
+  const float *u_old, *u_first;  // controls the step started from / of its first (alpha = 1) pass   [T,B,nu]
+  const float *costs;            // [B] cost of the step's result
+  float *best_costs, *best_norm, *last_norm;  // [B]
+  int32_t *keep;                 // [B] 1 where the step's x / u replace the best ones
+  int32_t *state;
+};
+
+__global__ __launch_bounds__(256) void box_ddp_select_kernel(const DdpSelectArgs a) {
+  __shared__ float s_max[256];
+  __shared__ int s_any[256];
+  const int tid = threadIdx.x;
+  if (a.state[kDdpDone] != 0) {  // stopped in an earlier iteration: nothing moves any more
+    for (int b = tid; b < a.B; b += 256) a.keep[b] = 0;
+    return;
+  }
+  const int row = a.T * a.nu;
+  float vmax = -1.f;
+  bool nan_seen = false;
+  int any = 0;
+  for (int b = tid; b < a.B; b += 256) {
+    float acc = 0.f;
+    for (int e = 0; e < row; ++e) {
+      size_t idx;
+      if (a.scrambled) {  // [T,nu,B] read as [B, T*nu]                                   mpc_step.py:261-263
+        const size_t flat = (size_t)b * row + e;
+        const size_t t = flat / ((size_t)a.nu * a.B), m = (flat / a.B) % a.nu, bb = flat % a.B;
+        idx = (t * a.B + bb) * a.nu + m;
+      } else {
+        const int t = e / a.nu, m = e % a.nu;
+        idx = ((size_t)t * a.B + b) * a.nu + m;
+      }
+      const float d = a.u_old[idx] - a.u_first[idx];
+      acc = fmaf(d, d, acc);
+    }
+    const float nrm = sqrtf(acc);
+    a.last_norm[b] = nrm;
+    nan_seen = nan_seen || !(nrm == nrm);
+    vmax = fmaxf(vmax, nrm);
+    const bool better = a.it == 0 || a.costs[b] <= a.best_costs[b] + a.best_cost_eps;      // box_ddp.py:200-209
+    if (better) {
+      a.best_costs[b] = a.costs[b];
+      a.best_norm[b] = nrm;
+    }
+    a.keep[b] = better ? 1 : 0;
+    any |= (a.it > 0 && better) ? 1 : 0;
+  }
+  s_max[tid] = nan_seen ? __builtin_nanf("") : vmax;
+  s_any[tid] = any;
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -1.f;
+    bool bad = false;
+    int an = 0;
+    for (int i = 0; i < 256; ++i) {
+      bad = bad || !(s_max[i] == s_max[i]);
+      mx = fmaxf(mx, s_max[i]);
+      an |= s_any[i];
+    }
+    int n_not = a.state[kDdpNotImproved] + 1;
+    if (an) n_not = 0;
+    a.state[kDdpNotImproved] = n_not;
+    a.state[kDdpIter] = a.it + 1;
+    if (!bad && mx < a.eps) {                                                               // box_ddp.py:223-230
+      a.state[kDdpStatus] = 1;
+      a.state[kDdpDone] = 1;
+    } else if (n_not > a.not_improved_lim) {
+      a.state[kDdpStatus] = 2;
+      a.state[kDdpDone] = 1;
+    } else if (a.it == a.max_iter - 1) {
+      a.state[kDdpStatus] = 3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void box_ddp_keep_kernel(int T, int B, int nx, int nu, const int32_t *__restrict__ keep,
+                                                           const float *__restrict__ x, const float *__restrict__ u,
+                                                           float *__restrict__ best_x, float *__restrict__ best_u) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nxe = (size_t)T * B * nx, nue = (size_t)T * B * nu;
+  for (size_t e = tid; e < nxe; e += stride)
+    if (keep[(e / nx) % B]) best_x[e] = x[e];
+  for (size_t e = tid; e < nue; e += stride)
+    if (keep[(e / nu) % B]) best_u[e] = u[e];
+}
+
+}  // namespace dmpc

@@ -2,10 +2,12 @@
 // (include/dmpc.h sections C and E).  Replaces PNQP (mpc/pnqp.py:37-201), MPCstep.forward /
 // backward_rec / forward_rec / backward (mpc/mpc_step.py:70-460) of the reference.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
 #include "costate_args.hpp"
+#include "box_ddp_kernels.hpp"
 #include "mpc_kernels.hpp"
 
 namespace dmpc {
@@ -65,7 +67,17 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a, hipStream_t str
   return DMPC_E_UNSUPPORTED;
 }
 
+static bool spec_line_search_disabled() {  // DMPC_NO_SPEC_LS=1: sequential line search for the pendulum (A/B timing)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_SPEC_LS"); return e && e[0] == '1'; }();
+  return off;
+}
+
 static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a, hipStream_t stream) {
+  if (a.dyn_kind == 1 && nx == 3 && nu == 1 && !spec_line_search_disabled()) {
+    // the pendulum's line search usually walks ten or more step sizes: 16 candidates per trajectory at once
+    hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+  }
 #define X(NX_, NU_, L_)                                                                                      \
   if (nx == NX_ && nu == NU_) {                                                                              \
     constexpr int GPB = 256 / L_;                                                                            \
@@ -98,6 +110,39 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
   w.mask = take((size_t)T * B * nu);
   w.lqr = off;
   off += round_up(dmpc_lqr_workspace_bytes(T, B, nx, nu), 256);
+  w.total = off;
+  return w;
+}
+
+// workspace of the device-driven box-DDP loop (dmpc_box_ddp)
+struct DdpWs {
+  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, total;
+};
+static DdpWs ddp_layout(int T, int B, int nx, int nu) {
+  const size_t ns = nx + nu, TB = (size_t)T * B, fl = sizeof(float);
+  DdpWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off += round_up(bytes, 256);
+    return o;
+  };
+  w.xs = take(TB * nx * fl);
+  w.F = take(TB * nx * ns * fl);   // linearisation of a built-in dynamics (unused with a LinDx)
+  w.f = take(TB * nx * fl);
+  w.c_back = take(TB * ns * fl);
+  w.Ks = take(TB * nu * nx * fl);
+  w.ks = take(TB * nu * fl);
+  w.x_new = take(TB * nx * fl);
+  w.u_a = take(TB * nu * fl);
+  w.u_b = take(TB * nu * fl);
+  w.u1 = take(TB * nu * fl);
+  w.costs = take((size_t)B * fl);
+  w.old = take((size_t)B * fl);
+  w.alphas = take((size_t)B * fl);
+  w.nqp = take((size_t)B * sizeof(int32_t));
+  w.nls = take((size_t)B * sizeof(int32_t));
+  w.keep = take((size_t)B * sizeof(int32_t));
   w.total = off;
   return w;
 }
@@ -231,6 +276,76 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
                 max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info};
   return launch_mpc_fwd(nx, nu, fa, stream);
+}
+
+size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
+  return ddp_layout(T, B, nx, nu).total;
+}
+
+int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float *C, const float *c, const float *F,
+                 const float *f, int dyn_kind, const float *dyn_params, const float *u_init, const float *u_lower,
+                 const float *u_upper, float eps, int not_improved_lim, float ls_decay, int max_ls_iter,
+                 float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, float *x_best,
+                 float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last, int32_t *state, void *ws,
+                 size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || max_iter <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
+  if (!x_init || !C || !c || !u_init || !u_lower || !u_upper || !x_best || !u_best || !costs_best || !du_norm_best ||
+      !du_norm_last || !state || !ws)
+    return DMPC_E_BADARG;
+  if (dyn_kind == 0 && !F) return DMPC_E_BADARG;
+  if (dyn_kind == 1 && (!dyn_params || nx != 3 || nu != 1)) return DMPC_E_BADARG;
+  if (dyn_kind != 0 && dyn_kind != 1) return DMPC_E_UNSUPPORTED;
+  if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(ws)) return DMPC_E_BADARG;
+  const DdpWs w = ddp_layout(T, B, nx, nu);
+  if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  char *base = static_cast<char *>(ws);
+  auto fp = [&](size_t off) { return reinterpret_cast<float *>(base + off); };
+  auto ip = [&](size_t off) { return reinterpret_cast<int32_t *>(base + off); };
+  float *xs = fp(w.xs), *c_back = fp(w.c_back), *Ks = fp(w.Ks), *ks = fp(w.ks), *x_new = fp(w.x_new);
+  float *u_buf[2] = {fp(w.u_a), fp(w.u_b)};
+  float *u1 = fp(w.u1), *costs = fp(w.costs), *old = fp(w.old), *alphas = fp(w.alphas);
+  const float *F_hat = dyn_kind == 0 ? F : fp(w.F);
+  const float pg = dyn_kind == 1 ? dyn_params[0] : 0.f, pm = dyn_kind == 1 ? dyn_params[1] : 0.f,
+              pl = dyn_kind == 1 ? dyn_params[2] : 0.f, pdt = dyn_kind == 1 ? dyn_params[3] : 0.f,
+              pmax = dyn_kind == 1 ? dyn_params[4] : 0.f;
+  const size_t rows = (size_t)T * B;
+  hipError_t e = hipMemsetAsync(state, 0, 8 * sizeof(int32_t), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpyAsync(u_buf[0], u_init, rows * nu * sizeof(float), hipMemcpyDeviceToDevice, stream);
+  if (e != hipSuccess) return (int)e;
+  const int32_t *done = state + kDdpDone;
+  for (int it = 0; it < max_iter; ++it) {
+    const float *u_cur = u_buf[it & 1];
+    float *u_new = u_buf[(it & 1) ^ 1];
+    // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
+    if (dyn_kind == 1) {
+      PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs, fp(w.F), fp(w.f), done};
+      hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, pa);
+    } else {
+      hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
+                         f, xs, done);
+    }
+    hipLaunchKernelGGL(taylor_c_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, C, c, xs,
+                       u_cur, c_back);
+    // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
+    MpcBackArgs ba{T, B, C, c_back, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks, ip(w.nqp), info,
+                   done};
+    int rc = launch_mpc_back(nx, nu, ba, stream);
+    if (rc != 0) return rc;
+    MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
+                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, x_new, u_new, u1, costs, old,
+                  alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done};
+    rc = launch_mpc_fwd(nx, nu, fa, stream);
+    if (rc != 0) return rc;
+    DdpSelectArgs sa{it, T, B, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
+                     costs_best, du_norm_best, du_norm_last, ip(w.keep), state};
+    hipLaunchKernelGGL(box_ddp_select_kernel, dim3(1), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
+                       ip(w.keep), x_new, u_new, x_best, u_best);
+  }
+  return (int)hipGetLastError();
 }
 
 int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,

@@ -32,6 +32,7 @@ struct MpcBackArgs {
   float *Ks, *ks;                       // [T,B,nu,nx], [T,B,nu]
   int32_t *n_qp_total;                  // [B]  sum_t (1 + i_t)   (mpc_step.py:145)
   int32_t *info;
+  const int32_t *done;                  // device flag of the BoxDDP loop (box_ddp_kernels.hpp): non-zero -> no-op
 };
 
 template <int NX, int NU, int L>
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   using G = Group<L>;
   using Blk = RiccatiBlocks<NX, NU, L>;
 
+  if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
   const int lane = threadIdx.x % L;
   const int grp = threadIdx.x / L;
   int b = blockIdx.x * GPB + grp;
@@ -190,6 +192,25 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   }
 }
 
+// The pendulum of env_dx/pendulum.py:84-98 (simple model), state (cos th, sin th, dth), one torque.  One definition
+// for the nominal rollout and for both line-search kernels: the search ends when the candidate collapses onto the
+// nominal trajectory and its cost EQUALS the old one (mpc_step.py:196), which needs bit-equal dynamics.
+struct PendulumModel {
+  float kg, ku, dt, max_torque;  // 3g/(2l), 3/(m l^2)
+};
+__device__ __forceinline__ PendulumModel pendulum_model(float g, float m, float l, float dt, float max_torque) {
+  return PendulumModel{3.f * g / (2.f * l), 3.f / (m * (l * l)), dt, max_torque};
+}
+__device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, float s, float w, float u, float &cn,
+                                              float &sn, float &wn, float &nth) {
+  const float uc = fminf(fmaxf(u, -p.max_torque), p.max_torque);
+  const float th = atan2f(s, c);
+  wn = w + p.dt * (p.kg * s + p.ku * uc);
+  nth = th + wn * p.dt;
+  cn = cosf(nth);
+  sn = sinf(nth);
+}
+
 struct MpcFwdArgs {
   int T, B;
   const float *Ks, *ks;                  // gains from backward_rec
@@ -209,6 +230,7 @@ struct MpcFwdArgs {
   //   0 LinDx (F, f above)   1 the pendulum of env_dx/pendulum.py:65-102, simple model (nx = 3, nu = 1)
   int dyn_kind;
   float pend_g, pend_m, pend_l, pend_dt, pend_max_torque;
+  const int32_t *done;                   // device flag of the BoxDDP loop: non-zero -> no-op
 };
 
 template <int NX, int NU, int L>
@@ -218,6 +240,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   constexpr int GPB = 256 / L;
   using G = Group<L>;
 
+  if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
   const int lane = threadIdx.x % L;
   const int grp = threadIdx.x / L;
   int b = blockIdx.x * GPB + grp;
@@ -318,12 +341,11 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       if (t < T - 1 && !lin) {  // built-in pendulum (cos th, sin th, dth), torque -> next   pendulum.py:84-98
         if constexpr (NX == 3 && NU == 1) {
           const float cs = G::template bcast<0>(tau), sn = G::template bcast<1>(tau), dth = G::template bcast<2>(tau);
-          float uu = G::template bcast<3>(tau);
-          uu = fminf(fmaxf(uu, -a.pend_max_torque), a.pend_max_torque);
-          const float th = atan2f(sn, cs);
-          const float newdth = dth + a.pend_dt * (-3.f * a.pend_g / (2.f * a.pend_l) * (-sn) + 3.f * uu / (a.pend_m * (a.pend_l * a.pend_l)));
-          const float newth = th + newdth * a.pend_dt;
-          xh = lane == 0 ? cosf(newth) : (lane == 1 ? sinf(newth) : (lane == 2 ? newdth : 0.f));
+          const float uu = G::template bcast<3>(tau);
+          const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+          float cn, sn2, wn, nth;
+          pendulum_next(pm, cs, sn, dth, uu, cn, sn2, wn, nth);
+          xh = lane == 0 ? cn : (lane == 1 ? sn2 : (lane == 2 ? wn : 0.f));
         }
       } else if (t < T - 1) {  // new_x_{t+1} = F_t [new_x;new_u] + f_t under the TRUE dynamics   :229-236
         float acc = sl.fi;
@@ -365,6 +387,158 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   }
 }
 
+// forward_rec for the pendulum with a SPECULATIVE line search: the step sizes the search of mpc_step.py:196-268 can
+// visit are known in advance (alpha_p = ls_decay^p), and on the swing-up problem it usually walks ten or more of
+// them before the candidate collapses onto the nominal trajectory.  One lane per (trajectory, candidate): the 16
+// lanes of a group roll 16 consecutive step sizes out at once, the first one that is not worse than the old cost is
+// the one the sequential search stops at, and one more pass writes its trajectory.  Two passes instead of p* + 1.
+__global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(const MpcFwdArgs a) {
+  constexpr int NX = 3, NU = 1, NS = 4, NC = 16;
+  if (a.done != nullptr && *a.done != 0) return;
+  const int k = threadIdx.x & (NC - 1);
+  const int base = (threadIdx.x & 63) & ~(NC - 1);  // first lane of the group within the wavefront
+  int b = blockIdx.x * (256 / NC) + (threadIdx.x / NC);
+  const bool live = b < a.B;
+  if (!live) b = a.B - 1;
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+
+  struct Slot {  // inputs of one timestep (the same for every candidate of the trajectory)
+    float xt[NX], K[NX], kk, uc, lb, ub, C[NS][NS], cc[NS];
+  };
+  auto load = [&](int t, Slot &sl) {
+    t = t < T ? t : T - 1;
+    const size_t tb = (size_t)t * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      sl.xt[i] = a.states[tb * NX + i];
+      sl.K[i] = a.Ks[tb * NX + i];
+    }
+    sl.kk = a.ks[tb];
+    sl.uc = a.controls[tb];
+    sl.lb = a.lower[tb];
+    sl.ub = a.upper[tb];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      load_contig<NS>(a.C + (tb * NS + i) * NS, sl.C[i]);
+      sl.cc[i] = a.c[tb * NS + i];
+    }
+  };
+  auto quad = [&](const Slot &sl, const float (&tau)[NS]) {  // 1/2 tau'C tau + c'tau                util.py:162-198
+    float obj = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      float qi = 0.f;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) qi = fmaf(sl.C[i][j], tau[j], qi);
+      obj = fmaf(tau[i], fmaf(0.5f, qi, sl.cc[i]), obj);
+    }
+    return obj;
+  };
+  // one rollout with step size alpha; mode 0: cost only, 1: also the cost of the nominal trajectory and (candidate 0)
+  // the controls of the alpha = 1 pass, 2: write the trajectory
+  auto pass = [&](float alpha, int mode, float &cost, float &old_cost) {
+    float xh[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xh[i] = a.states[(size_t)b * NX + i];                       // :198
+    cost = 0.f;
+    if (mode == 1) old_cost = 0.f;
+    auto step = [&](int t, const Slot &sl) {
+      const size_t tb = (size_t)t * B + b;
+      float v = alpha * sl.kk;
+#pragma unroll
+      for (int i = NX - 1; i >= 0; --i) v = fmaf(sl.K[i], xh[i] - sl.xt[i], v);
+      v += sl.uc;                                                                            // :209-219
+      v = fminf(fmaxf(v, sl.lb), sl.ub);                                                     // :221
+      v = (v - sl.lb <= bound_tol(sl.lb)) ? sl.lb : v;
+      v = (sl.ub - v <= bound_tol(sl.ub)) ? sl.ub : v;
+      const float tau[NS] = {xh[0], xh[1], xh[2], v};
+      const float obj = quad(sl, tau);
+      cost += obj;
+      if (mode == 1) {
+        const float tau0[NS] = {sl.xt[0], sl.xt[1], sl.xt[2], sl.uc};
+        old_cost += quad(sl, tau0);                                                          // :191
+        if (k == 0 && live && a.u_first != nullptr) a.u_first[tb] = v;                       // :260-263
+      }
+      if (mode == 2 && k == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a.x[tb * NX + i] = xh[i];
+        a.u[tb] = v;
+        if (a.objs != nullptr) a.objs[tb] = obj;
+      }
+      if (t < T - 1) {
+        float cn, sn, wn, nth;
+        pendulum_next(pm, xh[0], xh[1], xh[2], v, cn, sn, wn, nth);
+        xh[0] = cn;
+        xh[1] = sn;
+        xh[2] = wn;
+      }
+    };
+    Slot sa, sb;
+    load(0, sa);
+    for (int t = 0; t < T; t += 2) {
+      load(t + 1, sb);
+      step(t, sa);
+      if (t + 1 < T) {
+        load(t + 2, sa);
+        step(t + 1, sb);
+      }
+    }
+  };
+
+  const int rounds = (a.ls_cap + NC - 1) / NC;
+  float old_cost = 0.f, cost = 0.f, alpha = 1.f;
+  float alpha_sel = 1.f, cost_sel = 0.f;
+  int p_sel = -1;
+  for (int r = 0; r < rounds; ++r) {
+    const bool searching = p_sel < 0;
+    if (!__any(searching)) break;
+    const int p = r * NC + k;
+    if (searching) {
+      alpha = 1.f;
+      for (int i = 0; i < p; ++i) alpha *= a.ls_decay;                                       // :268, p times
+      float oc = 0.f;
+      pass(alpha, r == 0 ? 1 : 0, cost, oc);
+      if (r == 0) old_cost = oc;
+    }
+    const bool accept = searching && p < a.ls_cap && !(cost > old_cost);                     // :266
+    const unsigned mask = (unsigned)((__ballot(accept) >> base) & 0xFFFFull);
+    if (searching && mask != 0u) {
+      const int ks = __ffs(mask) - 1;
+      p_sel = r * NC + ks;
+      alpha_sel = __shfl(alpha, base + ks);
+      cost_sel = __shfl(cost, base + ks);
+    }
+  }
+  int info_bits = 0;
+  int n_pass;
+  if (p_sel < 0) {  // cap hit: the reference would still be looping; its last pass is the result        :274
+    const int last = (a.ls_cap - 1) % NC;
+    alpha_sel = __shfl(alpha, base + last);
+    cost_sel = __shfl(cost, base + last);
+    alpha_sel = (alpha_sel * a.ls_decay) / a.ls_decay;
+    n_pass = a.ls_cap;
+    info_bits |= 8;
+    float dummy = 0.f, c2 = 0.f;
+    float al = 1.f;
+    for (int i = 0; i < a.ls_cap - 1; ++i) al *= a.ls_decay;
+    pass(al, 2, c2, dummy);
+  } else {
+    n_pass = p_sel + 1;
+    float dummy = 0.f, c2 = 0.f;
+    pass(alpha_sel, 2, c2, dummy);
+  }
+  if (!is_finite(cost_sel)) info_bits |= 2;
+  if (live && k == 0) {
+    a.costs[b] = cost_sel;
+    if (a.old_costs != nullptr) a.old_costs[b] = old_cost;
+    a.alphas[b] = alpha_sel;
+    a.n_ls[b] = n_pass;
+    if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+  }
+}
+
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
 // (env_dx/pendulum.py:84-98, simple model), F_t = d x_{t+1} / d [x_t; u_t], f_t = x_{t+1} - F_t [x_t; u_t] - what
 // BoxDDP obtains from get_traj (util.py:201-277) followed by linearize_dynamics (mpc/approximate.py:77-119, there
@@ -374,14 +548,17 @@ struct PendulumArgs {
   const float *x_init, *u;   // [B,3], [T,B,1]
   float g, m, l, dt, max_torque;
   float *x, *F, *f;          // [T,B,3], [T-1,B,3,4] or nullptr, [T-1,B,3] or nullptr
+  const int32_t *done;       // device flag of the BoxDDP loop: non-zero -> no-op
 };
 
 __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const PendulumArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
+  if (a.done != nullptr && *a.done != 0) return;
   const size_t B = (size_t)a.B;
   float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
-  const float kg = 3.f * a.g / (2.f * a.l), ku = 3.f / (a.m * (a.l * a.l));
+  const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque);
+  const float kg = pm.kg, ku = pm.ku;
   for (int t = 0; t < a.T; ++t) {
     const size_t tb = (size_t)t * B + b;
     a.x[tb * 3 + 0] = c;
@@ -389,13 +566,10 @@ __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const Pe
     a.x[tb * 3 + 2] = w;
     if (t == a.T - 1) break;
     const float ur = a.u[tb];
-    const float uc = fminf(fmaxf(ur, -a.max_torque), a.max_torque);
     const float inside = (ur > -a.max_torque && ur < a.max_torque) ? 1.f : 0.f;
     const float r2 = c * c + s * s;
-    const float th = atan2f(s, c);
-    const float nw = w + a.dt * (kg * s + ku * uc);
-    const float nth = th + nw * a.dt;
-    const float sn = sinf(nth), cn = cosf(nth);
+    float cn, sn, nw, nth;
+    pendulum_next(pm, c, s, w, ur, cn, sn, nw, nth);
     if (a.F != nullptr) {
       const float dnw[4] = {0.f, a.dt * kg, 1.f, a.dt * ku * inside};
       const float dnth[4] = {-s / r2 + a.dt * dnw[0], c / r2 + a.dt * dnw[1], a.dt * dnw[2], a.dt * dnw[3]};

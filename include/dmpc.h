@@ -158,6 +158,25 @@ int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const flo
                                     float dt, float max_torque, float *x_out, float *F_out, float *f_out,
                                     dmpc_stream_t stream);
 
+/* The outer box-DDP loop (BoxDDP.forward, mpc/box_ddp.py:93-230) for a QuadCost and either a LinDx (dyn_kind 0:
+ * F [T-1|T,B,nx,ns], f [T-1,B,nx] or NULL) or the built-in pendulum (dyn_kind 1: F = f = NULL, dyn_params = HOST
+ * array {g, m, l, dt, max_torque}, nx = 3, nu = 1), as ONE chain of launches: per iteration the nominal rollout
+ * (util.py:239-277) and, for the pendulum, its linearisation (mpc/approximate.py:77-119), the MPC step with
+ * need_expand (mpc_step.py:288-328), the per-sample "best so far" update (box_ddp.py:200-209) and the stop tests
+ * (:223-230), all decided on the device: max_iter iterations are enqueued, those after the stop are no-ops.
+ *   u_init [T,B,nu];  outputs x_best [T,B,nx], u_best [T,B,nu], costs_best [B], du_norm_best [B] (full_du_norm of
+ *   the best iterate), du_norm_last [B] (of the last executed step, box_ddp.py:263-289 reads it);
+ *   state [8] int32: [0] stopped early, [1] iterations run, [2] 1 Converged / 2 Not improved lim / 3 Not Converged;
+ *   scrambled_norm != 0 reproduces the reference's reshape in full_du_norm (mpc_step.py:261-263);
+ *   info [B] accumulates the MPC step flags of every iteration (caller zeroes it).                              */
+size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu);
+int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float *C, const float *c, const float *F,
+                 const float *f, int dyn_kind, const float *dyn_params, const float *u_init, const float *u_lower,
+                 const float *u_upper, float eps, int not_improved_lim, float ls_decay, int max_ls_iter,
+                 float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, float *x_best,
+                 float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last, int32_t *state, void *ws,
+                 size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
+
 /* backward(): active-set LQR on (-d_tau) + co-state sweeps + outer products (mpc_step.py:330-460).
  *   outputs carry the reference's signs: dC = -1/2(dtau'(x)tau + tau(x)dtau'), dc = -dtau',
  *   dF = -(dlam(x)tau + lam(x)dtau'), df = -dlam[1:] (NULL to skip), dx_init = -dlam[0].  */

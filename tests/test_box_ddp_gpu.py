@@ -231,3 +231,76 @@ def test_il_env_and_cost_net_one_rmsprop_step():
     for prm in (net.learn_q_logit, net.learn_p):
         assert torch.isfinite(prm).all() and torch.isfinite(prm.grad).all()
     assert float(net.learn_q_logit.grad.abs().max()) > 0
+
+
+def _run_both(make_solver, args):
+    out = []
+    for device_loop in (True, False):
+        solver = make_solver(device_loop)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, costs = solver(args())
+        out.append((npy(x), npy(u), npy(costs), solver.status, solver.n_iter))
+    return out
+
+
+@pytest.mark.parametrize("max_iter", [1, 4, 10])
+def test_device_loop_matches_host_loop_pendulum(max_iter):
+    """`dmpc_box_ddp` (stop tests and best-so-far selection on the device) against the host loop over MPCstep
+    objects: same kernels in the same order, so iterates, status and iteration count agree"""
+    B, T = 128, 20
+    dx, x0, Q, pv = pendulum_problem(B, T, seed=3)
+    kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter)
+    dev_, host = _run_both(
+        lambda dl: BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, max_iter=max_iter, exit_unconverged=False, quiet=True,
+                          device_loop=dl, **kw),
+        lambda: (dev(x0), QuadCost(dev(Q), dev(pv)), dx))
+    assert dev_[3] == host[3] and dev_[4] == host[4], (dev_[3:], host[3:])
+    assert_close(dev_[1], host[1], 1e-5, "u")
+    assert_close(dev_[0], host[0], 1e-5, "x")
+    assert_close(dev_[2], host[2], 1e-5, "costs")
+
+
+@pytest.mark.parametrize("shape", [(16, 8, 3, 2, 0.3), (64, 12, 8, 2, 0.5), (5, 6, 4, 2, 10.0)])
+def test_device_loop_matches_host_loop_lindx(shape):
+    # the nominal rollout is a kernel here and torch ops there: rounding differs, the iteration amplifies it
+    B, T, nx, nu, bound = shape
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=11, with_f=True)
+    dev_, host = _run_both(
+        lambda dl: BoxDDP(T, -bound, bound, B, nx, nu, None, max_iter=10, quiet=True, device_loop=dl),
+        lambda: (dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
+    assert dev_[3] == host[3] and dev_[4] == host[4], (dev_[3:], host[3:])
+    assert_close(dev_[1], host[1], 5e-4, "u")
+    assert_close(dev_[0], host[0], 5e-4, "x")
+    assert_close(dev_[2], host[2], 5e-4, "costs")
+
+
+def test_device_loop_stops_early_and_freezes_the_result():
+    """an unconstrained LQ problem converges at the second step: later launches of the chain must be no-ops"""
+    B, T, nx, nu = 32, 10, 4, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=5, with_f=True)
+    solver = BoxDDP(T, -1e3, 1e3, B, nx, nu, None, max_iter=10, quiet=True)
+    x, u, costs = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
+    assert solver.status == "Converged" and solver.n_iter < 10
+    from oracle import lqr as olqr
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    assert_close(npy(u), ur, 1e-4, "u")
+    assert_close(npy(x), xr, 1e-4, "x")
+
+
+def test_device_loop_gradient_through_the_final_node():
+    """MpcNet-style use: the gradient is carried by the no-op MPCstep node after the device loop"""
+    B, T, nx, nu = 8, 6, 3, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=2, with_f=True)
+    grads = []
+    for dl in (True, False):
+        F = dev(p["F"]).clone().requires_grad_(True)
+        solver = BoxDDP(T, -0.5, 0.5, B, nx, nu, None, max_iter=10, quiet=True, device_loop=dl,
+                        detach_unconverged=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, _ = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(F, dev(p["f"]))))
+        (x.sum() + u.sum()).backward()
+        grads.append(npy(F.grad))
+    assert np.abs(grads[0]).max() > 0
+    assert_close(grads[0], grads[1], 2e-3, "dF")   # rollout rounding (kernel vs torch ops) through the co-state sweep
