@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .approximate import approximate_cost, linearize_dynamics
-from .lqr_recursion import _as_tensor, _device_of, _workspace, raise_info
+from .lqr_recursion import _as_tensor, _device_of, _workspace
 from .mpc_step import MPCstep
 from .util import LinDx, QuadCost, get_cost, get_traj
 
@@ -101,8 +101,8 @@ class BoxDDP(torch.nn.Module):
         if f is not None and list(f.shape) != [T - 1, B, nx]:
             return None
         u0, lo_, hi_ = _lib.f32c(u, d), _lib.f32c(lo, d), _lib.f32c(hi, d)
-        assert not bool(torch.isnan(u0).any())
-        assert bool((lo_ <= hi_).all()), " lower is larger than upper"
+        # MPCstep's input asserts (mpc_step.py:133-138), evaluated on the device and read with the loop state
+        bad_in = torch.stack((torch.isnan(u0).any(), (lo_ > hi_).any()))
         f32 = dict(dtype=torch.float32, device=d)
         bx, bu = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32)
         bc, bn, ln = torch.empty((B,), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
@@ -121,8 +121,13 @@ class BoxDDP(torch.nn.Module):
         if rc == _lib.E_UNSUPPORTED:
             return None
         _lib.check(rc, "dmpc_box_ddp")
-        st = state.cpu().tolist()                 # the one synchronisation of the loop
-        raise_info(info, "BoxDDP")                # the reference asserts on NaN inside every MPC step
+        n_bad = ((info & _lib.INFO_NONFINITE) != 0).sum()
+        summary = torch.cat((state[:4], bad_in.to(torch.int32), n_bad.to(torch.int32)[None]))
+        st = summary.cpu().tolist()               # the one synchronisation of the loop
+        assert not st[4]
+        assert not st[5], " lower is larger than upper"
+        if st[6]:                                 # the reference asserts on NaN inside every MPC step
+            raise AssertionError("BoxDDP: NaN/Inf in the solution of %d trajectories" % st[6])
         self.info = info
         self.n_iter = st[1]
         if st[2] in self._STATUS:

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(64) void lin_rollout_kernel(int T, int B, int nx, i
 }
 
 struct DdpSelectArgs {
-  int it, T, B, nu;
+  int it, T, B, nx, nu;
   int max_iter, not_improved_lim, scrambled;
   float eps, best_cost_eps;
   const float *u_old, *u_first;  // controls the step started from / of its first (alpha = 1) pass   [T,B,nu]
@@ -50,34 +50,74 @@ struct DdpSelectArgs {
   float *best_costs, *best_norm, *last_norm;  // [B]
   int32_t *keep;                 // [B] 1 where the step's x / u replace the best ones
   int32_t *state;
+  // small problems: the same workgroup also moves the kept trajectories (no box_ddp_keep_kernel launch)
+  int copy_here;
+  const float *x_new, *u_new;
+  float *best_x, *best_u;
 };
 
-__global__ __launch_bounds__(256) void box_ddp_select_kernel(const DdpSelectArgs a) {
-  __shared__ float s_max[256];
-  __shared__ int s_any[256];
+constexpr int kDdpCopyHereMaxB = 2048;
+constexpr int kDdpSelectThreads = 1024;
+
+__global__ __launch_bounds__(kDdpSelectThreads) void box_ddp_select_kernel(const DdpSelectArgs a) {
+  __shared__ float s_max[kDdpSelectThreads / 64];
+  __shared__ int s_any[kDdpSelectThreads / 64];
+  __shared__ unsigned char s_keep[kDdpCopyHereMaxB];
   const int tid = threadIdx.x;
   if (a.state[kDdpDone] != 0) {  // stopped in an earlier iteration: nothing moves any more
-    for (int b = tid; b < a.B; b += 256) a.keep[b] = 0;
+    for (int b = tid; b < a.B; b += kDdpSelectThreads) a.keep[b] = 0;
     return;
   }
   const int row = a.T * a.nu;
   float vmax = -1.f;
   bool nan_seen = false;
   int any = 0;
-  for (int b = tid; b < a.B; b += 256) {
+  for (int b = tid; b < a.B; b += kDdpSelectThreads) {
     float acc = 0.f;
-    for (int e = 0; e < row; ++e) {
-      size_t idx;
-      if (a.scrambled) {  // [T,nu,B] read as [B, T*nu]                                   mpc_step.py:261-263
-        const size_t flat = (size_t)b * row + e;
-        const size_t t = flat / ((size_t)a.nu * a.B), m = (flat / a.B) % a.nu, bb = flat % a.B;
-        idx = (t * a.B + bb) * a.nu + m;
-      } else {
-        const int t = e / a.nu, m = e % a.nu;
-        idx = ((size_t)t * a.B + b) * a.nu + m;
+    if (a.scrambled) {  // the [T,nu,B] array read as [B, T*nu]: row b = flat [b*row, (b+1)*row)      mpc_step.py:261-263
+      const unsigned flat = (unsigned)b * (unsigned)row;
+      unsigned bb = flat % (unsigned)a.B, tm = flat / (unsigned)a.B;
+      unsigned m = tm % (unsigned)a.nu, t = tm / (unsigned)a.nu;
+      auto next_idx = [&]() {
+        const size_t idx = ((size_t)t * a.B + bb) * a.nu + m;
+        if (++bb == (unsigned)a.B) {
+          bb = 0;
+          if (++m == (unsigned)a.nu) {
+            m = 0;
+            ++t;
+          }
+        }
+        return idx;
+      };
+      int e = 0;
+      for (; e + 8 <= row; e += 8) {  // eight independent pairs of loads in flight (one lane per row: latency bound)
+        size_t idx[8];
+        float uo[8], uf[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) idx[q] = next_idx();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          uo[q] = a.u_old[idx[q]];
+          uf[q] = a.u_first[idx[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float d = uo[q] - uf[q];
+          acc = fmaf(d, d, acc);
+        }
       }
-      const float d = a.u_old[idx] - a.u_first[idx];
-      acc = fmaf(d, d, acc);
+      for (; e < row; ++e) {
+        const size_t idx = next_idx();
+        const float d = a.u_old[idx] - a.u_first[idx];
+        acc = fmaf(d, d, acc);
+      }
+    } else {
+      for (int t = 0; t < a.T; ++t)
+        for (int m = 0; m < a.nu; ++m) {
+          const size_t idx = ((size_t)t * a.B + b) * a.nu + m;
+          const float d = a.u_old[idx] - a.u_first[idx];
+          acc = fmaf(d, d, acc);
+        }
     }
     const float nrm = sqrtf(acc);
     a.last_norm[b] = nrm;
@@ -89,20 +129,30 @@ __global__ __launch_bounds__(256) void box_ddp_select_kernel(const DdpSelectArgs
       a.best_norm[b] = nrm;
     }
     a.keep[b] = better ? 1 : 0;
+    if (a.copy_here) s_keep[b] = better ? 1 : 0;
     any |= (a.it > 0 && better) ? 1 : 0;
   }
-  s_max[tid] = nan_seen ? __builtin_nanf("") : vmax;
-  s_any[tid] = any;
+  // wavefront reduction first (a serial pass of one lane over 256 LDS entries costs more than the norms themselves)
+  int flags = (nan_seen ? 2 : 0) | any;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    flags |= __shfl_xor(flags, off);
+  }
+  if ((tid & 63) == 0) {
+    s_max[tid >> 6] = vmax;
+    s_any[tid >> 6] = flags;
+  }
   __syncthreads();
   if (tid == 0) {
     float mx = -1.f;
-    bool bad = false;
-    int an = 0;
-    for (int i = 0; i < 256; ++i) {
-      bad = bad || !(s_max[i] == s_max[i]);
+    int fl = 0;
+    for (int i = 0; i < kDdpSelectThreads / 64; ++i) {
       mx = fmaxf(mx, s_max[i]);
-      an |= s_any[i];
+      fl |= s_any[i];
     }
+    const bool bad = (fl & 2) != 0;
+    const int an = fl & 1;
     int n_not = a.state[kDdpNotImproved] + 1;
     if (an) n_not = 0;
     a.state[kDdpNotImproved] = n_not;
@@ -115,6 +165,19 @@ __global__ __launch_bounds__(256) void box_ddp_select_kernel(const DdpSelectArgs
       a.state[kDdpDone] = 1;
     } else if (a.it == a.max_iter - 1) {
       a.state[kDdpStatus] = 3;
+    }
+  }
+  if (a.copy_here) {
+    const int n_rows = a.T * a.B;  // one (t, b) row per thread and trip
+    const float *__restrict__ xn = a.x_new, *__restrict__ un = a.u_new;
+    float *__restrict__ bx = a.best_x, *__restrict__ bu = a.best_u;
+    int b = tid % a.B;
+    for (int r = tid; r < n_rows; r += kDdpSelectThreads) {
+      if (s_keep[b]) {
+        for (int i = 0; i < a.nx; ++i) bx[r * a.nx + i] = xn[r * a.nx + i];
+        for (int i = 0; i < a.nu; ++i) bu[r * a.nu + i] = un[r * a.nu + i];
+      }
+      b = (b + kDdpSelectThreads) % a.B;
     }
   }
 }

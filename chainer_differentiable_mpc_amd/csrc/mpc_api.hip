@@ -296,6 +296,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   if (dyn_kind == 0 && !F) return DMPC_E_BADARG;
   if (dyn_kind == 1 && (!dyn_params || nx != 3 || nu != 1)) return DMPC_E_BADARG;
   if (dyn_kind != 0 && dyn_kind != 1) return DMPC_E_UNSUPPORTED;
+  if ((size_t)T * B * (nx + nu) >= ((size_t)1 << 31)) return DMPC_E_UNSUPPORTED;  // 32-bit indices in the bookkeeping
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(ws)) return DMPC_E_BADARG;
   const DdpWs w = ddp_layout(T, B, nx, nu);
   if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
@@ -321,14 +322,14 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     float *u_new = u_buf[(it & 1) ^ 1];
     // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
     if (dyn_kind == 1) {
-      PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs, fp(w.F), fp(w.f), done};
+      PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs, fp(w.F), fp(w.f), done, C, c, c_back};
       hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, pa);
     } else {
       hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
                          f, xs, done);
+      hipLaunchKernelGGL(taylor_c_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, C, c,
+                         xs, u_cur, c_back);
     }
-    hipLaunchKernelGGL(taylor_c_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, C, c, xs,
-                       u_cur, c_back);
     // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
     MpcBackArgs ba{T, B, C, c_back, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks, ip(w.nqp), info,
                    done};
@@ -339,11 +340,14 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
                   alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done};
     rc = launch_mpc_fwd(nx, nu, fa, stream);
     if (rc != 0) return rc;
-    DdpSelectArgs sa{it, T, B, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
-                     costs_best, du_norm_best, du_norm_last, ip(w.keep), state};
-    hipLaunchKernelGGL(box_ddp_select_kernel, dim3(1), dim3(256), 0, stream, sa);
-    hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
-                       ip(w.keep), x_new, u_new, x_best, u_best);
+    const bool copy_here = B <= kDdpCopyHereMaxB && rows * (size_t)(nx + nu) <= (size_t)64 * 1024;
+    DdpSelectArgs sa{it, T, B, nx, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
+                     costs_best, du_norm_best, du_norm_last, ip(w.keep), state, copy_here ? 1 : 0, x_new, u_new,
+                     x_best, u_best};
+    hipLaunchKernelGGL(box_ddp_select_kernel, dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
+    if (!copy_here)
+      hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
+                         ip(w.keep), x_new, u_new, x_best, u_best);
   }
   return (int)hipGetLastError();
 }

@@ -549,6 +549,10 @@ struct PendulumArgs {
   float g, m, l, dt, max_torque;
   float *x, *F, *f;          // [T,B,3], [T-1,B,3,4] or nullptr, [T-1,B,3] or nullptr
   const int32_t *done;       // device flag of the BoxDDP loop: non-zero -> no-op
+  // optional Taylor re-centring of a QuadCost at the rolled-out trajectory (what taylor_c_kernel computes):
+  // c_back[t][b] = C[t][b] [x_t; u_t] + c[t][b]                                            mpc_step.py:305-317
+  const float *C, *c;        // [T,B,4,4], [T,B,4]
+  float *c_back;             // [T,B,4] or nullptr
 };
 
 __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const PendulumArgs a) {
@@ -559,13 +563,53 @@ __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const Pe
   float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
   const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque);
   const float kg = pm.kg, ku = pm.ku;
+  const bool taylor = a.c_back != nullptr;
+  // inputs of step t + 1 are fetched while step t runs its atan2 / sin / cos (one lane per trajectory: nothing else
+  // hides the latency)
+  float u_nx = a.u[b], C_nx[4][4], c_nx[4];
+  if (taylor) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      load_contig<4>(a.C + ((size_t)b * 4 + i) * 4, C_nx[i]);
+      c_nx[i] = a.c[(size_t)b * 4 + i];
+    }
+  }
   for (int t = 0; t < a.T; ++t) {
     const size_t tb = (size_t)t * B + b;
+    const float ur = u_nx;
+    float Cc[4][4], cc[4];
+    if (taylor) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Cc[i][j] = C_nx[i][j];
+        cc[i] = c_nx[i];
+      }
+    }
+    if (t + 1 < a.T) {
+      u_nx = a.u[tb + B];
+      if (taylor) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          load_contig<4>(a.C + ((tb + B) * 4 + i) * 4, C_nx[i]);
+          c_nx[i] = a.c[(tb + B) * 4 + i];
+        }
+      }
+    }
     a.x[tb * 3 + 0] = c;
     a.x[tb * 3 + 1] = s;
     a.x[tb * 3 + 2] = w;
+    if (taylor) {
+      const float tau[4] = {c, s, w, ur};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float acc = cc[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = fmaf(Cc[i][j], tau[j], acc);
+        a.c_back[tb * 4 + i] = acc;
+      }
+    }
     if (t == a.T - 1) break;
-    const float ur = a.u[tb];
     const float inside = (ur > -a.max_torque && ur < a.max_torque) ? 1.f : 0.f;
     const float r2 = c * c + s * s;
     float cn, sn, nw, nth;

@@ -9,7 +9,7 @@ x0 = torch.as_tensor(sample_xinit(B, seed=0), dtype=torch.float32, device="cuda"
 Q = torch.as_tensor(np.tile(np.diag(q.numpy()), (T, B, 1, 1)), dtype=torch.float32, device="cuda")
 pv = torch.as_tensor(np.tile(pp.numpy(), (T, B, 1)), dtype=torch.float32, device="cuda")
 kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter)
-solver = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, max_iter=3, exit_unconverged=False, quiet=True, **kw)
+solver = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, max_iter=10, exit_unconverged=False, quiet=True, **kw)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     solver((x0, QuadCost(Q, pv), dx))
