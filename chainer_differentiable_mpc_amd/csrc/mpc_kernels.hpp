@@ -256,22 +256,8 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   const int lane_x = is_x ? lane : NX - 1;
   const int lane_t = is_tau ? lane : NS - 1;
 
-  // cost of a trajectory under the true QuadCost: sum_t 1/2 tau'C tau + c'tau           util.py:162-198
-  auto step_cost = [&](size_t tb, float tau) {
-    float Crow[NS];
-    load_contig<NS>(a.C + (tb * NS + lane_t) * NS, Crow);
-    float qi = 0.f;
-    static_for<0, NS>([&](auto j) { qi = fmaf(Crow[j.value], G::template bcast<j.value>(tau), qi); });
-    const float ci = a.c[tb * NS + lane_t];
-    return group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, ci) : 0.f);
-  };
-
+  // OLD_COST of (states, controls) (mpc_step.py:191) is accumulated during the first pass from the same rows of C
   float old_cost = 0.f;
-  for (int t = 0; t < T; ++t) {  // OLD_COST of (states, controls)                      mpc_step.py:191
-    const size_t tb = (size_t)t * B + b;
-    const float tau = lane_t < NX ? a.states[tb * NX + lane_t] : a.controls[tb * NU + (lane_t - NX)];
-    old_cost += step_cost(tb, tau);
-  }
 
   // Inputs of one timestep of a pass; the loads of step t+2 are issued before step t is computed (see the backward
   // kernel above).  A pass that is no longer needed by this trajectory still runs masked while wave-mates search.
@@ -332,6 +318,12 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       for (int m = 0; m < NU; ++m) tau = (lane == NX + m) ? un[m] : tau;
       const float obj = slot_cost(sl, tau);                                          // :246-251
       cost += obj;
+      if (n_pass == 0) {  // cost of the iterate the step started from                                  :191
+        float tau0 = sl.xt;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) tau0 = (lane == NX + m) ? sl.uc[m] : tau0;
+        old_cost += slot_cost(sl, tau0);
+      }
       if (live) {  // outputs are overwritten by later passes; the last one is the accepted one
         if (is_x) a.x[tb * NX + lane] = xh;
         else if (lane < NS) a.u[tb * NU + (lane - NX)] = tau;
