@@ -184,6 +184,36 @@ def test_headline_shape_properties_and_sampled_oracle():
     assert_close(npy(u)[:, idx], ur, TOL_PRIMAL, "u")
 
 
+def test_config5_shard_properties_and_sampled_oracle():
+    """BASELINE.json configs[4]: nx=32, nu=8, T=50, batch 65536 over 8 GPUs = 8192 trajectories per GPU (one
+    shard, drawn on the device as bench.py does).  Size-independent properties on the whole shard + the oracle
+    on a sample of its trajectories."""
+    import bench
+    B, T, nx, nu = 8192, 50, 32, 8
+    _, d = bench.make_inputs(B, T, nx, nu, 3, torch.device("cuda"))
+    x, u, Ks, ks = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, want_gains=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(x).all() and torch.isfinite(u).all()
+    tau = torch.cat((x, u), dim=2)
+    nxt = torch.einsum("tbij,tbj->tbi", d["F"], tau[:-1]) + d["f"]                  # x_{t+1} = F_t [x_t;u_t] + f_t
+    assert float((nxt - x[1:]).abs().max()) <= 1e-4 * max(1.0, float(x.abs().max()))
+    assert torch.equal(x[0], d["x_init"])
+    ufb = torch.einsum("tbij,tbj->tbi", Ks, x) + ks                                 # u_t = K_t x_t + k_t
+    assert float((ufb - u).abs().max()) <= 1e-4 * max(1.0, float(u.abs().max()))
+    sl = slice(4096, 4096 + 256)                                                    # shard invariance
+    xs, us, _, _ = solve_device(d["C"][:, sl].contiguous(), d["c"][:, sl].contiguous(), d["F"][:, sl].contiguous(),
+                                d["f"][:, sl].contiguous(), d["x_init"][sl].contiguous(), None, T, nx, nu)
+    assert torch.equal(xs, x[:, sl]) and torch.equal(us, u[:, sl])
+    CT = d["C"][T - 1]                                                              # stationarity at the last step
+    res = torch.einsum("bij,bj->bi", CT[:, nx:, :], tau[T - 1]) + d["c"][T - 1][:, nx:]
+    assert float(res.abs().max()) <= 1e-3
+    idx = torch.as_tensor(np.random.RandomState(5).choice(B, 12, replace=False), device="cuda")
+    p = {k: npy(d[k].index_select(0 if k == "x_init" else 1, idx)).astype(np.float64) for k in d}
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    assert_close(npy(x.index_select(1, idx)), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u.index_select(1, idx)), ur, TOL_PRIMAL, "u")
+
+
 def test_reference_style_dynamics_still_within_primal_tolerance():
     """A = I + 0.2*randn (the reference's initialiser, rho(A) > 1): x,u stay within 1e-4"""
     B, T, nx, nu = 32, 50, 8, 2
