@@ -74,6 +74,24 @@ class BoxDDP(torch.nn.Module):
 
     _STATUS = {1: "Converged", 2: "Not improved lim", 3: "Not Converged "}
 
+    @staticmethod
+    def _nominal(T, u, x_init, dyn):
+        """get_traj (util.py:239-277).  Under a LinDx on the GPU the rollout kernel is used: it sums in the order of
+        the MPC step's own line-search rollout, so unchanged controls reproduce the nominal trajectory exactly and
+        the stop test `full_du_norm < eps` sees zero at a fixed point (torch's bmv rounds differently)."""
+        if isinstance(dyn, LinDx) and isinstance(x_init, torch.Tensor) and x_init.is_cuda and u.is_cuda:
+            lib = _lib.load()
+            d = x_init.device
+            B, nx, nu = x_init.shape[0], x_init.shape[1], u.shape[2]
+            x0, ud, F, f = _lib.f32c(x_init, d), _lib.f32c(u, d), _lib.f32c(dyn.F, d), _lib.f32c(dyn.f, d)
+            x = torch.empty((T, B, nx), dtype=torch.float32, device=d)
+            with torch.cuda.device(d):
+                rc = lib.dmpc_lin_rollout(T, B, nx, nu, _lib.ptr(x0), _lib.ptr(ud), _lib.ptr(F), _lib.ptr(f),
+                                          _lib.ptr(x), _lib.stream_ptr(d))
+            _lib.check(rc, "dmpc_lin_rollout")
+            return x.to(x_init.dtype)
+        return get_traj(T, u, x_init, dyn)
+
     def _device_loop(self, x_init, cost, dynamics, u, lo, hi):
         """box_ddp.py:123-230 behind one C call; returns (best, last full_du_norm) or None when the problem is not
         of the supported kind (then the host loop runs)."""
@@ -193,7 +211,7 @@ class BoxDDP(torch.nn.Module):
                     x, Fm, fm = dynamics.rollout_linearize(x_init.detach(), u)
                     Cm, cm = cost.C, cost.c
                 else:
-                    x = get_traj(T, u, x_init.detach(), detached_dyn())
+                    x = self._nominal(T, u, x_init.detach(), detached_dyn())
                     Cm, cm, Fm, fm = models(x, u)
                 step = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu,
                                current_states=x, true_cost=detached_cost(), true_dynamics=detached_dyn(),

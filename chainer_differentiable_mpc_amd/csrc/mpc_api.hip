@@ -8,6 +8,7 @@
 #include "api_util.hpp"
 #include "costate_args.hpp"
 #include "box_ddp_kernels.hpp"
+#include "mpc_generic.hpp"
 #include "mpc_kernels.hpp"
 
 namespace dmpc {
@@ -64,6 +65,16 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a, hipStream_t str
   }
   DMPC_MPC_SHAPES(X)
 #undef X
+  // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
+  if (nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
+#define G(NU_)                                                                                                    \
+  case NU_:                                                                                                       \
+    hipLaunchKernelGGL((mpc_generic_backward_kernel<NU_>), dim3(a.B), dim3(64), mpc_generic_back_lds_bytes<NU_>(nx), \
+                       stream, a, nx);                                                                            \
+    return (int)hipGetLastError();
+    switch (nu) { G(1) G(2) G(3) G(4) G(5) G(6) G(7) G(8) }
+#undef G
+  }
   return DMPC_E_UNSUPPORTED;
 }
 
@@ -87,6 +98,11 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a, hipStream_t strea
   }
   DMPC_MPC_SHAPES(X)
 #undef X
+  if (a.dyn_kind == 0 && nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
+    hipLaunchKernelGGL(mpc_generic_forward_kernel, dim3(a.B), dim3(64), mpc_generic_fwd_lds_bytes(nx, nu), stream, a,
+                       nx, nu);
+    return (int)hipGetLastError();
+  }
   return DMPC_E_UNSUPPORTED;
 }
 
@@ -276,6 +292,14 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
                 max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info};
   return launch_mpc_fwd(nx, nu, fa, stream);
+}
+
+int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const float *u, const float *F,
+                     const float *f, float *x_out, dmpc_stream_t stream_) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0 || !x_init || !u || !x_out || (T > 1 && !F)) return DMPC_E_BADARG;
+  hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), T, B, nx,
+                     nu, x_init, u, F, f, x_out, nullptr);
+  return (int)hipGetLastError();
 }
 
 size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu) {

@@ -158,6 +158,12 @@ int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const flo
                                     float dt, float max_torque, float *x_out, float *F_out, float *f_out,
                                     dmpc_stream_t stream);
 
+/* Nominal rollout under a LinDx (util.py:239-277 get_traj): x_0 = x_init, x_{t+1} = F_t [x_t; u_t] + f_t (f may be
+ * NULL), with the summation order of the MPC step's own line-search rollout - so that a trajectory re-rolled from
+ * unchanged controls reproduces the nominal one bit for bit and the box-DDP stop test sees du = 0 at a fixed point. */
+int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const float *u, const float *F,
+                     const float *f, float *x_out, dmpc_stream_t stream);
+
 /* The outer box-DDP loop (BoxDDP.forward, mpc/box_ddp.py:93-230) for a QuadCost and either a LinDx (dyn_kind 0:
  * F [T-1|T,B,nx,ns], f [T-1,B,nx] or NULL) or the built-in pendulum (dyn_kind 1: F = f = NULL, dyn_params = HOST
  * array {g, m, l, dt, max_torque}, nx = 3, nu = 1), as ONE chain of launches: per iteration the nominal rollout

@@ -261,7 +261,7 @@ def test_device_loop_matches_host_loop_pendulum(max_iter):
     assert_close(dev_[2], host[2], 1e-5, "costs")
 
 
-@pytest.mark.parametrize("shape", [(16, 8, 3, 2, 0.3), (64, 12, 8, 2, 0.5), (5, 6, 4, 2, 10.0)])
+@pytest.mark.parametrize("shape", [(16, 8, 3, 2, 0.3), (64, 12, 8, 2, 0.5), (5, 6, 4, 2, 10.0), (12, 6, 5, 3, 0.5)])
 def test_device_loop_matches_host_loop_lindx(shape):
     # the nominal rollout is a kernel here and torch ops there: rounding differs, the iteration amplifies it
     B, T, nx, nu, bound = shape

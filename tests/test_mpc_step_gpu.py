@@ -197,3 +197,41 @@ def test_headline_shape_properties():
         (torch.cat((x0, u0), 2) * d["c"]).sum(dim=(0, 2))
     assert bool((step.for_out.costs <= old * (1 + 1e-5) + 1e-3).all())        # the line search never accepts a worse cost
     assert float((u == lo).float().mean() + (u == hi).float().mean()) > 0.05  # the box is active somewhere
+
+
+@pytest.mark.parametrize("shape", [(6, 7, 5, 2, 0.25), (5, 6, 4, 3, 0.375), (4, 8, 7, 1, 0.5), (3, 5, 10, 5, 0.25),
+                                   (3, 6, 32, 8, 0.25), (4, 6, 20, 6, 0.375)])   # bounds exact in float32
+def test_shapes_without_a_specialisation_against_the_oracle(shape):
+    """runtime-dimension MPC kernels (mpc_generic.hpp): forward (backward_rec with PNQP + line search) and the
+    analytic backward for shapes outside the register-resident list, against the per-trajectory oracle"""
+    B, T, nx, nu, bound = shape
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7, with_f=True)
+    lo, hi = -bound * np.ones((T, B, nu)), bound * np.ones((T, B, nu))
+    u0 = np.zeros((T, B, nu))
+    xs = [p["x_init"]]
+    for t in range(T - 1):
+        xs.append(np.einsum("bij,bj->bi", p["F"][t], np.concatenate((xs[t], u0[t]), axis=1)) + p["f"][t])
+    x0 = np.stack(xs).astype(np.float32).astype(np.float64)
+    xr, ur, bo, fo, Ksr, ksr = ompc.mpc_forward(p["C"], p["c"], p["F"], p["f"], u0, x0, lo, hi,
+                                                ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"]), 0.2, 5,
+                                                T, nx, nu, need_expand=True, batch_coupled=False)
+    step = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(p["C"]), dev(p["c"])),
+                   LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, u = step.forward((dev(x0[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    assert_close(npy(step.ks), ksr, TOL, "ks")
+    assert_close(npy(step.Ks), Ksr, TOL, "Ks")
+    assert_close(npy(u), ur, TOL, "u")
+    assert_close(npy(x), xr, TOL, "x")
+    assert_close(npy(step.for_out.costs), fo.costs, TOL, "costs")
+    active = (npy(u) == lo) | (npy(u) == hi)
+    np.testing.assert_array_equal(active, (np.abs(ur - lo) <= 1e-8) | (np.abs(ur - hi) <= 1e-8))
+    assert active.any()
+    gx, gu = np.ones((T, B, nx)), np.ones((T, B, nu))
+    ref = ompc.mpc_backward(x0[0], p["C"], p["c"], p["F"], None, xr, ur, lo, hi, gx, gu, T, nx, nu)
+    out = step.backward((0, 1, 2, 3, 4), (dev(gx), dev(gu)))
+    for got, want, key in zip(out, ref, ("d_x_init", "dC", "dc", "dF", "df")):
+        if want is None:
+            continue
+        assert_close(npy(got), want, 5e-4, key)
