@@ -58,6 +58,8 @@ class BoxDDP(torch.nn.Module):
         self.device_loop = device_loop
         self.status = None
         self.info = None            # MPC step flags of the device loop, per trajectory
+        self._bounds_on = None
+        self._best_norm_max = None
         self.n_iter = 0
         if isinstance(u_lower, (int, float)):       # scalar bounds are broadcast to [T,B,nu] (:68-90)
             u_lower = torch.full((T, n_batch, n_ctrl), float(u_lower))
@@ -140,8 +142,10 @@ class BoxDDP(torch.nn.Module):
             return None
         _lib.check(rc, "dmpc_box_ddp")
         n_bad = ((info & _lib.INFO_NONFINITE) != 0).sum()
-        summary = torch.cat((state[:4], bad_in.to(torch.int32), n_bad.to(torch.int32)[None]))
+        summary = torch.cat((state[:4], bad_in.to(torch.int32), n_bad.to(torch.int32)[None],
+                             (bn.max() > self.eps).to(torch.int32)[None]))
         st = summary.cpu().tolist()               # the one synchronisation of the loop
+        self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
         assert not st[4]
         assert not st[5], " lower is larger than upper"
         if st[6]:                                 # the reference asserts on NaN inside every MPC step
@@ -161,7 +165,10 @@ class BoxDDP(torch.nn.Module):
         T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
         assert list(x_init.shape) == [B, nx], " x_init dim mismatch"
         dev, dt = x_init.device, x_init.dtype
-        lo, hi = self.u_lower.to(device=dev, dtype=dt), self.u_upper.to(device=dev, dtype=dt)
+        key = (dev, dt)
+        if self._bounds_on is None or self._bounds_on[0] != key:   # the bounds travel to the device once, not per call
+            self._bounds_on = (key, self.u_lower.to(device=dev, dtype=dt), self.u_upper.to(device=dev, dtype=dt))
+        lo, hi = self._bounds_on[1], self._bounds_on[2]
         if self.u_init is None:
             u = torch.zeros((T, B, nu), dtype=dt, device=dev)
         else:
@@ -200,6 +207,7 @@ class BoxDDP(torch.nn.Module):
         n_not_improved = 0
         for_out = None
         last_norm = None
+        self._best_norm_max = None
         if self.device_loop and not self.verbose and not self.ilqr_verbose and isinstance(cost, QuadCost):
             looped = self._device_loop(x_init, cost, dynamics, u, lo, hi)
             if looped is not None:
@@ -264,7 +272,9 @@ class BoxDDP(torch.nn.Module):
         needs_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (Cm, cm, Fm, fm, x_init))
         if needs_graph:
             x, u = node.apply((x[0].detach(), Cm, cm, Fm, fm))
-        if self.detach_unconverged and float(best['full_du_norm'].max()) > self.eps:      # :263-289
+        unconverged = self._best_norm_max if last_norm is not None and self._best_norm_max is not None \
+            else (float(best['full_du_norm'].max()) > self.eps)
+        if self.detach_unconverged and unconverged:                                        # :263-289
             if self.verbose:
                 print("LQR Warning: All examples did not converge to a fixed point.")
                 print("Detaching and *not* backpropping through the bad examples.")

@@ -207,8 +207,7 @@ __device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, f
   const float th = atan2f(s, c);
   wn = w + p.dt * (p.kg * s + p.ku * uc);
   nth = th + wn * p.dt;
-  cn = cosf(nth);
-  sn = sinf(nth);
+  sincosf(nth, &sn, &cn);  // one argument reduction for both
 }
 
 struct MpcFwdArgs {
