@@ -181,7 +181,9 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 
 // The shapes with a register-resident specialisation.  Anything else (ns + 1 <= 64) goes to the
 // runtime-dimension LDS kernel in lqr_generic.hpp.
-#ifdef DMPC_EXPERIMENT_ONLY_8_2  // quick single-shape builds for kernel experiments (scripts/variants.sh)
+#if defined(DMPC_EXPERIMENT_ONLY_32_8)  // quick single-shape builds for kernel experiments (scripts/*variants.sh)
+#define DMPC_LQR_SHAPES(X) X(32, 8, 64)
+#elif defined(DMPC_EXPERIMENT_ONLY_8_2)
 #define DMPC_LQR_SHAPES(X) X(8, 2, 16)
 #else
 #define DMPC_LQR_SHAPES(X) \
