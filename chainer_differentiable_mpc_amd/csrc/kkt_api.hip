@@ -4,9 +4,11 @@
 //   (2) lambda, d_lambda backward sweeps + outer products                             (:85-104, :115-134)
 // Step (1) is the fused solve kernel of lqr_api.hip, step (2) is costate_kernel.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
+#include "costate_dma_kernel.hpp"
 #include "costate_kernels.hpp"
 
 namespace dmpc {
@@ -34,10 +36,25 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
 #endif
 
+static bool costate_dma_disabled() {  // DMPC_NO_COSTATE_DMA=1: register-prefetch co-state kernel (A/B timing, debugging)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_COSTATE_DMA"); return e && e[0] == '1'; }();
+  return off;
+}
+constexpr int kCostateDmaDepth = 4;
+
 int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
 #define X(NX_, NU_, L_)                                                                                     \
   if (nx == NX_ && nu == NU_) {                                                                             \
     constexpr int GPB = 256 / L_;                                                                           \
+    if constexpr (L_ == 16) { /* inputs staged through an LDS-DMA ring (costate_dma_kernel.hpp) */          \
+      if (a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled()) {                                                \
+        using Lay = CostateDmaLayout<NX_, NU_, kCostateDmaDepth>;                                           \
+        const int waves = (a.B + 3) / 4;                                                                    \
+        hipLaunchKernelGGL((costate_dma_kernel<NX_, NU_, kCostateDmaDepth>), dim3((waves + 3) / 4), dim3(256), \
+                           Lay::lds_bytes(), stream, a);                                                    \
+        return (int)hipGetLastError();                                                                      \
+      }                                                                                                     \
+    }                                                                                                       \
     hipLaunchKernelGGL((costate_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, a); \
     return (int)hipGetLastError();                                                                          \
   }
