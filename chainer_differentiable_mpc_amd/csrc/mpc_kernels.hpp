@@ -262,8 +262,9 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   // kernel above).  A pass that is no longer needed by this trajectory still runs masked while wave-mates search.
   struct Slot {
     float xt, kv[NU], uc[NU], lb[NU], ub[NU];
-    float Crow[NS], ci, Frow[NS], fi;
+    float Crow[NS + 1], ci, Frow[NS + 1], fi;  // (+1: the fused DPP blocks take rows in the [row | affine] shape)
   };
+  using Blk = RiccatiBlocks<NX, NU, L>;
   const bool lin = a.dyn_kind == 0;
   auto load = [&](int t, Slot &sl) {
     t = t < T ? t : T - 1;  // prefetch past the horizon: the last step again (never consumed)
@@ -277,18 +278,21 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       sl.lb[m] = a.lower[tb * NU + m];
       sl.ub[m] = a.upper[tb * NU + m];
     }
-    load_contig<NS>(a.C + (tb * NS + lane_t) * NS, sl.Crow);
+    load_contig<NS>(a.C + (tb * NS + lane_t) * NS, reinterpret_cast<float (&)[NS]>(sl.Crow));
+    sl.Crow[NS] = 0.f;
+    sl.Frow[NS] = 0.f;
     sl.ci = a.c[tb * NS + lane_t];
     if (lin) {
       const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);  // there is no F_{T-1}
       const size_t tbF = (size_t)tF * B + b;
-      load_contig<NS>(a.F + (tbF * NX + lane_x) * NS, sl.Frow);
+      load_contig<NS>(a.F + (tbF * NX + lane_x) * NS, reinterpret_cast<float (&)[NS]>(sl.Frow));
       sl.fi = has_f ? a.f[tbF * NX + lane_x] : 0.f;
     }
   };
   auto slot_cost = [&](const Slot &sl, float tau) {  // 1/2 tau'C tau + c'tau of one timestep          util.py:162-198
     float qi = 0.f;
-    static_for<0, NS>([&](auto j) { qi = fmaf(sl.Crow[j.value], G::template bcast<j.value>(tau), qi); });
+    Blk::dot_x(qi, tau, sl.Crow);  // broadcast-FMAs fused into one DPP instruction each
+    Blk::dot_u(qi, tau, sl.Crow);
     return group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f);
   };
 
@@ -340,7 +344,8 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
         }
       } else if (t < T - 1) {  // new_x_{t+1} = F_t [new_x;new_u] + f_t under the TRUE dynamics   :229-236
         float acc = sl.fi;
-        static_for<0, NS>([&](auto j) { acc = fmaf(sl.Frow[j.value], G::template bcast<j.value>(tau), acc); });
+        Blk::dot_x(acc, tau, sl.Frow);
+        Blk::dot_u(acc, tau, sl.Frow);
         xh = is_x ? acc : 0.f;
       }
     };
