@@ -21,5 +21,6 @@ from .box_ddp import BoxDDP  # noqa: F401
 from .mpc_net import MpcNet_cost, MpcNet_dx  # noqa: F401
 from .pendulum import PendulumDx  # noqa: F401
 from .il_env import IL_Env, Pendulum_Net_cost_logit  # noqa: F401
+from . import make_dataset  # noqa: F401
 
 __version__ = "0.1.0"

@@ -24,6 +24,7 @@ _c_sz = ctypes.c_size_t
 # name -> (restype, argtypes); mirrors include/dmpc.h one to one
 SIGNATURES = {
     "dmpc_version": (_c_i, []),
+    "dmpc_source_hash": (ctypes.c_char_p, []),
     "dmpc_lqr_kernel_family": (_c_i, [_c_i, _c_i]),
     "dmpc_lqr_solve_path": (_c_i, [_c_i] * 4),
     "dmpc_lqr_workspace_bytes": (_c_sz, [_c_i] * 4),

@@ -5,10 +5,18 @@
 
 hipcc cross-compiles without a GPU.  The .so lands next to the Python package so that it travels
 to the GPU box with the repo snapshot and shows up as loaded native code.
+
+Staleness is decided by CONTENT, not by mtimes: every object carries the SHA-256 of what it was
+compiled from (its .hip, every header, the flags), and the library carries the hash of the whole
+source set twice - in `libdmpc_hip.so.srchash` next to it and inside the code (`dmpc_source_hash()`),
+so a library that does not belong to the sources in the tree is detected (`is_current()`), whatever
+the file times say.  Both generated headers (`lqr_asm_gen.hpp`, `dpp_blocks_gen.hpp`) are written here
+from their generators and are not kept in git.
 """
 import argparse
 import concurrent.futures
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -18,10 +26,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libdmpc_hip.so")
+STAMP = OUT + ".srchash"
 OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include")]
+GENERATED = {"lqr_asm_gen.hpp": "gen_lqr_asm.py", "dpp_blocks_gen.hpp": "gen_dpp_blocks.py"}
+HASH_TU = "lu_api.hip"      # the translation unit that defines dmpc_source_hash()
 
 
 def hipcc():
@@ -31,49 +42,84 @@ def hipcc():
     return exe
 
 
-def newer(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
-def compile_one(src, force):
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-    deps = [src] + glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h")) \
-        + [os.path.abspath(__file__)]
-    if force or newer(obj, deps):
-        cmd = [hipcc()] + FLAGS + ["-c", src, "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-    return obj
+def hand_written_sources():
+    """everything a human edits: .hip, hand-written headers, the generators, the public header, this script"""
+    srcs = glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(ROOT, "include", "*.h")) \
+        + [p for p in glob.glob(os.path.join(HERE, "*.hpp")) if os.path.basename(p) not in GENERATED] \
+        + [os.path.join(HERE, g) for g in GENERATED.values()] + [os.path.abspath(__file__)]
+    return srcs
+
+
+def source_hash():
+    return _sha(hand_written_sources(), " ".join(FLAGS))[:32]
+
+
+def is_current():
+    """the library in the tree was built from the sources in the tree"""
+    if not (os.path.exists(OUT) and os.path.exists(STAMP)):
+        return False
+    return open(STAMP).read().strip() == source_hash()
 
 
 def generate(force=False):
-    """lqr_asm_gen.hpp (3.8 MB of generated instruction streams) is not kept in git: gen_lqr_asm.py writes it here"""
-    gen = os.path.join(HERE, "gen_lqr_asm.py")
-    out = os.path.join(HERE, "lqr_asm_gen.hpp")
-    if force or newer(out, [gen]):
-        r = subprocess.run([sys.executable, gen], capture_output=True, text=True)
+    for out_name, gen_name in GENERATED.items():
+        gen = os.path.join(HERE, gen_name)
+        out = os.path.join(HERE, out_name)
+        stamp = os.path.join(OBJ_DIR, out_name + ".genhash")
+        want = _sha([gen])
+        if force or not os.path.exists(out) or not os.path.exists(stamp) or open(stamp).read() != want:
+            r = subprocess.run([sys.executable, gen], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("%s failed:\n%s\n%s" % (gen_name, r.stdout, r.stderr))
+            open(stamp, "w").write(want)
+
+
+def compile_one(src, force, src_hash):
+    base = os.path.basename(src)
+    obj = os.path.join(OBJ_DIR, base[:-4] + ".o")
+    stamp = obj + ".hash"
+    deps = [src] + glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    flags = list(FLAGS)
+    if base == HASH_TU:
+        flags.append('-DDMPC_SOURCE_HASH="%s"' % src_hash)
+    want = _sha(deps, " ".join(flags))
+    if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != want:
+        cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("gen_lqr_asm.py failed:\n%s\n%s" % (r.stdout, r.stderr))
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        open(stamp, "w").write(want)
+        return obj, True
+    return obj, False
 
 
 def build(force=False, jobs=None, verbose=True):
     os.makedirs(OBJ_DIR, exist_ok=True)
     generate(force)
+    src_hash = source_hash()
     srcs = sorted(glob.glob(os.path.join(HERE, "*.hip")))
     jobs = jobs or min(len(srcs), max(1, (os.cpu_count() or 2) - 1))
     with concurrent.futures.ThreadPoolExecutor(jobs) as ex:
-        objs = list(ex.map(lambda s: compile_one(s, force), srcs))
-    if force or newer(OUT, objs):
+        res = list(ex.map(lambda s: compile_one(s, force, src_hash), srcs))
+    objs = [o for o, _ in res]
+    rebuilt = sum(1 for _, r in res if r)
+    if force or rebuilt or not is_current():
         cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        open(STAMP, "w").write(src_hash)
     if verbose:
-        print("built", OUT, "(%d translation units)" % len(srcs))
+        print("built", OUT, "(%d translation units, %d recompiled, source hash %s)" % (len(srcs), rebuilt, src_hash))
     return OUT
 
 

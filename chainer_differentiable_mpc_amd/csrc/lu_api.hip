@@ -129,6 +129,13 @@ using namespace dmpc;
 
 extern "C" {
 
+#ifndef DMPC_SOURCE_HASH
+#define DMPC_SOURCE_HASH "unknown"
+#endif
+// SHA-256 prefix of the source set this library was compiled from (csrc/build.py writes it)
+const char *dmpc_source_hash(void) { return DMPC_SOURCE_HASH; }
+
+
 int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, int32_t *info,
                          dmpc_stream_t stream_) {
   if (B <= 0 || n <= 0 || !A || !LU || !piv) return DMPC_E_BADARG;

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(cons
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
 // (env_dx/pendulum.py:84-98, simple model), F_t = d x_{t+1} / d [x_t; u_t], f_t = x_{t+1} - F_t [x_t; u_t] - what
 // BoxDDP obtains from get_traj (util.py:201-277) followed by linearize_dynamics (mpc/approximate.py:77-119, there
-// through chainer.grad).  The torque clamp has derivative 1 strictly inside (-max_torque, max_torque), else 0.
+// through chainer.grad).  The torque clamp has derivative 1 on the CLOSED interval [-max_torque, max_torque] (Chainer's F.clip backward, torch.clamp autograd), else 0: box-DDP's bounds equal the torque limit, so saturated controls sit exactly on it.
 struct PendulumArgs {
   int T, B;
   const float *x_init, *u;   // [B,3], [T,B,1]
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const Pe
       }
     }
     if (t == a.T - 1) break;
-    const float inside = (ur > -a.max_torque && ur < a.max_torque) ? 1.f : 0.f;
+    const float inside = (ur >= -a.max_torque && ur <= a.max_torque) ? 1.f : 0.f;
     const float r2 = c * c + s * s;
     float cn, sn, nw, nth;
     pendulum_next(pm, c, s, w, ur, cn, sn, nw, nth);

@@ -48,6 +48,10 @@ class _DiffLqrFn(torch.autograd.Function):
     def forward(ctx, x_init, C, c, F, f, node):
         x, u = node._forward_impl(x_init, C, c, F, f)
         ctx.node = node
+        # per-call state lives on the autograd ctx: one DiffLqr (e.g. LqrNet.lqr_layer) may run forward several times
+        # before any backward (summed minibatches, a validation pass in between); node._retained only serves the
+        # reference-style explicit forward()/backward() pair
+        ctx.retained = node._retained
         ctx.had_f = f is not None
         ctx.in_meta = [(t.dtype, t.device, tuple(t.shape)) if t is not None else None for t in (x_init, C, c, F, f)]
         return x, u
@@ -55,7 +59,7 @@ class _DiffLqrFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_x, grad_u):
         node = ctx.node
-        grads = node.backward((0, 1, 2, 3, 4), (grad_x, grad_u))
+        grads = node.backward((0, 1, 2, 3, 4), (grad_x, grad_u), retained=ctx.retained)
         out = []
         for g, meta in zip(grads, ctx.in_meta):
             if meta is None or g is None:
@@ -123,9 +127,9 @@ class DiffLqr:
 
     __call__ = apply
 
-    def backward(self, target_input_indexes, grad_outputs):
+    def backward(self, target_input_indexes, grad_outputs, retained=None):
         """-> (d_x_init, dC, dc, dF, df) for upstream (grad_x, grad_u)  (differentiable_lqr.py:78-142)"""
-        r = self._retained
+        r = self._retained if retained is None else retained
         assert r is not None, "backward() before forward()"
         T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
         grad_x, grad_u = grad_outputs

@@ -37,14 +37,23 @@ def shard_problem(x_init, C, c, F, f, rank=None, world=None):
 
 
 def all_gather_batch(local, n_batch_total=None, batch_dim=1, group=None):
-    """all-gather along the batch axis; shards may be ragged (balanced split of shard_bounds)"""
+    """all-gather along the batch axis; shards may be ragged.  With `n_batch_total` the shard sizes are those of
+    `shard_bounds` (no extra exchange); without it the local sizes are all-gathered first, so ragged shards can
+    never reach the equal-size collective by accident."""
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    sizes = [shard_bounds(n_batch_total, r, world)[1] - shard_bounds(n_batch_total, r, world)[0]
-             for r in range(world)] if n_batch_total is not None else None
+    if n_batch_total is not None:
+        sizes = [shard_bounds(n_batch_total, r, world)[1] - shard_bounds(n_batch_total, r, world)[0]
+                 for r in range(world)]
+        assert local.shape[batch_dim] == sizes[dist.get_rank(group)], "local shard does not match shard_bounds"
+    else:
+        mine = torch.tensor([local.shape[batch_dim]], dtype=torch.int64, device=local.device)
+        every = torch.empty((world,), dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(every, mine, group=group)
+        sizes = [int(v) for v in every.cpu().tolist()]
     moved = local.movedim(batch_dim, 0).contiguous()
-    if sizes is None or len(set(sizes)) == 1:
+    if len(set(sizes)) == 1:
         out = torch.empty((world * moved.shape[0],) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
         dist.all_gather_into_tensor(out, moved, group=group)
     else:   # ragged split: pad every shard to the largest, gather, drop the padding

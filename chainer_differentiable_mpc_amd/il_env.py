@@ -23,6 +23,33 @@ class IL_Env:
         self.device, self.dtype, self.quiet = torch.device(device), dtype, quiet
         self.train_data = self.val_data = self.test_data = None
 
+    # the pickle of env_dx/make_dataset.py holds numpy arrays; keep that format (and no device handles) on disk
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in ("train_data", "val_data", "test_data"):
+            if isinstance(st[k], torch.Tensor):
+                st[k] = st[k].detach().cpu().numpy().astype(np.float64)
+        st["device"] = str(st["device"])
+        st["dtype"] = str(st["dtype"]).replace("torch.", "")
+        return st
+
+    def __setstate__(self, st):
+        st = dict(st)
+        st["dtype"] = getattr(torch, st["dtype"])
+        st["device"] = torch.device("cpu")          # data stays on the host until .to(device)
+        for k in ("train_data", "val_data", "test_data"):
+            if st[k] is not None:
+                st[k] = torch.as_tensor(st[k], dtype=st["dtype"])
+        self.__dict__.update(st)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        for k in ("train_data", "val_data", "test_data"):
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, v.to(self.device))
+        return self
+
     @staticmethod
     def sample_xinit(n_batch=1):
         """(cos th, sin th, dth), th ~ U(-pi/2, pi/2), dth ~ U(-1, 1): two successive numpy draws (il_env.py:55-69)"""

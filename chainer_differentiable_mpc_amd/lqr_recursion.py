@@ -136,8 +136,12 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    """grow-only per-device scratch (the C library allocates nothing itself)"""
-    key = (device.type, device.index)
+    """grow-only scratch per (device, stream) - the C library allocates nothing itself.  Calls enqueued on one stream
+    are ordered, so they may share a buffer; calls on different streams get different buffers.  A buffer that is
+    replaced by a larger one goes back to torch's caching allocator, which keeps it tied to the stream it was
+    allocated on (the same one), so kernels still in flight on it are safe."""
+    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    key = (device.type, device.index, stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)

@@ -50,12 +50,13 @@ class _MPCstepFn(torch.autograd.Function):
     def forward(ctx, x_init, C, c, F, f, node):
         x, u = node._forward_impl(x_init, C, c, F, f)
         ctx.node = node
+        ctx.retained = node._retained       # per-call state (a node object may be applied more than once)
         ctx.in_meta = [(t.dtype, t.device, tuple(t.shape)) if t is not None else None for t in (x_init, C, c, F, f)]
         return x, u
 
     @staticmethod
     def backward(ctx, dl_dx, dl_du):
-        grads = ctx.node.backward((0, 1, 2, 3, 4), (dl_dx, dl_du))
+        grads = ctx.node.backward((0, 1, 2, 3, 4), (dl_dx, dl_du), retained=ctx.retained)
         out = []
         for g, meta in zip(grads, ctx.in_meta):
             if meta is None or g is None:
@@ -335,9 +336,9 @@ class MPCstep:
     __call__ = apply
 
     # ------------------------------------------------------------------ E5
-    def backward(self, target_input_indexes, grad_outputs):
+    def backward(self, target_input_indexes, grad_outputs, retained=None):
         """-> (dx_init, dC, dc, dF, df|None)   mpc_step.py:330-460"""
-        r = self._retained
+        r = self._retained if retained is None else retained
         assert r is not None, "backward() before forward()"
         lib = _lib.load()
         T, B, nx, nu, ns = self.T, self.n_batch, self.n_state, self.n_ctrl, self.n_sc

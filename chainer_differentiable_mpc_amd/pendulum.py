@@ -62,7 +62,7 @@ class PendulumDx(torch.nn.Module):
             xt, ut = xs[t], u[t]
             c, s, w = xt[:, 0], xt[:, 1], xt[:, 2]
             uc = torch.clamp(ut[:, 0], -self.max_torque, self.max_torque)
-            inside = ((ut[:, 0] > -self.max_torque) & (ut[:, 0] < self.max_torque)).to(xt.dtype)
+            inside = ((ut[:, 0] >= -self.max_torque) & (ut[:, 0] <= self.max_torque)).to(xt.dtype)   # closed, like F.clip's backward
             r2 = c * c + s * s
             th = torch.atan2(s, c)
             nw = w + dt * (3. * g / (2. * l) * s + 3. * uc / (m * l ** 2))

@@ -41,11 +41,13 @@ def make_lqr_problem(n_batch, T, n_state, n_ctrl, seed=0, with_f=True,
     return out
 
 
-def make_box_qp(n_batch, n, seed=0, bound=0.5, fp32_representable=True):
-    """Random strictly convex box QPs with a mix of active and inactive bounds."""
+def make_box_qp(n_batch, n, seed=0, bound=0.5, fp32_representable=True, reg=None):
+    """Random strictly convex box QPs with a mix of active and inactive bounds.  H = (L L' + reg I) / n with
+    reg = n by default (well conditioned); a small `reg` with wide bounds gives QPs whose projected-Newton steps
+    fail the Armijo test - the cases where the reference's batch-global termination makes rows fork."""
     rng = np.random.RandomState(seed)
     L = rng.randn(n_batch, n, n)
-    H = (np.matmul(L, np.transpose(L, (0, 2, 1))) + n * np.eye(n)) / n
+    H = (np.matmul(L, np.transpose(L, (0, 2, 1))) + (n if reg is None else reg) * np.eye(n)) / n
     q = 2.0 * rng.randn(n_batch, n)
     lower = -bound * (0.2 + rng.rand(n_batch, n))
     upper = bound * (0.2 + rng.rand(n_batch, n))

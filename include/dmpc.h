@@ -41,6 +41,9 @@ typedef void *dmpc_stream_t; /* hipStream_t */
 
 int dmpc_version(void);
 
+/* Hash of the source set the library was built from (csrc/build.py); lets a loader refuse a stale binary. */
+const char *dmpc_source_hash(void);
+
 /* Which kernel family a shape dispatches to: 1 = DPP row kernel (16 lanes / trajectory),
  * 2 = wave kernel (64 lanes / trajectory), 3 = generic LDS kernel, <0 unsupported. */
 int dmpc_lqr_kernel_family(int nx, int nu);

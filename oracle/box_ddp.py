@@ -30,7 +30,7 @@ def get_traj(T, u, x_init, dynamics):
 def box_ddp(x_init, cost, dynamics, T, u_lower, u_upper, n_state, n_ctrl, u_init=None, eps=1e-5,
             not_improved_lim=5, line_search_decay=0.2, max_line_search_iter=10, best_cost_eps=1e-4, max_iter=10,
             linearize=None, batch_coupled=True):
-    """-> (x, u, costs, status, n_iter, last_full_du_norm)"""
+    """-> (x, u, costs, status, n_iter, last_full_du_norm, best_full_du_norm)"""
     B = x_init.shape[0]
     nx, nu = n_state, n_ctrl
     if np.isscalar(u_lower):
@@ -73,7 +73,7 @@ def box_ddp(x_init, cost, dynamics, T, u_lower, u_upper, n_state, n_ctrl, u_init
             break
         if i == max_iter - 1:
             status = "Not Converged"
-    return best["x"], best["u"], best["costs"], status, n_iter, for_out.full_du_norm
+    return best["x"], best["u"], best["costs"], status, n_iter, for_out.full_du_norm, best["full_du_norm"]
 
 
 # ---- pendulum (env_dx/pendulum.py:65-102, simple model: params g, m, l = 10, 1, 1; dt = 0.05; |u| <= 2)
@@ -94,7 +94,9 @@ def pendulum_linearize(x, u, g=10.0, m=1.0, l=1.0, dt=0.05, max_torque=2.0):
     for t in range(T - 1):
         xt, ut = xs[t], u[t]
         c, s, w = xt[:, 0], xt[:, 1], xt[:, 2]
-        inside = ((ut[:, 0] > -max_torque) & (ut[:, 0] < max_torque)).astype(xt.dtype)
+        # d clip(u) / du = 1 on the CLOSED interval (Chainer's F.clip backward, torch.clamp autograd): the box-DDP
+        # bounds equal the torque limit, so saturated controls sit exactly on it
+        inside = ((ut[:, 0] >= -max_torque) & (ut[:, 0] <= max_torque)).astype(xt.dtype)
         r2 = c * c + s * s
         new_x = pendulum_step(xt, ut, g, m, l, dt, max_torque)
         nth = np.arctan2(s, c) + new_x[:, 2] * dt

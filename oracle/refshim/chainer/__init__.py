@@ -1,4 +1,4 @@
-"""Forward-only numpy stand-in for the `chainer` package.
+"""numpy stand-in for the `chainer` package (array wrapper + a small reverse-mode tape).
 
 TEST INFRASTRUCTURE ONLY.  Chainer is not installable in the build container (no
 network), yet every hot-path module of the reference imports it at module scope.
@@ -9,7 +9,10 @@ execute the *unmodified* reference sources from /root/reference and record golde
 input/output vectors.  It is never imported by the product package, by bench.py's
 GPU path, or on the GPU box (the reference does not travel there).
 
-Not provided: autograd (`chainer.grad`), optimizers, iterators, serializers.
+`chainer.grad` / `Variable.backward` are a small tape over numpy with exact analytic derivatives (variable.py,
+functions.py) - enough for mpc/approximate.py (`linearize_dynamics`, `approximate_cost` with double backprop),
+BoxDDP around the non-linear PendulumDx and the imitation step's gradient through `MPCstep.backward`.
+Not provided: optimizers, iterators, serializers.
 """
 import contextlib
 
@@ -19,7 +22,10 @@ from . import backend  # noqa: F401
 from . import function_node  # noqa: F401
 from . import functions  # noqa: F401
 from . import utils  # noqa: F401
-from .variable import Parameter, Variable, as_variable  # noqa: F401
+from . import variable as _variable
+from .variable import Parameter, Variable, as_variable, grad  # noqa: F401
+
+_variable._install_operators()
 
 __version__ = "0.0-shim"
 
@@ -46,7 +52,7 @@ class Link:
 
     def cleargrads(self):
         for p in self.params():
-            p.grad = None
+            p.grad_var = None
 
 
 Chain = Link
@@ -54,8 +60,9 @@ Chain = Link
 
 @contextlib.contextmanager
 def no_backprop_mode():
-    yield
-
-
-def grad(*args, **kwargs):  # pragma: no cover - documented gap
-    raise NotImplementedError("the numpy stand-in has no autograd (chainer.grad)")
+    prev = _variable._state["record"]
+    _variable._state["record"] = False
+    try:
+        yield
+    finally:
+        _variable._state["record"] = prev

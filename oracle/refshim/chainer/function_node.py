@@ -1,5 +1,9 @@
-"""`chainer.function_node.FunctionNode` stand-in: apply = unwrap -> forward -> wrap."""
-from .variable import Variable, _raw
+"""`chainer.function_node.FunctionNode` stand-in: apply = unwrap -> forward -> wrap, recorded on the tape with
+the node's own hand-written `backward(target_input_indexes, grad_outputs)` as the vector-Jacobian product
+(that is how Chainer drives DiffLqr.backward / MPCstep.backward)."""
+import numpy as np
+
+from .variable import Variable, _raw, make_multi, recording
 
 
 class FunctionNode:
@@ -30,4 +34,19 @@ class FunctionNode:
             outs = (outs,)
         outs = tuple(_raw(o) for o in outs)
         self._outputs = outs
-        return tuple(Variable(o) for o in outs)
+        if not recording() or not any(isinstance(x, Variable) for x in inputs):
+            return tuple(Variable(o) for o in outs)
+        n_in = len(inputs)
+
+        def vjp(gys):
+            gys = tuple(Variable(np.zeros_like(o)) if g is None else g for g, o in zip(gys, outs))
+            gxs = self.backward(tuple(range(n_in)), gys)
+            res = []
+            for gx in gxs:
+                if gx is None or (isinstance(gx, Variable) and gx.array is None):
+                    res.append(None)
+                else:
+                    res.append(gx if isinstance(gx, Variable) else Variable(gx))
+            return res
+
+        return tuple(make_multi(outs, list(inputs), vjp))

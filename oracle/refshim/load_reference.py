@@ -55,13 +55,13 @@ def load():
         return _loaded
     if not available():
         raise RuntimeError("reference tree not found at %s" % REFERENCE_ROOT)
-    for p in (os.path.join(REFERENCE_ROOT, "mpc"), os.path.join(REFERENCE_ROOT, "lqr"),
-              REFERENCE_ROOT, _SHIM_DIR):
+    for p in (os.path.join(REFERENCE_ROOT, "env_dx"), os.path.join(REFERENCE_ROOT, "mpc"),
+              os.path.join(REFERENCE_ROOT, "lqr"), REFERENCE_ROOT, _SHIM_DIR):
         if p in sys.path:
             sys.path.remove(p)
         sys.path.insert(0, p)
     for name in ("chainer", "util", "lqr_recursion", "differentiable_lqr", "pnqp",
-                 "mpc_step", "active_constrained_lqr"):
+                 "mpc_step", "active_constrained_lqr", "box_ddp", "approximate", "pendulum", "il_env"):
         if name in sys.modules and not getattr(sys.modules[name], "__file__", "").startswith(
                 (REFERENCE_ROOT, _SHIM_DIR)):
             del sys.modules[name]
@@ -79,8 +79,17 @@ def load():
         ns.mpc_step = importlib.import_module("mpc_step")
         try:
             ns.box_ddp = importlib.import_module("box_ddp")
-        except Exception as e:  # needs approximate.py -> chainer.grad at call time only
-            ns.box_ddp = None
+            ns.approximate = importlib.import_module("approximate")
+        except Exception as e:
+            ns.box_ddp = ns.approximate = None
             ns.box_ddp_error = e
+        # env_dx/pendulum.py (PendulumDx forward model, true objective) and env_dx/il_env.py (sample_xinit, mpc):
+        # pendulum.py imports matplotlib at module scope (Agg backend, present in this image)
+        try:
+            ns.pendulum = importlib.import_module("pendulum")
+            ns.il_env = importlib.import_module("il_env")
+        except Exception as e:
+            ns.pendulum = ns.il_env = None
+            ns.env_dx_error = e
     _loaded = ns
     return ns

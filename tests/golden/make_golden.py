@@ -18,6 +18,13 @@ Files written:
   mpc_<B>_<T>_<nx>_<nu>_<exp|noexp>.npz rows E/F: MPCstep forward+backward, LQR_active
   boxddp_trace.npz                     BoxDDP + LinDx/QuadCost per-iteration trace
   anchors.npz                          reference outputs on the notebook problems
+  pendulum.npz                         env_dx/pendulum.py: PendulumDx.forward, get_true_obj; il_env.sample_xinit;
+                                       mpc/approximate.py linearize_dynamics around the pendulum (torques on/over the clamp)
+  approx_cost.npz                      mpc/approximate.py approximate_cost on a quadratic and a non-quadratic cost
+  pendulum_boxddp.npz                  BoxDDP around the non-linear PendulumDx (config 2 family): iterates after 1..4 steps
+  imitation_16.npz                     config 4 chain, small: Pendulum_Net_cost_logit -> IL_Env.mpc -> loss -> d logit, d p
+  imitation_step_1024.npz              config 4 at B=1024, T=20: one MPCstep from a common iterate + the no-op gradient node
+  pnqp_n8_b256.npz                     PNQP n=8, B=256: the batch whose rows fork under the batch-global termination
 """
 import io
 import os
@@ -268,6 +275,220 @@ def gen_anchors(ref, extra):
     print("wrote anchors.npz")
 
 
+def _f32(a):
+    return np.asarray(a).astype(np.float32).astype(np.float64)
+
+
+def gen_pendulum(ref):
+    V = ref.chainer.Variable
+    dx = ref.pendulum.PendulumDx()
+    rng = np.random.RandomState(11)
+    B = 96
+    th = rng.uniform(-np.pi, np.pi, B)
+    th[:4] = [np.pi, -np.pi, 0.0, np.pi / 2]
+    x = _f32(np.stack((np.cos(th), np.sin(th), rng.uniform(-3, 3, B)), axis=1))
+    u = _f32(rng.uniform(-3.0, 3.0, (B, 1)))
+    u[:8, 0] = [2.0, -2.0, 2.0, -2.0, 0.0, 2.5, -2.5, 1.9999999]
+    nxt = arr(dx(V(x), V(u)))
+    q, p = dx.get_true_obj()
+    np.random.seed(0)
+    xi128 = ref.il_env.IL_Env.sample_xinit(128)
+    np.random.seed(0)
+    xi1024 = ref.il_env.IL_Env.sample_xinit(1024)
+    # linearize_dynamics (mpc/approximate.py:77-119) along a trajectory with torques inside, ON and beyond the clamp
+    T, Bl = 20, 12
+    ul = _f32(rng.uniform(-2.6, 2.6, (T, Bl, 1)))
+    ul[:, 0, 0] = 2.0
+    ul[:, 1, 0] = -2.0
+    ul[::2, 2, 0] = 2.0
+    np.random.seed(3)
+    x0 = _f32(ref.il_env.IL_Env.sample_xinit(Bl))
+    xs = [x0]
+    for t in range(T - 1):
+        xs.append(arr(dx(V(xs[t]), V(ul[t]))))
+    xl = np.stack(xs)
+    Fl, fl = ref.approximate.linearize_dynamics(V(xl), V(ul), dx)
+    np.savez_compressed(os.path.join(HERE, "pendulum.npz"), x=x, u=u, next=nxt, q=q, p=p, params=arr(dx.params),
+                        dt=dx.dt, max_torque=dx.max_torque, lower=dx.lower, upper=dx.upper, mpc_eps=dx.mpc_eps,
+                        linesearch_decay=dx.linesearch_decay, max_linesearch_iter=dx.max_linesearch_iter,
+                        xinit128=xi128, xinit1024_head=xi1024[:64], xinit1024_sum=xi1024.sum(axis=0),
+                        lin_x=xl, lin_u=ul, lin_F=arr(Fl), lin_f=arr(fl))
+    print("wrote pendulum.npz; d next/d u at u=+-2:", arr(Fl)[0, :2, 2, 3])
+
+
+def gen_approx_cost(ref):
+    V = ref.chainer.Variable
+    F = ref.chainer.functions
+    rng = np.random.RandomState(21)
+    T, B, nx, nu = 4, 5, 3, 2
+    ns = nx + nu
+    x = _f32(rng.randn(T, B, nx))
+    u = _f32(rng.randn(T, B, nu))
+    L = rng.randn(ns, ns)
+    Cq = _f32(L @ L.T + ns * np.eye(ns))
+    cq = _f32(rng.randn(ns))
+    out = dict(x=x, u=u, Cq=Cq, cq=cq)
+
+    def quad(tau):          # 1/2 tau' C tau + c' tau, per batch row
+        return 0.5 * F.sum(F.matmul(tau, Cq) * tau, axis=1) + F.sum(tau * cq, axis=1)
+
+    def nonquad(tau):       # smooth, non-quadratic: sqrt(1 + |tau|^2) + sum sin(tau_i) tau_{i+1}
+        r = F.sqrt(1.0 + F.sum(tau ** 2, axis=1))
+        return r + F.sum(F.sin(tau[:, :-1]) * tau[:, 1:], axis=1)
+
+    for name, fn in (("quad", quad), ("nonquad", nonquad)):
+        H, g, cst = ref.approximate.approximate_cost(V(x), V(u), fn)
+        out[name + "_H"], out[name + "_g"], out[name + "_cost"] = arr(H), arr(g), arr(cst)
+    np.savez_compressed(os.path.join(HERE, "approx_cost.npz"), **out)
+    print("wrote approx_cost.npz")
+
+
+def _tiled_cost(ref, q, p, T, B):
+    Q = np.tile(np.diag(q), (T, B, 1, 1))
+    pv = np.tile(p, (T, B, 1))
+    return ref.util.QuadCost(ref.chainer.Variable(Q), ref.chainer.Variable(pv))
+
+
+def gen_pendulum_boxddp(ref):
+    """BoxDDP.forward (mpc/box_ddp.py:93-291) with the non-linear PendulumDx: linearize_dynamics by chainer.grad,
+    MPCstep with the pendulum as the true dynamics callable.  The returned iterate after k = 1..4 outer iterations."""
+    V = ref.chainer.Variable
+    dx = ref.pendulum.PendulumDx()
+    q, p = dx.get_true_obj()
+    B, T = 16, 20
+    np.random.seed(5)
+    x0 = _f32(ref.il_env.IL_Env.sample_xinit(B))
+    out = dict(B=B, T=T, x_init=x0, q=q, p=p)
+    for k in (1, 2, 3, 4):
+        ddp = ref.box_ddp.BoxDDP(T=T, u_lower=dx.lower, u_upper=dx.upper, n_batch=B, n_state=3, n_ctrl=1, u_init=None,
+                                 eps=dx.mpc_eps, max_iter=k, verbose=False, exit_unconverged=False,
+                                 detach_unconverged=True, line_search_decay=dx.linesearch_decay,
+                                 max_line_search_iter=dx.max_linesearch_iter, update_dynamics=True)
+        buf = io.StringIO()
+        with warnings.catch_warnings(), redirect_stdout(buf):
+            warnings.simplefilter("ignore")
+            x, u, costs = ddp((V(x0), _tiled_cost(ref, q, p, T, B), dx))
+        out["x_%d" % k], out["u_%d" % k], out["costs_%d" % k] = arr(x), arr(u), arr(costs)
+        out["stdout_%d" % k] = buf.getvalue()
+    np.savez_compressed(os.path.join(HERE, "pendulum_boxddp.npz"), **out)
+    print("wrote pendulum_boxddp.npz; mean cost after 1..4:", [float(out["costs_%d" % k].mean()) for k in (1, 2, 3, 4)])
+
+
+def gen_imitation(ref):
+    """config 4 (env_dx/il_exp.py:213-302 around env_dx/il_env.py:104-158 and pendulum_net.py:12-39)"""
+    import importlib
+    ch = ref.chainer
+    V, F = ch.Variable, ch.functions
+    pnet = importlib.import_module("pendulum_net")
+    # ---- (a) the whole chain at B=16: expert under the true cost, learner with a perturbed cost, 5 iLQR iterations
+    B, T = 16, 20
+    env = ref.il_env.IL_Env('pendulum', lqr_iter=5, mpc_T=T)
+    np.random.seed(7)
+    xinit = _f32(env.sample_xinit(B))
+    tq, tp = env.true_dx.get_true_obj()
+    buf = io.StringIO()
+    with warnings.catch_warnings(), redirect_stdout(buf):
+        warnings.simplefilter("ignore")
+        ex, eu = env.mpc(env.true_dx, xinit, tq, tp, update_dynamics=True)
+        net = pnet.Pendulum_Net_cost_logit(4)
+        net.learn_q_logit.array[:] = np.array([0.5, -0.25, -1.0, -3.0])
+        net.learn_p.array[:] = np.array([-0.75, 0.125, 0.0625, 0.0])
+        warm = np.zeros((B, T, 1))
+        nom_x, nom_u = net(xinit, env, warm)
+    us = np.transpose(arr(eu), (1, 0, 2))
+    nu_ = F.transpose(nom_u, axes=(1, 0, 2))
+    loss = F.mean((us - nu_) * (us - nu_))                          # il_exp.py:254-255
+    g_logit, g_p = ch.grad([loss], [net.learn_q_logit, net.learn_p])
+    np.savez_compressed(os.path.join(HERE, "imitation_16.npz"), B=B, T=T, lqr_iter=5, xinit=xinit, expert_x=arr(ex),
+                        expert_u=arr(eu), q_logit=net.learn_q_logit.array, learn_p=net.learn_p.array,
+                        nom_x=arr(nom_x), nom_u=arr(nom_u), loss=arr(loss), g_logit=arr(g_logit), g_p=arr(g_p))
+    print("wrote imitation_16.npz loss %.6f g_logit %s g_p %s" % (float(arr(loss)), arr(g_logit), arr(g_p)))
+
+    # ---- (b) B=1024, T=20: ONE MPCstep from a common iterate (forward + the no-op node's backward, the unit of work
+    # of a config-4 iteration), learnable cost, true pendulum, update_dynamics=False (box_ddp.py:165-171,252-258)
+    B = 1024
+    dx = env.true_dx
+    np.random.seed(0)
+    xinit = _f32(env.sample_xinit(B))
+    rng = np.random.RandomState(9)
+    logit0, learn_p0 = np.array([0.5, -0.25, -1.0, -3.0]), np.array([-0.75, 0.125, 0.0625, 0.0])
+    # the common iterate: three box-DDP iterations of the reference under the learner's cost (float32-rounded so that
+    # the GPU path starts from identical numbers)
+    q0 = 1.0 / (1.0 + np.exp(-logit0))
+    env3 = ref.il_env.IL_Env('pendulum', lqr_iter=3, mpc_T=T)
+    with warnings.catch_warnings(), redirect_stdout(io.StringIO()):
+        warnings.simplefilter("ignore")
+        _, u3 = env3.mpc(dx, xinit, V(q0), V(np.sqrt(q0) * learn_p0), update_dynamics=True)
+    u_k = _f32(arr(u3))
+    expert_u = _f32(np.clip(u_k + 0.3 * rng.randn(T, B, 1), -2.0, 2.0))
+    logit, learn_p = V(logit0), V(learn_p0)
+
+    def cost_of(B):
+        q = F.sigmoid(logit)
+        p = F.sqrt(q) * learn_p
+        Q = ref.util.chainer_diag(q)
+        Q = F.repeat(F.repeat(F.expand_dims(F.expand_dims(Q, 0), 0), T, axis=0), B, axis=1)   # il_env.py:119-123
+        pp = F.repeat(F.repeat(F.expand_dims(F.expand_dims(p, 0), 0), T, axis=0), B, axis=1)
+        return Q, pp
+
+    lo = np.full((T, B, 1), dx.lower)
+    hi = np.full((T, B, 1), dx.upper)
+    Q, pp = cost_of(B)
+    x_k = ref.util.get_traj(T, V(u_k), x_init=V(xinit), dynamics=dx)
+    Fk, fk = ref.approximate.linearize_dynamics(x_k, V(u_k), dx)
+    step = ref.mpc_step.MPCstep(controls=V(u_k), T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=3, n_ctrl=1,
+                                current_states=x_k, true_cost=ref.util.QuadCost(Q, pp), true_dynamics=dx,
+                                ls_decay=dx.linesearch_decay, max_ls_iter=dx.max_linesearch_iter, need_expand=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x1, u1 = step.apply((arr(x_k)[0], Q, pp, arr(Fk), arr(fk)))
+    fo = step.for_out
+    # the gradient node (box_ddp.py:234-259): Taylor models at the new point, no-op forward, loss on the controls
+    F1, f1 = ref.approximate.linearize_dynamics(x1, u1, dx)
+    node = ref.mpc_step.MPCstep(controls=u1, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=3, n_ctrl=1,
+                                current_states=x1, true_cost=ref.util.QuadCost(Q, pp), true_dynamics=dx,
+                                ls_decay=dx.linesearch_decay, max_ls_iter=dx.max_linesearch_iter, need_expand=True,
+                                no_op_forward=True)
+    x2, u2 = node.apply((arr(x1)[0], Q, pp, arr(F1), arr(f1)))
+    loss = F.mean((expert_u - u2) * (expert_u - u2))
+    g_logit, g_p, gQ, gp = ch.grad([loss], [logit, learn_p, Q, pp])
+    S = np.arange(0, B, 8)                                               # 128 sampled trajectories for the big tensors
+    np.savez_compressed(
+        os.path.join(HERE, "imitation_step_1024.npz"), B=B, T=T, sample=S, logit=arr(logit), learn_p=arr(learn_p),
+        u_k=u_k.astype(np.float32), expert_u=expert_u.astype(np.float32),
+        x_k_s=arr(x_k)[:, S], F_k_s=arr(Fk)[:, S], f_k_s=arr(fk)[:, S],
+        x1_s=arr(x1)[:, S], u1=arr(u1).astype(np.float32), costs=fo.costs, full_du_norm=fo.full_du_norm,
+        mean_alphas=fo.mean_alphas, n_total_qp_iter=step.back_out.n_total_qp_iter,
+        loss=arr(loss), g_logit=arr(g_logit), g_p=arr(g_p), dC_s=arr(gQ)[:, S], dc_s=arr(gp)[:, S])
+    print("wrote imitation_step_1024.npz loss %.6f sat %.2f g_logit %s g_p %s mean_alpha %.3f" % (
+        float(arr(loss)), float((np.abs(arr(u1)) == 2.0).mean()), arr(g_logit), arr(g_p), fo.mean_alphas))
+
+
+def gen_pnqp_fork(ref):
+    """PNQP n=8, B=256: batch-global convergence / Armijo tests make rows fork from their batch-of-one
+    answers.  Batched run recorded in full; per-row answers for comparison."""
+    n, B = 8, 256
+    p = synthetic.make_box_qp(B, n, seed=1, bound=2.0, reg=0.1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x, (LU, piv), idx_f, it = ref.pnqp.PNQP(p["H"], p["q"], p["lower"], p["upper"], n_iter=20)
+        warned = len(w) > 0
+    xs, its = [], []
+    for b in range(B):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xb, _, _, itb = ref.pnqp.PNQP(p["H"][b:b + 1], p["q"][b:b + 1], p["lower"][b:b + 1], p["upper"][b:b + 1],
+                                          n_iter=20)
+        xs.append(xb)
+        its.append(itb)
+    xr = np.concatenate(xs)
+    np.savez_compressed(os.path.join(HERE, "pnqp_n8_b256.npz"), n=n, B=B, seed=1, bound=2.0, reg=0.1, in_checksum=checksum(p), x=x,
+                        LU=LU, piv=piv, idx_f=idx_f, it=it, warned=warned, row_x=xr, row_it=np.array(its))
+    d = np.abs(x - xr).max(axis=1)
+    print("wrote pnqp_n8_b256.npz: it", it, "warned", warned, "rows differing > 1e-6:", int((d > 1e-6).sum()),
+          "max", d.max())
+
+
 def main():
     ref = load_reference.load()
     gen_lqr(ref)
@@ -276,10 +497,17 @@ def main():
     gen_mpc(ref)
     gen_boxddp(ref)
     gen_anchors(ref, extra)
+    gen_pendulum(ref)
+    gen_approx_cost(ref)
+    gen_pendulum_boxddp(ref)
+    gen_imitation(ref)
+    gen_pnqp_fork(ref)
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "mpc":
-        gen_mpc(load_reference.load())
+    if len(sys.argv) > 1:
+        _ref = load_reference.load()
+        for _name in sys.argv[1:]:
+            globals()["gen_" + _name](_ref)
     else:
         main()

@@ -30,6 +30,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.dmpc_version() == 100
 
 
+def test_library_belongs_to_the_sources_in_the_tree():
+    """csrc/build.py stamps the library with a hash of the source set (content, not mtimes): a stale binary is caught"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dmpc_build", os.path.join(ROOT, "chainer_differentiable_mpc_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = _lib.load()
+    assert lib.dmpc_source_hash().decode() == mod.source_hash(), \
+        "libdmpc_hip.so was built from other sources - run python chainer_differentiable_mpc_amd/csrc/build.py"
+
+
 def test_dispatch_table_and_workspace_queries():
     lib = _lib.load()
     assert lib.dmpc_lqr_kernel_family(8, 2) == 1        # DPP row kernel

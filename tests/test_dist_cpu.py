@@ -33,6 +33,8 @@ def worker(rank, world, port, B, T, nx, nu, out_dir):
     x, u = olqr.lqr_solve(x0.numpy(), C.numpy(), c.numpy(), F.numpy(), f.numpy(), T, nx, nu)
     gx = all_gather_batch(torch.as_tensor(x), B)
     gu = all_gather_batch(torch.as_tensor(u), B)
+    gu2 = all_gather_batch(torch.as_tensor(u))          # sizes not given: exchanged first, ragged shards stay correct
+    assert torch.equal(gu, gu2)
     # a parameter-shaped reduction: sum_{t,b} of something per-sample
     g = torch.as_tensor(x).sum(dim=(0, 1))
     all_reduce_param_grad(g)

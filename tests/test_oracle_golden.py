@@ -248,7 +248,7 @@ def test_box_ddp_trace_golden():
     g = load("boxddp_trace.npz")
     B, T, nx, nu = int(g["B"]), int(g["T"]), int(g["nx"]), int(g["nu"])
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=int(g["seed"]), with_f=True)
-    x, u, costs, status, n_iter, _ = box_ddp.box_ddp(p["x_init"], mpc.QuadCost(p["C"], p["c"]), mpc.LinDx(p["F"], p["f"]),
+    x, u, costs, status, n_iter, *_ = box_ddp.box_ddp(p["x_init"], mpc.QuadCost(p["C"], p["c"]), mpc.LinDx(p["F"], p["f"]),
                                                      T, -float(g["bound"]), float(g["bound"]), nx, nu)
     assert status in str(g["stdout"])
     np.testing.assert_allclose(u, g["u"], rtol=2e-5, atol=2e-6)
@@ -277,3 +277,102 @@ def test_pendulum_jacobian_matches_finite_differences():
             plus = box_ddp.pendulum_step(x[t] + d[:3], u[t] + d[3:])
             minus = box_ddp.pendulum_step(x[t] - d[:3], u[t] - d[3:])
             np.testing.assert_allclose(F[t][:, :, j], (plus - minus) / (2 * eps), atol=1e-6)
+
+
+# ----------------------------------------------------------------- pendulum / box-DDP / imitation (config 2 and 4)
+def test_oracle_pendulum_step_and_linearisation_match_the_reference():
+    """env_dx/pendulum.py:65-102 (PendulumDx.forward) and mpc/approximate.py:77-119 around it, torques inside,
+    exactly ON and beyond the clamp (d clip / du = 1 on the closed interval)"""
+    from oracle import box_ddp as obox
+    g = load("pendulum.npz")
+    np.testing.assert_allclose(obox.pendulum_step(g["x"], g["u"]), g["next"], rtol=0, atol=1e-15)
+    F, f = obox.pendulum_linearize(g["lin_x"], g["lin_u"])
+    np.testing.assert_allclose(F, g["lin_F"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(f, g["lin_f"], rtol=0, atol=1e-13)
+    assert np.allclose(g["lin_F"][:, :2, 2, 3], 0.15, atol=1e-15)      # d newdth / du at u = +-2 exactly: not zero
+
+
+def test_oracle_box_ddp_around_the_pendulum_matches_the_reference():
+    """BoxDDP.forward (mpc/box_ddp.py:93-291) with the non-linear pendulum, 1..4 outer iterations"""
+    from oracle import box_ddp as obox
+    from oracle import imitation as oim
+    g = load("pendulum_boxddp.npz")
+    B, T = int(g["B"]), int(g["T"])
+    Q, pv = oim.tile_cost(g["q"], g["p"], T, B)
+    for k in (1, 2, 3, 4):
+        x, u, c, status, *_ = obox.box_ddp(g["x_init"], mpc.QuadCost(Q, pv), obox.pendulum_step, T, -2.0, 2.0, 3, 1,
+                                           eps=1e-3, line_search_decay=0.2, max_line_search_iter=5, max_iter=k,
+                                           linearize=obox.pendulum_linearize, batch_coupled=True)
+        np.testing.assert_allclose(u, g["u_%d" % k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(x, g["x_%d" % k], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(c, g["costs_%d" % k], rtol=0, atol=1e-9)
+        assert status.strip() in str(g["stdout_%d" % k])
+
+
+def test_oracle_imitation_chain_matches_the_reference():
+    """config 4, small: Pendulum_Net_cost_logit -> IL_Env.mpc -> loss -> (d logit, d learn_p), incl. the detach mask
+    for unconverged samples (env_dx/pendulum_net.py:27-39, il_env.py:104-158, il_exp.py:246-270)"""
+    from oracle import imitation as oim
+    g = load("imitation_16.npz")
+    r = oim.imitation_grads(g["q_logit"], g["learn_p"], g["xinit"], g["expert_u"], int(g["T"]), int(g["lqr_iter"]))
+    np.testing.assert_allclose(r["nom_u"], g["nom_u"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(r["nom_x"], g["nom_x"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(r["loss"], float(g["loss"]), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r["g_logit"], g["g_logit"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(r["g_p"], g["g_p"], rtol=0, atol=1e-12)
+    assert np.abs(g["g_logit"]).max() > 1e-4
+
+
+def test_oracle_imitation_step_b1024_matches_the_reference():
+    """config 4 at full size (B=1024, T=20): one MPCstep from a common iterate + the gradient node"""
+    from oracle import box_ddp as obox
+    from oracle import imitation as oim
+    g = load("imitation_step_1024.npz")
+    pg = load("pendulum.npz")
+    B, T, S = int(g["B"]), int(g["T"]), g["sample"]
+    np.random.seed(0)
+    th = np.random.rand(B) * np.pi - 0.5 * np.pi              # env_dx/il_env.py:55-69
+    thdot = np.random.rand(B) * 2.0 - 1.0
+    xinit = np.stack((np.cos(th), np.sin(th), thdot), axis=1)
+    np.testing.assert_allclose(xinit[:64], pg["xinit1024_head"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(xinit.sum(axis=0), pg["xinit1024_sum"], rtol=0, atol=1e-10)
+    xinit = xinit.astype(np.float32).astype(np.float64)
+    u_k = g["u_k"].astype(np.float64)
+    x_k = obox.get_traj(T, u_k, xinit, obox.pendulum_step)
+    Fk, fk = obox.pendulum_linearize(x_k, u_k)
+    np.testing.assert_allclose(x_k[:, S], g["x_k_s"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Fk[:, S], g["F_k_s"], rtol=0, atol=1e-13)
+    q, p = oim.cost_from_params(g["logit"], g["learn_p"])
+    Q, pv = oim.tile_cost(q, p, T, B)
+    lo, hi = np.full((T, B, 1), -2.0), np.full((T, B, 1), 2.0)
+    x1, u1, bo, fo, _, _ = mpc.mpc_forward(Q, pv, Fk, fk, u_k, x_k, lo, hi, mpc.QuadCost(Q, pv), obox.pendulum_step,
+                                           0.2, 5, T, 3, 1, need_expand=True, batch_coupled=True)
+    np.testing.assert_allclose(u1, g["u1"], rtol=0, atol=2e-7)          # stored as float32
+    np.testing.assert_allclose(x1[:, S], g["x1_s"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fo.costs, g["costs"], rtol=0, atol=1e-11)
+    assert bo.n_total_qp_iter == int(g["n_total_qp_iter"])
+    loss, dC, dc = oim.gradient_node(x1, u1, Q, pv, g["expert_u"].astype(np.float64))
+    gl, gp = oim.param_grads(dC, dc, g["logit"], g["learn_p"])
+    np.testing.assert_allclose(loss, float(g["loss"]), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(dC[:, S], g["dC_s"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(dc[:, S], g["dc_s"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(gl, g["g_logit"], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(gp, g["g_p"], rtol=0, atol=1e-14)
+
+
+def test_oracle_pnqp_batch_coupling_fork_matches_the_reference():
+    """n=8, B=256: under the batch-global termination (pnqp.py:139-144,172,187) a row ends far from
+    its batch-of-one answer and the batch runs into the iteration cap; both modes of the oracle against the reference"""
+    g = load("pnqp_n8_b256.npz")
+    p = synthetic.make_box_qp(int(g["B"]), int(g["n"]), seed=int(g["seed"]), bound=float(g["bound"]), reg=float(g["reg"]))
+    assert abs(checksum(p) - float(g["in_checksum"])) < 1e-9
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, (LU, piv), idx_f, it = pnqp.pnqp(p["H"], p["q"], p["lower"], p["upper"], n_iter=20, batch_coupled=True)
+        xr, _, _, itr = pnqp.pnqp(p["H"], p["q"], p["lower"], p["upper"], n_iter=20, batch_coupled=False)
+    assert it == int(g["it"]) == 19
+    np.testing.assert_allclose(x, g["x"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(idx_f, g["idx_f"])
+    np.testing.assert_array_equal(piv, g["piv"])
+    np.testing.assert_allclose(xr, g["row_x"], rtol=0, atol=1e-6)
+    assert np.abs(g["x"] - g["row_x"]).max() > 1.0            # the fork is real
