@@ -35,11 +35,12 @@ SIGNATURES = {
     "dmpc_lqr_kkt_grad": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_batch_lu_factor": (_c_i, [_c_i, _c_i] + [_c_f] * 5),
     "dmpc_batch_lu_solve": (_c_i, [_c_i, _c_i, _c_i] + [_c_f] * 5),
-    "dmpc_pnqp": (_c_i, [_c_i, _c_i] + [_c_f] * 5 + [_c_i] + [_c_f] * 7),
+    "dmpc_coupled_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "dmpc_pnqp": (_c_i, [_c_i, _c_i] + [_c_f] * 5 + [_c_i, _c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_mpc_step_workspace_bytes": (_c_sz, [_c_i] * 4),
-    "dmpc_mpc_step_forward": (_c_i, [_c_i] * 4 + [_c_f] * 12 + [_c_i, ctypes.c_float, _c_i, _c_i]
+    "dmpc_mpc_step_forward": (_c_i, [_c_i] * 4 + [_c_f] * 12 + [_c_i, ctypes.c_float, _c_i, _c_i, _c_i]
                               + [_c_f] * 11 + [_c_f, _c_sz, _c_f, _c_f]),
-    "dmpc_mpc_backward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5),
+    "dmpc_mpc_backward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i, _c_i] + [_c_f] * 3 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_mpc_forward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [ctypes.c_float, _c_i] + [_c_f] * 10),
     "dmpc_mpc_forward_rec_pendulum": (_c_i, [_c_i] * 2 + [_c_f] * 8 + [ctypes.c_float] * 6 + [_c_i] + [_c_f] * 10),
     "dmpc_pendulum_rollout_linearize": (_c_i, [_c_i] * 2 + [_c_f] * 2 + [ctypes.c_float] * 5 + [_c_f] * 4),
@@ -47,7 +48,7 @@ SIGNATURES = {
     "dmpc_lin_rollout": (_c_i, [_c_i] * 4 + [_c_f] * 6),
     "dmpc_box_ddp_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_box_ddp": (_c_i, [_c_i] * 4 + [_c_f] * 5 + [_c_i, _c_f] + [_c_f] * 3 +
-                     [ctypes.c_float, _c_i, ctypes.c_float, _c_i, ctypes.c_float, _c_i, _c_i, _c_i] +
+                     [ctypes.c_float, _c_i, ctypes.c_float, _c_i, ctypes.c_float, _c_i, _c_i, _c_i, _c_i] +
                      [_c_f] * 7 + [_c_sz, _c_f, _c_f]),
 }
 

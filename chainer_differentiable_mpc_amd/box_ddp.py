@@ -36,7 +36,7 @@ class BoxDDP(torch.nn.Module):
     def __init__(self, T, u_lower, u_upper, n_batch, n_state, n_ctrl, u_init, eps=1e-5, not_improved_lim=5,
                  line_search_decay=0.2, max_line_search_iter=10, best_cost_eps=1e-4, max_iter=10,
                  detach_unconverged=True, exit_unconverged=True, verbose=False, ilqr_verbose=False,
-                 update_dynamics=True, quiet=False, device_loop=True):
+                 update_dynamics=True, quiet=False, device_loop=True, batch_coupled=False):
         super().__init__()
         self.T, self.n_batch, self.n_state, self.n_ctrl = T, n_batch, n_state, n_ctrl
         self.n_sc = n_state + n_ctrl
@@ -56,6 +56,10 @@ class BoxDDP(torch.nn.Module):
         # QuadCost with a LinDx or the built-in pendulum: the whole loop is one chain of launches with the
         # stop tests on the device (`dmpc_box_ddp`); False keeps the host loop over MPCstep objects
         self.device_loop = device_loop
+        # PNQP termination inside every MPC step: per trajectory (default; shard-invariant) or the reference's
+        # batch-global tests (pnqp.py:139-144,172,187; the batch must fit one cooperative launch).  The outer
+        # stop tests (box_ddp.py:223-230) are batch-global in both modes, as in the reference.
+        self.batch_coupled = batch_coupled
         self.status = None
         self.info = None            # MPC step flags of the device loop, per trajectory
         self._bounds_on = None
@@ -135,7 +139,8 @@ class BoxDDP(torch.nn.Module):
                                   None if params is None else ctypes.cast(params, ctypes.c_void_p), _lib.ptr(u0),
                                   _lib.ptr(lo_), _lib.ptr(hi_), float(self.eps), int(self.not_improved_lim),
                                   float(self.ls_decay), int(self.max_ls_iter), float(self.best_cost_eps),
-                                  int(self.max_iter), 20, 1, _lib.ptr(bx), _lib.ptr(bu), _lib.ptr(bc), _lib.ptr(bn),
+                                  int(self.max_iter), 20, 1, 1 if self.batch_coupled else 0, _lib.ptr(bx), _lib.ptr(bu),
+                                  _lib.ptr(bc), _lib.ptr(bn),
                                   _lib.ptr(ln), _lib.ptr(state), _lib.ptr(ws), need, _lib.ptr(info),
                                   _lib.stream_ptr(d))
         if rc == _lib.E_UNSUPPORTED:
@@ -224,7 +229,7 @@ class BoxDDP(torch.nn.Module):
                 step = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu,
                                current_states=x, true_cost=detached_cost(), true_dynamics=detached_dyn(),
                                ls_decay=self.ls_decay, max_ls_iter=self.max_ls_iter, verbose=self.ilqr_verbose,
-                               need_expand=True)
+                               need_expand=True, batch_coupled=self.batch_coupled)
                 x, u = step.forward((x[0], Cm, cm, Fm, fm))
             back_out, for_out = step.back_out, step.for_out
             n_not_improved += 1

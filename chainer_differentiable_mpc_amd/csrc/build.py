@@ -83,11 +83,25 @@ def generate(force=False):
             open(stamp, "w").write(want)
 
 
+def include_closure(src):
+    """the files a translation unit really includes (quoted includes, followed recursively)"""
+    import re
+    seen, todo = set(), [src]
+    while todo:
+        p = os.path.normpath(todo.pop())
+        if p in seen or not os.path.exists(p):
+            continue
+        seen.add(p)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(p).read(), flags=re.M):
+            todo.append(os.path.join(os.path.dirname(p), inc))
+    return sorted(seen)
+
+
 def compile_one(src, force, src_hash):
     base = os.path.basename(src)
     obj = os.path.join(OBJ_DIR, base[:-4] + ".o")
     stamp = obj + ".hash"
-    deps = [src] + glob.glob(os.path.join(HERE, "*.hpp")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    deps = include_closure(src)
     flags = list(FLAGS)
     if base == HASH_TU:
         flags.append('-DDMPC_SOURCE_HASH="%s"' % src_hash)

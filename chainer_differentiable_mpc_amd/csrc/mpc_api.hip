@@ -14,38 +14,65 @@
 namespace dmpc {
 
 // Standalone PNQP: one lane per QP, everything in registers.
+struct PnqpArgs {
+  int B;
+  const float *H, *q, *lower, *upper, *x_init;
+  int n_iter;
+  float *x_out, *fac;
+  int32_t *piv;
+  float *index_f;
+  int32_t *n_iter_out, *info;
+  unsigned *sync;   // batch-coupled termination (pnqp_device.hpp): pnqp_sync_slots(n_iter) zeroed slots, or nullptr
+};
+
 template <int N>
-__global__ __launch_bounds__(256) void pnqp_kernel(int B, const float *__restrict__ H, const float *__restrict__ q,
-                                                   const float *__restrict__ lower, const float *__restrict__ upper,
-                                                   const float *__restrict__ x_init, int n_iter,
-                                                   float *__restrict__ x_out, float *__restrict__ fac,
-                                                   int32_t *__restrict__ piv, float *__restrict__ index_f,
-                                                   int32_t *__restrict__ n_iter_out, int32_t *info) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__global__ __launch_bounds__(256) void pnqp_kernel(const PnqpArgs a) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b < a.B;
+  if (!live) {
+    if (a.sync == nullptr) return;
+    b = a.B - 1;   // coupled: padding lanes repeat the last row (neutral in the any-reductions) and take every barrier
+  }
   float Hm[N][N], qv[N], lo[N], hi[N], x[N];
 #pragma unroll
   for (int r = 0; r < N; ++r) {
 #pragma unroll
-    for (int c = 0; c < N; ++c) Hm[r][c] = H[((size_t)b * N + r) * N + c];
-    qv[r] = q[(size_t)b * N + r];
-    lo[r] = lower[(size_t)b * N + r];
-    hi[r] = upper[(size_t)b * N + r];
-    x[r] = x_init != nullptr ? x_init[(size_t)b * N + r] : 0.f;
+    for (int c = 0; c < N; ++c) Hm[r][c] = a.H[((size_t)b * N + r) * N + c];
+    qv[r] = a.q[(size_t)b * N + r];
+    lo[r] = a.lower[(size_t)b * N + r];
+    hi[r] = a.upper[(size_t)b * N + r];
+    x[r] = a.x_init != nullptr ? a.x_init[(size_t)b * N + r] : 0.f;
   }
   PnqpResult<N> res;
-  pnqp_solve<N>(Hm, qv, lo, hi, x, x_init != nullptr, n_iter, res);
+  QpTermination term;
+  term.slots = a.sync;
+  term.n_blocks = gridDim.x;
+  pnqp_solve<N>(Hm, qv, lo, hi, x, a.x_init != nullptr, a.n_iter, res, term);
+  if (!live) return;
 #pragma unroll
   for (int r = 0; r < N; ++r) {
-    x_out[(size_t)b * N + r] = x[r];
-    index_f[(size_t)b * N + r] = res.free_[r] ? 1.0f : 0.0f;
-    if (piv != nullptr) piv[(size_t)b * N + r] = res.piv[r];
+    a.x_out[(size_t)b * N + r] = x[r];
+    a.index_f[(size_t)b * N + r] = res.free_[r] ? 1.0f : 0.0f;
+    if (a.piv != nullptr) a.piv[(size_t)b * N + r] = res.piv[r];
 #pragma unroll
-    for (int c = 0; c < N; ++c) fac[((size_t)b * N + r) * N + c] = res.fac[r][c];
+    for (int c = 0; c < N; ++c) a.fac[((size_t)b * N + r) * N + c] = res.fac[r][c];
   }
-  n_iter_out[b] = res.it;
-  if (info != nullptr && !res.converged) atomicOr(&info[b], DMPC_INFO_QP_ITERCAP);
+  a.n_iter_out[b] = res.it;
+  if (a.info != nullptr && !res.converged) atomicOr(&a.info[b], DMPC_INFO_QP_ITERCAP);
 }
+
+// A kernel whose workgroups meet at grid barriers needs all of them resident: cooperative launch (the runtime
+// refuses a grid that does not fit instead of letting it deadlock).
+static int launch_cooperative(const void *kernel, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t stream) {
+  const hipError_t e = hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds, stream);
+  if (e == hipErrorCooperativeLaunchTooLarge) {
+    (void)hipGetLastError();
+    return DMPC_E_UNSUPPORTED;   // batch too large to be coupled in one launch: shard it, or use per-row termination
+  }
+  return (int)e;
+}
+
+static size_t coupled_bytes(int T, int n_qp_iter) { return round_up((size_t)T * pnqp_sync_slots(n_qp_iter) * 2 * sizeof(unsigned), 256); }
 
 #ifdef DMPC_EXPERIMENT_ONLY_8_2
 #define DMPC_MPC_SHAPES(X) X(8, 2, 16)
@@ -55,10 +82,19 @@ __global__ __launch_bounds__(256) void pnqp_kernel(int B, const float *__restric
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16)
 #endif
 
-static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a, hipStream_t stream) {
+static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t stream) {
+  MpcBackArgs a = a_in;
+  if (a.sync != nullptr) {   // fresh decision slots for this launch
+    const hipError_t e = hipMemsetAsync(a.sync, 0, coupled_bytes(a.T, a.n_qp_iter), stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  void *args1[] = {&a};
 #define X(NX_, NU_, L_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                               \
     constexpr int GPB = 256 / L_;                                                                             \
+    if (a.sync != nullptr)                                                                                    \
+      return launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, L_>),       \
+                                dim3((a.B + GPB - 1) / GPB), dim3(256), args1, 0, stream);                    \
     hipLaunchKernelGGL((mpc_backward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
                        a);                                                                                    \
     return (int)hipGetLastError();                                                                            \
@@ -67,8 +103,12 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a, hipStream_t str
 #undef X
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
   if (nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
+    void *args2[] = {&a, &nx};
 #define G(NU_)                                                                                                    \
   case NU_:                                                                                                       \
+    if (a.sync != nullptr)                                                                                        \
+      return launch_cooperative(reinterpret_cast<const void *>(&mpc_generic_backward_kernel<NU_>), dim3(a.B),     \
+                                dim3(64), args2, mpc_generic_back_lds_bytes<NU_>(nx), stream);                    \
     hipLaunchKernelGGL((mpc_generic_backward_kernel<NU_>), dim3(a.B), dim3(64), mpc_generic_back_lds_bytes<NU_>(nx), \
                        stream, a, nx);                                                                            \
     return (int)hipGetLastError();
@@ -107,8 +147,9 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a, hipStream_t strea
 }
 
 struct MpcWs {
-  size_t c_back, neg, x0, dx, du, mask, lqr, total;
+  size_t c_back, neg, x0, dx, du, mask, sync, lqr, total;
 };
+constexpr int kSyncQpIterMax = 64;   // the workspace queries do not know n_qp_iter_max: sized for up to this many
 static MpcWs mpc_layout(int T, int B, int nx, int nu) {
   const size_t ns = nx + nu;
   MpcWs w;
@@ -124,6 +165,7 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
   w.dx = take((size_t)T * B * nx * sizeof(float));
   w.du = take((size_t)T * B * nu * sizeof(float));
   w.mask = take((size_t)T * B * nu);
+  w.sync = take(coupled_bytes(T, kSyncQpIterMax));
   w.lqr = off;
   off += round_up(dmpc_lqr_workspace_bytes(T, B, nx, nu), 256);
   w.total = off;
@@ -132,7 +174,7 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
 
 // workspace of the device-driven box-DDP loop (dmpc_box_ddp)
 struct DdpWs {
-  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, total;
+  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, sync, total;
 };
 static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   const size_t ns = nx + nu, TB = (size_t)T * B, fl = sizeof(float);
@@ -159,6 +201,7 @@ static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   w.nqp = take((size_t)B * sizeof(int32_t));
   w.nls = take((size_t)B * sizeof(int32_t));
   w.keep = take((size_t)B * sizeof(int32_t));
+  w.sync = take(coupled_bytes(T, kSyncQpIterMax));
   w.total = off;
   return w;
 }
@@ -174,18 +217,33 @@ using namespace dmpc;
 
 extern "C" {
 
+size_t dmpc_coupled_workspace_bytes(int T, int n_qp_iter_max) {
+  if (T <= 0 || n_qp_iter_max <= 0) return 0;
+  return coupled_bytes(T, n_qp_iter_max);
+}
+
 int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
-              const float *x_init, int n_iter, float *x, float *fac, int32_t *piv, float *index_f,
-              int32_t *n_iter_out, int32_t *info, dmpc_stream_t stream_) {
+              const float *x_init, int n_iter, int batch_coupled, float *x, float *fac, int32_t *piv, float *index_f,
+              int32_t *n_iter_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
   if (B <= 0 || n <= 0 || n_iter <= 0 || !H || !q || !lower || !upper || !x || !fac || !index_f || !n_iter_out)
     return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const dim3 block(256), grid((B + 255) / 256);
+  unsigned *sync = nullptr;
+  if (batch_coupled) {
+    if (!ws || ws_bytes < coupled_bytes(1, n_iter)) return DMPC_E_WORKSPACE;
+    sync = static_cast<unsigned *>(ws);
+    const hipError_t e = hipMemsetAsync(sync, 0, coupled_bytes(1, n_iter), stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  PnqpArgs a{B, H, q, lower, upper, x_init, n_iter, x, fac, piv, index_f, n_iter_out, info, sync};
+  void *args[] = {&a};
   switch (n) {
 #define CASE(N)                                                                                                  \
   case N:                                                                                                        \
-    hipLaunchKernelGGL((pnqp_kernel<N>), grid, block, 0, stream, B, H, q, lower, upper, x_init, n_iter, x, fac, piv, \
-                       index_f, n_iter_out, info);                                                               \
+    if (sync != nullptr)                                                                                         \
+      return launch_cooperative(reinterpret_cast<const void *>(&pnqp_kernel<N>), grid, block, args, 0, stream);  \
+    hipLaunchKernelGGL((pnqp_kernel<N>), grid, block, 0, stream, a);                                             \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
@@ -196,14 +254,15 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
 
 int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
                           const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
-                          const float *u_upper, int n_qp_iter_max, float *Ks_out, float *ks_out,
-                          int32_t *n_qp_iter, int32_t *info, dmpc_stream_t stream_) {
+                          const float *u_upper, int n_qp_iter_max, int batch_coupled, float *Ks_out, float *ks_out,
+                          int32_t *n_qp_iter, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (!C_hat || !c_hat || !F_hat || !controls || !u_lower || !u_upper || !Ks_out || !ks_out || !n_qp_iter)
     return DMPC_E_BADARG;
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(f_hat)) return DMPC_E_BADARG;
+  if (batch_coupled && (!ws || ws_bytes < coupled_bytes(T, n_qp_iter_max))) return DMPC_E_WORKSPACE;
   MpcBackArgs ba{T, B, C_hat, c_hat, F_hat, f_hat, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
-                 n_qp_iter, info};
+                 n_qp_iter, info, nullptr, batch_coupled ? static_cast<unsigned *>(ws) : nullptr};
   return launch_mpc_back(nx, nu, ba, static_cast<hipStream_t>(stream_));
 }
 
@@ -260,11 +319,12 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_hat, const float *f_hat, const float *controls, const float *states,
                           const float *u_lower, const float *u_upper, const float *C_true, const float *c_true,
                           const float *F_true, const float *f_true, int need_expand, float ls_decay,
-                          int max_ls_iter, int n_qp_iter_max, float *x_out, float *u_out, float *Ks_out,
-                          float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
+                          int max_ls_iter, int n_qp_iter_max, int batch_coupled, float *x_out, float *u_out,
+                          float *Ks_out, float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
                           float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
                           int32_t *info, dmpc_stream_t stream_) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
+  if (batch_coupled && n_qp_iter_max > kSyncQpIterMax) return DMPC_E_UNSUPPORTED;
   if (!C_hat || !c_hat || !F_hat || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true ||
       !x_out || !u_out || !Ks_out || !ks_out || !costs || !alphas || !n_qp_iter || !n_ls_iter || !ws)
     return DMPC_E_BADARG;
@@ -286,7 +346,7 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
     f_use = nullptr;
   }
   MpcBackArgs ba{T, B, C_hat, c_use, F_hat, f_use, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
-                 n_qp_iter, info};
+                 n_qp_iter, info, nullptr, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr};
   int rc = launch_mpc_back(nx, nu, ba, stream);
   if (rc != 0) return rc;
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
@@ -310,10 +370,11 @@ size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu) {
 int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float *C, const float *c, const float *F,
                  const float *f, int dyn_kind, const float *dyn_params, const float *u_init, const float *u_lower,
                  const float *u_upper, float eps, int not_improved_lim, float ls_decay, int max_ls_iter,
-                 float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, float *x_best,
-                 float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last, int32_t *state, void *ws,
-                 size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+                 float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, int batch_coupled,
+                 float *x_best, float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last,
+                 int32_t *state, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || max_iter <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
+  if (batch_coupled && n_qp_iter_max > kSyncQpIterMax) return DMPC_E_UNSUPPORTED;
   if (!x_init || !C || !c || !u_init || !u_lower || !u_upper || !x_best || !u_best || !costs_best || !du_norm_best ||
       !du_norm_last || !state || !ws)
     return DMPC_E_BADARG;
@@ -356,7 +417,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     }
     // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
     MpcBackArgs ba{T, B, C, c_back, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks, ip(w.nqp), info,
-                   done};
+                   done, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr};
     int rc = launch_mpc_back(nx, nu, ba, stream);
     if (rc != 0) return rc;
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
 #pragma unroll
   for (int m = 0; m < NU; ++m) kprev[m] = 0.f;
   int n_total = 0, info_bits = 0;
+  QpTermination term;          // batch-coupled termination: every lane runs the QP (the grid-wide OR needs them all)
+  term.slots = a.sync;
+  term.n_blocks = gridDim.x;
+  const bool coupled = a.sync != nullptr;
 
   for (int e = lane; e < nx * nc; e += 64) Vt[e] = 0.f;
   __syncthreads();
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
       }
       __syncthreads();
     }
-    if (lane == 0) {  // k_t: box QP on (Quu, qu), warm-started from the later timestep              :119-146
+    if (lane == 0 || coupled) {  // k_t: box QP on (Quu, qu), warm-started from the later timestep   :119-146
       float H[NU][NU], q[NU], lo[NU], hi[NU], kt[NU];
 #pragma unroll
       for (int m = 0; m < NU; ++m) {
@@ -93,17 +97,20 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
         kt[m] = kprev[m];
       }
       PnqpResult<NU> qp;
-      pnqp_solve<NU>(H, q, lo, hi, kt, /*warm=*/t != T - 1, a.n_qp_iter, qp);
+      pnqp_solve<NU>(H, q, lo, hi, kt, /*warm=*/t != T - 1, a.n_qp_iter, qp, term);
       n_total += 1 + qp.it;
       if (!qp.converged) info_bits |= 4;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) {
-        kprev[m] = kt[m];
-        kt_s[m] = kt[m];
-        piv_s[m] = qp.piv[m];
-        free_s[m] = qp.free_[m] ? 1 : 0;
+      for (int m = 0; m < NU; ++m) kprev[m] = kt[m];
+      if (lane == 0) {
 #pragma unroll
-        for (int l = 0; l < NU; ++l) fac_s[m * NU + l] = qp.fac[m][l];
+        for (int m = 0; m < NU; ++m) {
+          kt_s[m] = kt[m];
+          piv_s[m] = qp.piv[m];
+          free_s[m] = qp.free_[m] ? 1 : 0;
+#pragma unroll
+          for (int l = 0; l < NU; ++l) fac_s[m * NU + l] = qp.fac[m][l];
+        }
       }
     }
     __syncthreads();

@@ -33,6 +33,9 @@ struct MpcBackArgs {
   int32_t *n_qp_total;                  // [B]  sum_t (1 + i_t)   (mpc_step.py:145)
   int32_t *info;
   const int32_t *done;                  // device flag of the BoxDDP loop (box_ddp_kernels.hpp): non-zero -> no-op
+  // batch-coupled PNQP termination (pnqp.py:139-144,172,187): zeroed decision slots, T * pnqp_sync_slots(n_qp_iter) of
+  // them; nullptr = per-trajectory termination.  With slots the kernel must be launched cooperatively.
+  unsigned *sync;
 };
 
 template <int NX, int NU, int L>
@@ -63,6 +66,9 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   for (int m = 0; m < NU; ++m) kprev[m] = 0.f;
   int n_total = 0;
   int info_bits = 0;
+  QpTermination term;
+  term.slots = a.sync;
+  term.n_blocks = gridDim.x;
 
   // Inputs of one timestep, column-per-lane.  One wavefront per SIMD: nothing else hides HBM latency, so the loads
   // of step t-2 are issued before step t is computed (three banks rotated statically - hipcc drains vmcnt at a loop
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
     float kt[NU];
 #pragma unroll
     for (int m = 0; m < NU; ++m) kt[m] = kprev[m];
-    pnqp_solve<NU>(Quu, qu, lo, hi, kt, /*warm=*/t != T - 1, a.n_qp_iter, qp);
+    pnqp_solve<NU>(Quu, qu, lo, hi, kt, /*warm=*/t != T - 1, a.n_qp_iter, qp, term);
     n_total += 1 + qp.it;
     if (!qp.converged) info_bits |= 4;
 #pragma unroll

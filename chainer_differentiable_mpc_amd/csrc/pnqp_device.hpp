@@ -2,11 +2,15 @@
 //
 //     min 1/2 x'Hx + q'x   s.t.  lo <= x <= hi            (Tassa, Mansard, Todorov 2014, Alg. 1)
 //
-// Follows PNQP, mpc/pnqp.py:37-201 of the reference, with PER-ROW termination: the reference tests
-// convergence and the Armijo condition over the whole batch (pnqp.py:139-144, 172, 187), which makes a
-// row's result depend on its batch-mates; a fused per-trajectory kernel cannot (and should not) do that,
-// so this is the reference called with a batch of one - the semantics pinned by the per-row golden
-// vectors (tests/golden/pnqp_n*.npz, *_row_* keys) and by oracle.pnqp(batch_coupled=False).
+// Follows PNQP, mpc/pnqp.py:37-201 of the reference.  The reference tests convergence and the Armijo
+// condition over the whole batch (pnqp.py:139-144, 172, 187), which makes a row's result depend on its
+// batch-mates.  Two termination modes (`QpTermination`):
+//   * per row (default; what shards across GPUs): the reference called with a batch of one per row - pinned by
+//     the per-row golden vectors (tests/golden/pnqp_n*.npz, *_row_* keys) and oracle.pnqp(batch_coupled=False);
+//   * batch coupled: the reference's own semantics for an unsharded batch.  Both tests become ONE any-reduction
+//     over the grid each ("is any row still moving", "did any row pass / is any row already converged"), done
+//     with a grid barrier on a fresh slot per decision; the kernel must then be launched cooperatively (all
+//     workgroups resident).  Pinned by the batched golden vectors and oracle.pnqp(batch_coupled=True).
 //
 // Everything is float32 (the reference computes in float64 but rounds every solve to float32,
 // util.py:522-527).  The routine is executed redundantly by every lane that needs the result - inside
@@ -21,6 +25,35 @@ constexpr float kPnqpDecay = 0.1f;   // pnqp.py:163
 constexpr float kPnqpDxTol = 1e-4f;  // pnqp.py:140
 constexpr float kPnqpReg = 1e-11f;   // pnqp.py:73
 constexpr int kPnqpMaxLs = 10;       // pnqp.py:172
+
+// Where PNQP's two termination tests are reduced.  `slots == nullptr`: per row.  Otherwise a grid-wide OR: slot k
+// (two dwords {arrivals, flag}, zeroed before the launch, never reused) serves the k-th decision of the launch; every
+// thread of every workgroup must call any() the same number of times - true because all exits of the coupled
+// algorithm are taken on grid-uniform values.
+struct QpTermination {
+  unsigned *slots = nullptr;
+  unsigned n_blocks = 0;
+  unsigned seq = 0;
+
+  __device__ __forceinline__ bool any(bool v) {
+    if (slots == nullptr) return v;
+    __shared__ int flag;
+    const int block_any = __syncthreads_or(v ? 1 : 0);
+    if (threadIdx.x == 0) {
+      unsigned *s = slots + 2 * (size_t)seq;
+      if (block_any) __hip_atomic_fetch_or(&s[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&s[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(&s[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < n_blocks) __builtin_amdgcn_s_sleep(2);
+      flag = (int)__hip_atomic_load(&s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // the next any() writes `flag` only behind its own __syncthreads_or: no second barrier needed
+    ++seq;
+    return flag != 0;
+  }
+};
+
+// decisions one PNQP call can take: per QP iteration the convergence test and up to kPnqpMaxLs Armijo passes
+__host__ __device__ constexpr size_t pnqp_sync_slots(int n_iter) { return (size_t)n_iter * (1 + 10); }
 
 template <int N>
 struct PnqpResult {
@@ -49,7 +82,7 @@ __device__ __forceinline__ float pnqp_obj(const float (&H)[N][N], const float (&
 template <int N>
 __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (&q)[N], const float (&lo)[N],
                                            const float (&hi)[N], float (&x)[N], bool warm, int n_iter,
-                                           PnqpResult<N> &res) {
+                                           PnqpResult<N> &res, QpTermination &term) {
   if (!warm) {  // x_init = -H^-1 q                                                   pnqp.py:75-83
     if constexpr (N == 1) {
       x[0] = -(1.0f / H[0][0]) * q[0];
@@ -116,7 +149,8 @@ __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (
     float n2 = 0.f;
 #pragma unroll
     for (int r = 0; r < N; ++r) n2 = fmaf(dx[r], dx[r], n2);
-    if (!(sqrtf(n2) >= kPnqpDxTol)) {  // :139-144 (a NaN norm counts as converged there too)
+    const bool large = sqrtf(n2) >= kPnqpDxTol;  // :139-140 (a NaN norm counts as converged there too)
+    if (!term.any(large)) {                      // :141-144: no row (of the batch / this row) still moves
       res.it = i;
       res.converged = true;
       return;
@@ -146,13 +180,23 @@ __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (
         dHd = fmaf(d[r], hd, dHd);
       }
       const float lhs = 1.0f + 0.5f * dHd / gd;             // :175-176
-      again = lhs <= kPnqpGamma;                            // false for NaN, like numpy's max(nan) <= GAMMA
-      if (again) alpha *= kPnqpDecay;                       // :185-186
+      // a row that has already converged carries GAMMA + 1e-6 (:174): it passes, and keeps its alpha
+      const bool fails = large && lhs <= kPnqpGamma;        // false for NaN, like numpy's max(nan) <= GAMMA
+      if (fails) alpha *= kPnqpDecay;                       // :185-186
       ++count;
+      again = !term.any(!fails);                            // :172,187: the search ends once ANY row passes
     } while (again && count < kPnqpMaxLs);                  // :172
 #pragma unroll
     for (int r = 0; r < N; ++r) x[r] = xh[r];               // :190
   }
+}
+
+template <int N>
+__device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (&q)[N], const float (&lo)[N],
+                                           const float (&hi)[N], float (&x)[N], bool warm, int n_iter,
+                                           PnqpResult<N> &res) {
+  QpTermination per_row;
+  pnqp_solve<N>(H, q, lo, hi, x, warm, n_iter, res, per_row);
 }
 
 }  // namespace dmpc

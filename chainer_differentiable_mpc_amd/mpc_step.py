@@ -10,10 +10,13 @@ a `LinDx`.  A callable true cost / dynamics (e.g. the pendulum) keeps backward_r
 and rolls the line search out with torch ops around the callable.
 
 Differences from the reference, by design:
-  * PNQP and the line search terminate per trajectory (the reference's batch-global tests make a
-    trajectory's result depend on its batch-mates);
+  * by default PNQP terminates per trajectory (the reference's batch-global tests make a trajectory's result
+    depend on its batch-mates; per trajectory is what shards across GPUs).  `batch_coupled=True` gives the
+    reference's batch semantics (pnqp.py:139-144,172,187) for a batch that fits one cooperative launch.  The line
+    search's batch-global loop condition (mpc_step.py:196) never changes a trajectory's result, so it stays per
+    trajectory in both modes;
   * `LqrBackOut.n_total_qp_iter` is the largest per-trajectory total (per-trajectory values in
-    `self.n_qp_iter`);
+    `self.n_qp_iter`; with `batch_coupled` they are all equal to the reference's number);
   * `full_du_norm` / `alpha_du_norm` reproduce the reference's reshape of a [T,nu,B] array to
     [B, T*nu] (mpc_step.py:261-263) unless `strict_math=True` (then true per-trajectory norms).
 """
@@ -77,7 +80,7 @@ class MPCstep:
 
     def __init__(self, controls, T, u_upper, u_lower, n_batch, n_state, n_ctrl, current_states,
                  true_cost, true_dynamics, ls_decay, max_ls_iter, verbose=False, need_expand=False,
-                 no_op_forward=False, strict_math=False, n_qp_iter=20):
+                 no_op_forward=False, strict_math=False, n_qp_iter=20, batch_coupled=False):
         self.controls = _as_tensor(controls)
         self.u_upper = _as_tensor(u_upper)
         self.u_lower = _as_tensor(u_lower)
@@ -96,6 +99,7 @@ class MPCstep:
         self.no_op_forward = no_op_forward
         self.strict_math = strict_math
         self.n_qp_iter_max = int(n_qp_iter)
+        self.batch_coupled = bool(batch_coupled)
         self.n_qp_iter = None     # per-trajectory sum_t (1 + i_t)
         self.n_ls_iter = None     # per-trajectory line-search passes
         self.alphas = None
@@ -136,11 +140,16 @@ class MPCstep:
         ks = torch.empty((T, B, nu), dtype=torch.float32, device=d)
         nqp = torch.empty((B,), dtype=torch.int32, device=d)
         info = torch.zeros(B, dtype=torch.int32, device=d)
+        ws, need = None, 0
+        if self.batch_coupled:
+            need = lib.dmpc_coupled_workspace_bytes(T, self.n_qp_iter_max)
+            ws = _workspace(need, d)
         with torch.cuda.device(d):
             rc = lib.dmpc_mpc_backward_rec(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f),
                                            _lib.ptr(self._u), _lib.ptr(self._lo), _lib.ptr(self._hi),
-                                           self.n_qp_iter_max, _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(nqp),
-                                           _lib.ptr(info), _lib.stream_ptr(d))
+                                           self.n_qp_iter_max, 1 if self.batch_coupled else 0, _lib.ptr(Ks),
+                                           _lib.ptr(ks), _lib.ptr(nqp), _lib.ptr(ws), need, _lib.ptr(info),
+                                           _lib.stream_ptr(d))
         _lib.check(rc, "dmpc_mpc_backward_rec")
         self.n_qp_iter = nqp
         self.info = info
@@ -300,7 +309,8 @@ class MPCstep:
                     T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(self._u),
                     _lib.ptr(self._xs), _lib.ptr(self._lo), _lib.ptr(self._hi), _lib.ptr(Ct), _lib.ptr(ct),
                     _lib.ptr(Ft), _lib.ptr(ft), 1 if self.need_expand else 0, self.ls_decay, self.max_ls_iter,
-                    self.n_qp_iter_max, _lib.ptr(x), _lib.ptr(u), _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(costs),
+                    self.n_qp_iter_max, 1 if self.batch_coupled else 0, _lib.ptr(x), _lib.ptr(u), _lib.ptr(Ks),
+                    _lib.ptr(ks), _lib.ptr(costs),
                     _lib.ptr(old), _lib.ptr(alphas), _lib.ptr(objs), _lib.ptr(u1), _lib.ptr(nqp), _lib.ptr(nls),
                     _lib.ptr(ws), need, _lib.ptr(info), _lib.stream_ptr(d))
             _lib.check(rc, "dmpc_mpc_step_forward")

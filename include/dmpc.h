@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DMPC_VERSION 100 /* 0.1.0 */
+#define DMPC_VERSION 200 /* 0.2.0: batch_coupled PNQP / MPC step */
 
 #define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
 #define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */
@@ -101,13 +101,19 @@ int dmpc_batch_lu_solve(int B, int n, int k, const float *LU, const int32_t *piv
                         dmpc_stream_t stream);
 
 /* ---- C. PNQP (mpc/pnqp.py:37-201): min 1/2 x'Hx + q'x, lower <= x <= upper ------------
- *   x_init NULL = cold start (-H^-1 q clamped).  Per-row termination (= the reference called
- *   with a batch of one per row; its batch-global coupling is described in DESIGN.md).
+ *   x_init NULL = cold start (-H^-1 q clamped).
+ *   batch_coupled = 0: per-row termination (= the reference called with a batch of one per row; what shards
+ *   across GPUs).  batch_coupled = 1: the reference's own batch semantics - the convergence test and the Armijo
+ *   loop are reduced over the WHOLE batch (pnqp.py:139-144,172,187), so a row's answer depends on its batch-mates;
+ *   needs `ws` of dmpc_coupled_workspace_bytes(1, n_iter) bytes and a batch that is resident in one cooperative
+ *   launch (DMPC_E_UNSUPPORTED otherwise).
  *   outputs: x [B,n]; fac [B,n,n] = LU of the last free-set Hessian (n == 1: H_f [B,1,1]);
- *   piv [B,n] int32 1-based; index_f [B,n] float {0,1}; n_iter_out [B] int32 (the reference's `i`). */
+ *   piv [B,n] int32 1-based; index_f [B,n] float {0,1}; n_iter_out [B] int32 (the reference's `i`; one value
+ *   for the whole batch when coupled). */
+size_t dmpc_coupled_workspace_bytes(int T, int n_qp_iter_max);
 int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
-              const float *x_init, int n_iter, float *x, float *fac, int32_t *piv, float *index_f,
-              int32_t *n_iter_out, int32_t *info, dmpc_stream_t stream);
+              const float *x_init, int n_iter, int batch_coupled, float *x, float *fac, int32_t *piv,
+              float *index_f, int32_t *n_iter_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
 
 /* ---- E. MPCstep (mpc/mpc_step.py:70-460), LinDx true dynamics + QuadCost true cost --------
  * forward(): Taylor re-centre (need_expand), backward_rec with one PNQP per timestep, forward_rec
@@ -124,18 +130,22 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_hat, const float *f_hat, const float *controls, const float *states,
                           const float *u_lower, const float *u_upper, const float *C_true, const float *c_true,
                           const float *F_true, const float *f_true, int need_expand, float ls_decay,
-                          int max_ls_iter, int n_qp_iter_max, float *x_out, float *u_out, float *Ks_out,
-                          float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
+                          int max_ls_iter, int n_qp_iter_max, int batch_coupled, float *x_out, float *u_out,
+                          float *Ks_out, float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
                           float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
                           int32_t *info, dmpc_stream_t stream);
 
 /* The two halves of forward(), separately callable like the reference's methods:
  * backward_rec (mpc_step.py:70-173): c_hat must already be re-centred when need_expand applies;
- * forward_rec (mpc_step.py:175-286): gains in, line-searched trajectory out. */
+ *   batch_coupled as in dmpc_pnqp (one PNQP per timestep; `ws` of dmpc_coupled_workspace_bytes(T, n_qp_iter_max)
+ *   bytes, NULL when not coupled; dmpc_mpc_step_forward / dmpc_box_ddp carve it out of their own workspace);
+ * forward_rec (mpc_step.py:175-286): gains in, line-searched trajectory out.  Its loop condition is batch-global in
+ *   the reference too (:196), but there a trajectory's result does not depend on its batch-mates (a trajectory that
+ *   is no longer worse keeps its step size and re-computes the same rollout), so it has no coupled mode. */
 int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
                           const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
-                          const float *u_upper, int n_qp_iter_max, float *Ks_out, float *ks_out,
-                          int32_t *n_qp_iter, int32_t *info, dmpc_stream_t stream);
+                          const float *u_upper, int n_qp_iter_max, int batch_coupled, float *Ks_out, float *ks_out,
+                          int32_t *n_qp_iter, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
 int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *controls,
                          const float *states, const float *u_lower, const float *u_upper, const float *C_true,
                          const float *c_true, const float *F_true, const float *f_true, float ls_decay,
@@ -177,14 +187,15 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
  *   the best iterate), du_norm_last [B] (of the last executed step, box_ddp.py:263-289 reads it);
  *   state [8] int32: [0] stopped early, [1] iterations run, [2] 1 Converged / 2 Not improved lim / 3 Not Converged;
  *   scrambled_norm != 0 reproduces the reference's reshape in full_du_norm (mpc_step.py:261-263);
+ *   batch_coupled != 0: batch-global PNQP termination inside every step (as dmpc_mpc_backward_rec);
  *   info [B] accumulates the MPC step flags of every iteration (caller zeroes it).                              */
 size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu);
 int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float *C, const float *c, const float *F,
                  const float *f, int dyn_kind, const float *dyn_params, const float *u_init, const float *u_lower,
                  const float *u_upper, float eps, int not_improved_lim, float ls_decay, int max_ls_iter,
-                 float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, float *x_best,
-                 float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last, int32_t *state, void *ws,
-                 size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
+                 float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, int batch_coupled,
+                 float *x_best, float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last,
+                 int32_t *state, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
 
 /* backward(): active-set LQR on (-d_tau) + co-state sweeps + outer products (mpc_step.py:330-460).
  *   outputs carry the reference's signs: dC = -1/2(dtau'(x)tau + tau(x)dtau'), dc = -dtau',

@@ -110,6 +110,37 @@ def mpc_backward_rec(C_hat, c_hat, F_hat, f_hat, controls, u_lower, u_upper, T, 
 
 
 # --------------------------------------------------------------------------- E3
+def ls_rollout(Ks, ks, controls, states, u_lower, u_upper, true_cost, true_dynamics, alphas, T):
+    """one pass of the line search, mpc_step.py:198-256: clamped closed-loop rollout with step sizes `alphas` [B]
+    under the true dynamics, per-step true cost -> (new_x [T,B,nx], new_u [T,B,nu], objs [T,B])"""
+    new_x = [states[0]]
+    new_u = []
+    dx = [np.zeros_like(states[0])]
+    objs = []
+    for t in range(T):
+        new_xt = new_x[t]
+        new_ut = bmv(Ks[t], dx[t]) + controls[t]                             # :209
+        new_ut = new_ut + alphas[:, None].astype(ks.dtype) * ks[t]           # :213-219 (diagflat(alpha) @ kt)
+        new_ut = clamp(new_ut, u_lower[t], u_upper[t])                       # :221
+        new_u.append(new_ut)
+        new_xut = np.concatenate((new_xt, new_ut), axis=1)
+        if t < T - 1:
+            if isinstance(true_dynamics, LinDx):
+                new_xtp1 = bmv(true_dynamics.F[t], new_xut)                  # :234
+                if true_dynamics.f is not None:
+                    new_xtp1 = new_xtp1 + true_dynamics.f[t]
+            else:
+                new_xtp1 = np.asarray(true_dynamics(new_xt, new_ut))         # :239
+            new_x.append(new_xtp1)
+            dx.append(new_xtp1 - states[t + 1])                              # :243
+        if isinstance(true_cost, QuadCost):
+            obj = 0.5 * bquad(new_xut, true_cost.C[t]) + bdot(new_xut, true_cost.c[t])   # :251
+        else:
+            obj = true_cost(new_xut)
+        objs.append(obj)
+    return np.stack(new_x, axis=0), np.stack(new_u, axis=0), np.stack(objs, axis=0)
+
+
 def mpc_forward_rec(Ks, ks, controls, states, u_lower, u_upper, true_cost, true_dynamics,
                     ls_decay, max_ls_iter, T, per_sample=False, max_total_iter=200):
     """mpc_step.py:175-286.  Clamped rollout + line search on the TRUE cost.
@@ -124,35 +155,8 @@ def mpc_forward_rec(Ks, ks, controls, states, u_lower, u_upper, true_cost, true_
     n_iter = 0
     full_du_norm = None
     while (n_iter < max_ls_iter and current_cost is None) or (current_cost > OLD_COST).any():   # :196
-        new_x = [states[0]]
-        new_u = []
-        dx = [np.zeros_like(states[0])]
-        objs = []
-        for t in range(T):
-            new_xt = new_x[t]
-            new_ut = bmv(Ks[t], dx[t]) + controls[t]                         # :209
-            new_ut = new_ut + alphas[:, None].astype(ks.dtype) * ks[t]       # :213-219 (diagflat(alpha) @ kt)
-            new_ut = clamp(new_ut, u_lower[t], u_upper[t])                   # :221
-            new_u.append(new_ut)
-            new_xut = np.concatenate((new_xt, new_ut), axis=1)
-            if t < T - 1:
-                if isinstance(true_dynamics, LinDx):
-                    new_xtp1 = bmv(true_dynamics.F[t], new_xut)              # :234
-                    if true_dynamics.f is not None:
-                        new_xtp1 = new_xtp1 + true_dynamics.f[t]
-                else:
-                    new_xtp1 = np.asarray(true_dynamics(new_xt, new_ut))     # :239
-                new_x.append(new_xtp1)
-                dx.append(new_xtp1 - states[t + 1])                          # :243
-            if isinstance(true_cost, QuadCost):
-                obj = 0.5 * bquad(new_xut, true_cost.C[t]) + bdot(new_xut, true_cost.c[t])   # :251
-            else:
-                obj = true_cost(new_xut)
-            objs.append(obj)
-        objs = np.stack(objs, axis=0)
+        new_x, new_u, objs = ls_rollout(Ks, ks, controls, states, u_lower, u_upper, true_cost, true_dynamics, alphas, T)
         current_cost = np.sum(objs, axis=0)
-        new_x = np.stack(new_x, axis=0)
-        new_u = np.stack(new_u, axis=0)
         if full_du_norm is None:
             full_du_norm = du_norm(controls, new_u)                          # :260-263
         index_decay = current_cost > OLD_COST

@@ -30,3 +30,39 @@ def to_dev(p, device="cuda"):
 
 def npy(t):
     return t.detach().cpu().numpy().astype(np.float64)
+
+
+# ---- line-search ties.  MPCstep.forward_rec accepts a step when `cost <= old cost` (mpc_step.py:196,266).  The
+# reference decides that in float64; where its margin (old - new) / max(1, |old|) is below what float32 resolves,
+# a float32 solver may legitimately stop at another step size of the same search.  Such rows are identified from the
+# float64 side and held to "equals ONE of the search's candidates"; every other row is held to the plain tolerance.
+TIE_MARGIN = 1e-6      # 8 float32 ulps of the trajectory cost
+
+
+def tie_rows(old_costs, new_costs):
+    margin = (np.asarray(old_costs) - np.asarray(new_costs)) / np.maximum(1.0, np.abs(old_costs))
+    return margin < TIE_MARGIN
+
+
+def assert_step_close(got_u, got_x, ref_u, ref_x, old_costs, ref_costs, candidates, tol, what=""):
+    """`candidates(rows, alpha)` -> (x, u) of the reference's line-search pass with step size alpha on those rows.
+    Returns (number of tie rows, number of them that stopped at another candidate than the reference)."""
+    ties = tie_rows(old_costs, ref_costs)
+    strict = ~ties
+    assert_close(got_u[:, strict], ref_u[:, strict], tol, what + " u (rows with a resolvable line-search margin)")
+    assert_close(got_x[:, strict], ref_x[:, strict], tol, what + " x (rows with a resolvable line-search margin)")
+    rows = np.nonzero(ties)[0]
+    forked = 0
+    if rows.size:
+        err = lambda a, b: (np.abs(a - b) / np.maximum(1.0, np.abs(b))).max(axis=(0, 2))   # noqa: E731
+        best = err(got_u[:, rows], ref_u[:, rows])
+        forked = int((best > tol).sum())
+        for p in range(0, 14):
+            if not (best > tol).any():
+                break
+            alpha = 0.0 if p == 13 else 0.2 ** p
+            xc, uc = candidates(rows, alpha)
+            best = np.minimum(best, np.maximum(err(got_u[:, rows], uc), err(got_x[:, rows], xc)))
+        assert (best <= tol).all(), "%s: tie rows %s match no candidate of the line search (worst %.2e)" % (
+            what, rows[best > tol][:8], best.max())
+    return int(ties.sum()), forked

@@ -1,0 +1,242 @@
+"""GPU: config 4 (pendulum imitation loop, env_dx/il_exp.py) and the pendulum callers against vectors recorded
+from the reference itself (tests/golden/make_golden.py: the unmodified reference on the numpy stand-in with a
+reverse-mode tape), plus the small rows: util helpers on the device, approximate.py through BoxDDP, the data set."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from chainer_differentiable_mpc_amd import BoxDDP, IL_Env, LinDx, MPCstep, PendulumDx, Pendulum_Net_cost_logit, QuadCost
+from chainer_differentiable_mpc_amd import make_dataset, synthetic
+from chainer_differentiable_mpc_amd.util import get_traj
+from tests.helpers import GOLDEN, assert_close, assert_step_close, npy, tie_rows
+from tests.test_host_cpu import helpers_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL_STEP = 2e-4     # one MPC step, float32 against the float64 reference
+
+
+def dev(a, dtype=torch.float32):
+    return None if a is None else torch.as_tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def test_util_helpers_match_the_oracle_on_the_device():
+    helpers_against_oracle("cuda")
+
+
+def test_pendulum_kernel_matches_the_reference_on_and_beyond_the_clamp():
+    """dmpc_pendulum_rollout_linearize against PendulumDx.forward + linearize_dynamics of the reference
+    (tests/golden/pendulum.npz), with torques exactly ON the clamp: d clip / du = 1 there"""
+    g = load("pendulum.npz")
+    dx = PendulumDx()
+    x, F, f = dx.rollout_linearize(dev(g["lin_x"][0]), dev(g["lin_u"]))
+    assert_close(npy(x), g["lin_x"], 2e-5, "x")
+    assert_close(npy(F), g["lin_F"], 2e-5, "F")
+    assert_close(npy(f), g["lin_f"], 5e-5, "f")
+    assert float((F[:, :2, 2, 3] - 0.15).abs().max()) < 1e-6       # u = +-2: the torque column is not zeroed
+    # single steps from arbitrary states
+    x1, _, _ = dx.rollout_linearize(dev(g["x"]), dev(np.stack((g["u"], g["u"]))), want_model=False)
+    assert_close(npy(x1[1]), g["next"], 2e-5, "next")
+    # torch twin on the device, autograd at the clamp
+    u = dev(g["lin_u"][0]).clone().requires_grad_(True)
+    dx(dev(g["lin_x"][0]), u)[:, 2].sum().backward()
+    assert float((u.grad[:2, 0] - 0.15).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_pendulum_box_ddp_iterates_match_the_reference(k):
+    """BoxDDP around the non-linear pendulum (config 2 family, B=16, T=20): the iterate returned after k outer
+    iterations by the unmodified reference (chainer.grad linearisation, PendulumDx as the true dynamics callable).
+    The swing-up iteration amplifies rounding, so float32 is held to 1e-3 on the controls; per-step parity at the
+    plain tolerance is test_imitation_step_config4_b1024 and test_box_ddp_gpu's common-iterate steps."""
+    g = load("pendulum_boxddp.npz")
+    B, T = int(g["B"]), int(g["T"])
+    dx = PendulumDx()
+    Q = np.tile(np.diag(g["q"]), (T, B, 1, 1))
+    pv = np.tile(g["p"], (T, B, 1))
+    for device_loop in (True, False):
+        solver = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, eps=dx.mpc_eps, max_iter=k, exit_unconverged=False,
+                        line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter, quiet=True,
+                        device_loop=device_loop)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, costs = solver((dev(g["x_init"]), QuadCost(dev(Q), dev(pv)), dx))
+        assert solver.status in str(g["stdout_%d" % k])
+        assert_close(npy(costs), g["costs_%d" % k], 1e-3, "costs after %d" % k)
+        assert_close(npy(u), g["u_%d" % k], 1e-3, "u after %d" % k)
+        assert_close(npy(x), g["x_%d" % k], 1e-3, "x after %d" % k)
+        sat_ref = np.abs(g["u_%d" % k]) == 2.0
+        assert (np.abs(npy(u)) == 2.0)[sat_ref].mean() > 0.98
+
+
+def _cost_from(logit, learn_p, T, B):
+    q = torch.sigmoid(logit)
+    p = torch.sqrt(q) * learn_p
+    Q = torch.diag(q)[None, None].expand(T, B, -1, -1).contiguous()          # il_env.py:117-129
+    pv = p[None, None].expand(T, B, -1).contiguous()
+    return Q, pv
+
+
+def test_imitation_step_config4_b1024():
+    """BASELINE.json configs[3] at full size, B=1024, T=20: from a common iterate (three box-DDP iterations of the
+    reference), ONE MPCstep (linearise the pendulum, PNQP backward sweep, line search on the true pendulum) and the
+    gradient node of BoxDDP (no-op MPCstep at the new point, mpc/box_ddp.py:234-259) with update_dynamics=False:
+    x', u', costs, dC, dc and the reduced parameter gradients (d logit, d learn_p) of il_env.py:104-158 /
+    pendulum_net.py:27-39 against the unmodified reference (tests/golden/imitation_step_1024.npz)."""
+    g = load("imitation_step_1024.npz")
+    B, T, S = int(g["B"]), int(g["T"]), g["sample"]
+    dx = PendulumDx()
+    np.random.seed(0)
+    xinit = dev(IL_Env.sample_xinit(B))
+    u_k = dev(g["u_k"])
+    lo, hi = torch.full((T, B, 1), -2.0, device="cuda"), torch.full((T, B, 1), 2.0, device="cuda")
+    logit = dev(g["logit"]).requires_grad_(True)
+    learn_p = dev(g["learn_p"]).requires_grad_(True)
+    Q, pv = _cost_from(logit, learn_p, T, B)
+    # -- the step (host loop body of BoxDDP: rollout + linearisation in one launch, then MPCstep)
+    with torch.no_grad():
+        x_k, Fk, fk = dx.rollout_linearize(xinit, u_k)
+        assert_close(npy(x_k[:, S]), g["x_k_s"], 2e-5, "x_k")
+        assert_close(npy(Fk[:, S]), g["F_k_s"], 2e-5, "F_k")
+        step = MPCstep(controls=u_k, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=3, n_ctrl=1, current_states=x_k,
+                       true_cost=QuadCost(Q.detach(), pv.detach()), true_dynamics=dx, ls_decay=dx.linesearch_decay,
+                       max_ls_iter=dx.max_linesearch_iter, need_expand=True)
+        x1, u1 = step.forward((x_k[0], Q.detach(), pv.detach(), Fk, fk))
+    # rows whose line search the reference decides by a margin float32 cannot resolve are held to "one of the
+    # candidates of the same search" (tests/helpers.py); candidates come from the (pinned) oracle's gains
+    from oracle import box_ddp as obox
+    from oracle import imitation as oim
+    from oracle import mpc as ompc
+    x0_64 = npy(xinit)
+    uk64 = g["u_k"].astype(np.float64)
+    xk64 = obox.get_traj(T, uk64, x0_64, obox.pendulum_step)
+    Fo, fo_ = obox.pendulum_linearize(xk64, uk64)
+    qo, po = oim.cost_from_params(g["logit"], g["learn_p"])
+    Qo, pvo = oim.tile_cost(qo, po, T, B)
+    lo64, hi64 = np.full((T, B, 1), -2.0), np.full((T, B, 1), 2.0)
+    old = ompc.get_cost(T, uk64, ompc.QuadCost(Qo, pvo), xk64)
+    tau = np.concatenate((xk64, uk64), axis=2)
+    Ko, ko, _, _ = ompc.mpc_backward_rec(Qo, np.einsum("tbij,tbj->tbi", Qo, tau) + pvo, Fo, None, uk64, lo64, hi64,
+                                         T, 3, 1, batch_coupled=True)
+    x1_ref, u1_ref, _ = ompc.ls_rollout(Ko, ko, uk64, xk64, lo64, hi64, ompc.QuadCost(Qo, pvo), obox.pendulum_step,
+                                        np.ones(B), T)
+    assert np.abs(u1_ref - g["u1"]).max() < 1e-6                     # golden: every row stops at alpha = 1
+
+    def candidates(rows, alpha):
+        xc, uc, _ = ompc.ls_rollout(Ko[:, rows], ko[:, rows], uk64[:, rows], xk64[:, rows], lo64[:, rows],
+                                    hi64[:, rows], ompc.QuadCost(Qo[:, rows], pvo[:, rows]), obox.pendulum_step,
+                                    np.full(len(rows), alpha), T)
+        return xc, uc
+
+    n_tie, n_fork = assert_step_close(npy(u1), npy(x1), u1_ref, x1_ref, old, g["costs"], candidates, TOL_STEP, "step")
+    strict = ~tie_rows(old, g["costs"])
+    assert strict.sum() >= 300                                        # a third of the batch is NOT a tie
+    assert_close(npy(x1[:, S]), np.where(strict[S][None, :, None], g["x1_s"], npy(x1[:, S])), TOL_STEP, "x' vs golden")
+    assert_close(npy(step.for_out.costs), g["costs"], TOL_STEP, "costs")      # a fork moves the cost by < its margin
+    sat = (np.abs(g["u1"]) == 2.0)[:, strict]
+    assert ((np.abs(npy(u1)) == 2.0)[:, strict] == sat).mean() > 0.9995      # the active set of the gradient node
+    # -- the gradient node at the reference's new point (so that both sides differentiate the same iterate)
+    u1r = dev(g["u1"])
+    x1r, F1, f1 = dx.rollout_linearize(xinit, u1r)
+    node = MPCstep(controls=u1r, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=3, n_ctrl=1, current_states=x1r,
+                   true_cost=QuadCost(Q.detach(), pv.detach()), true_dynamics=dx, ls_decay=dx.linesearch_decay,
+                   max_ls_iter=dx.max_linesearch_iter, need_expand=True, no_op_forward=True)
+    Q.retain_grad()
+    pv.retain_grad()
+    x2, u2 = node.apply((x1r[0], Q, pv, F1, f1))
+    loss = ((dev(g["expert_u"]) - u2) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert_close(npy(Q.grad[:, S]), g["dC_s"], 1e-6, "dC")            # entries are O(1e-5): absolute 1e-6 of max(1, .)
+    scale = np.abs(g["dC_s"]).max()
+    assert np.abs(npy(Q.grad[:, S]) - g["dC_s"]).max() <= 5e-4 * scale
+    assert np.abs(npy(pv.grad[:, S]) - g["dc_s"]).max() <= 5e-4 * np.abs(g["dc_s"]).max()
+    for got, ref, name in ((logit.grad, g["g_logit"], "d logit"), (learn_p.grad, g["g_p"], "d learn_p")):
+        assert np.abs(npy(got) - ref).max() <= 1e-3 * np.abs(ref).max(), (name, npy(got), ref)
+
+
+def test_imitation_chain_small_against_the_reference():
+    """the whole chain of config 4 at B=16 (Pendulum_Net_cost_logit -> IL_Env.mpc, 5 iLQR iterations -> loss ->
+    gradients, incl. the detach mask of unconverged samples) against tests/golden/imitation_16.npz.  Over five
+    iterations a float32 line-search tie (tests/helpers.py) moves a control by at most its feed-forward step
+    (|k| ~ 1e-2 when the cost margin is below float32 resolution): 95 % of the entries are held to 2e-4, all to 1e-2."""
+    g = load("imitation_16.npz")
+    B, T = int(g["B"]), int(g["T"])
+    env = IL_Env('pendulum', lqr_iter=int(g["lqr_iter"]), mpc_T=T)
+    net = Pendulum_Net_cost_logit(4)
+    with torch.no_grad():
+        net.learn_q_logit.copy_(dev(g["q_logit"]))
+        net.learn_p.copy_(dev(g["learn_p"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # the expert under the true cost (il_env.py:86-95)
+        tq, tp = env.true_dx.get_true_obj()
+        with torch.no_grad():
+            ex, eu = env.mpc(env.true_dx, g["xinit"], tq, tp, update_dynamics=True)
+        assert_close(npy(eu), g["expert_u"], 2e-3, "expert u")
+        nom_x, nom_u = net(dev(g["xinit"]), env, np.zeros((B, T, 1), dtype=np.float32))
+    assert_close(npy(nom_u), g["nom_u"], 1e-2, "nominal u")
+    assert_close(npy(nom_x), g["nom_x"], 1e-2, "nominal x")
+    assert np.mean(np.abs(npy(nom_u) - g["nom_u"]) <= 2e-4) >= 0.95
+    loss = ((dev(g["expert_u"]) - nom_u) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 5e-3 * float(g["loss"])
+    for got, ref in ((net.learn_q_logit.grad, g["g_logit"]), (net.learn_p.grad, g["g_p"])):
+        assert np.abs(npy(got) - ref).max() <= 5e-2 * np.abs(ref).max(), (npy(got), ref)
+
+
+def test_gradient_reaches_learnable_nonlinear_dynamics_and_cost():
+    """BoxDDP with update_dynamics=True and a non-LinDx dynamics whose parameters require grad (learn_dx mode of the
+    reference: f_t stays on the graph, mpc/approximate.py:106), and a learnable non-quadratic cost
+    (approximate_cost keeps `grad - H tau` on the graph, :47): parameters receive finite non-zero gradients"""
+    T, B, nx, nu = 6, 8, 3, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=4, with_f=True)
+    A = torch.nn.Parameter(0.9 * torch.eye(nx, device="cuda"))
+    Bm = torch.nn.Parameter(0.3 * torch.ones((nx, nu), device="cuda"))
+
+    def dyn(x, u):
+        return torch.tanh(x @ A.T + u @ Bm.T)
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        solver = BoxDDP(T, -0.5, 0.5, B, nx, nu, None, max_iter=4, quiet=True, detach_unconverged=False)
+        x, u, _ = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), dyn))
+        (x.sum() + u.sum()).backward()
+    for prm in (A, Bm):
+        assert prm.grad is not None and torch.isfinite(prm.grad).all() and float(prm.grad.abs().max()) > 0
+    w = torch.nn.Parameter(torch.tensor([1.0, 2.0, 0.5, 1.5, 0.25], device="cuda"))
+
+    def cost(tau):
+        return 0.5 * (tau * tau * w).sum(1) + torch.cos(tau).sum(1) * 0.1
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        solver = BoxDDP(T, -0.5, 0.5, B, nx, nu, None, max_iter=4, quiet=True, detach_unconverged=False,
+                        update_dynamics=False)
+        x, u, _ = solver((dev(p["x_init"]), cost, LinDx(dev(p["F"]), dev(p["f"]))))
+        (x.sum() + u.sum()).backward()
+    assert w.grad is not None and torch.isfinite(w.grad).all() and float(w.grad.abs().max()) > 0
+
+
+def test_make_dataset_writes_the_reference_format(tmp_path):
+    """env_dx/make_dataset.py:16-34: IL_Env populated under the true cost, pickled; loads back (il_exp.py:44-45)"""
+    path = os.path.join(str(tmp_path), "data", "pendulum.pkl")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = make_dataset.main(6, 2, 2, path=path, lqr_iter=4)
+    assert out == path and os.path.exists(path)
+    env = make_dataset.load(path)
+    assert list(env.train_data.shape) == [6, 20, 4] and list(env.val_data.shape) == [2, 20, 4]
+    assert env.train_data.is_cuda and float(env.train_data[:, :, 3].abs().max()) <= 2.0 + 1e-6
+    np.random.seed(0)
+    assert_close(npy(env.train_data[:, 0, :3]), IL_Env.sample_xinit(10)[:6], 1e-6, "x_init")
+    # every stored trajectory is the pendulum rolled out under its controls
+    x = get_traj(20, env.train_data[:, :, 3:].transpose(0, 1), env.train_data[:, 0, :3], env.true_dx)
+    assert_close(npy(x.transpose(0, 1)), npy(env.train_data[:, :, :3]), 1e-4, "rollout")

@@ -121,3 +121,28 @@ def test_headline_shape_sampled_oracle_and_linearity():
     sel = [npy(out1[0])[idx], npy(out1[1])[:, idx], npy(out1[2])[:, idx], npy(out1[3])[:, idx], npy(out1[4])[:, idx]]
     for got, want, key in zip(sel, ref, KEYS):
         assert_close(got, want, TOLS[key], key)
+
+
+def test_two_forwards_before_backward_keep_their_own_state():
+    """one DiffLqr object (as in LqrNet) applied twice before any backward - summed minibatches, a validation pass
+    in between: each graph differentiates its own retained tensors"""
+    import torch
+    from chainer_differentiable_mpc_amd import DiffLqr
+    T, B, nx, nu = 6, 5, 4, 2
+    layer = DiffLqr(T, B, nx, nu)
+    probs = [synthetic.make_lqr_problem(B, T, nx, nu, seed=s) for s in (21, 22)]
+    grads = []
+    for order in ("separate", "interleaved"):
+        Fs = [torch.as_tensor(p["F"], dtype=torch.float32, device="cuda").requires_grad_(True) for p in probs]
+        outs = []
+        for p, F in zip(probs, Fs):
+            d = to_dev(p)
+            x, u = layer.apply((d["x_init"], d["C"], d["c"], F, d["f"]))
+            outs.append(x.sum() + (u ** 2).sum())
+            if order == "separate":
+                outs[-1].backward()
+        if order == "interleaved":
+            (outs[0] + outs[1]).backward()
+        grads.append([npy(F.grad) for F in Fs])
+    for a, b in zip(grads[0], grads[1]):
+        assert np.array_equal(a, b)

@@ -29,6 +29,11 @@ def test_notebook_anchor():
     assert list(LU.shape) == [2, 4, 4] and piv.dtype == torch.int32
 
 
+# rows (of 16) whose iteration count may differ by one from the float64 reference (threshold ties), per case
+MAX_TIE_ROWS = {(1, "cold"): 0, (1, "warm"): 0, (2, "cold"): 2, (2, "warm"): 2, (4, "cold"): 2, (4, "warm"): 2,
+                (8, "cold"): 3, (8, "warm"): 3}
+
+
 @pytest.mark.parametrize("n", [1, 2, 4, 8])
 @pytest.mark.parametrize("tag", ["cold", "warm"])
 def test_per_row_golden(n, tag):
@@ -43,10 +48,64 @@ def test_per_row_golden(n, tag):
     np.testing.assert_array_equal(npy(idx_f), g[tag + "_row_idx_f"])          # identical active sets
     assert_close(npy(x), g[tag + "_row_x"], 1e-4, "x")
     iters = PNQP.last_info["iters"].cpu().numpy()
-    assert np.mean(iters == g[tag + "_row_it"]) >= 0.85, (iters, g[tag + "_row_it"])
+    # iteration counts are exact except where the reference's final |dx| sits within float32 resolution of the 1e-4
+    # threshold (then one more / one fewer pass is a tie, not an error): such rows are counted and bounded
+    off = iters != g[tag + "_row_it"]
+    assert np.all(np.abs(iters - g[tag + "_row_it"])[off] == 1), (iters, g[tag + "_row_it"])
+    assert off.sum() <= MAX_TIE_ROWS[(n, tag)], (n, tag, int(off.sum()), np.nonzero(off)[0])
     assert (len(w) > 0) == bool(g[tag + "_row_warned"].any())
     # box feasibility is exact
     assert (npy(x) >= p["lower"] - 1e-7).all() and (npy(x) <= p["upper"] + 1e-7).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8])
+@pytest.mark.parametrize("tag", ["cold", "warm"])
+def test_batched_golden_with_batch_coupled_termination(n, tag):
+    """the reference called on the whole batch (tests/golden/pnqp_n*.npz, plain keys): convergence and Armijo tests
+    reduced over the batch (pnqp.py:139-144,172,187) - `batch_coupled=True`, one grid-wide reduction per decision"""
+    g = np.load(os.path.join(GOLDEN, "pnqp_n%d.npz" % n))
+    B = int(g["B"])
+    p = synthetic.make_box_qp(B, n, seed=int(g["seed"]), bound=0.5)
+    x0 = None if tag == "cold" else dev(g["warm"])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x, fac, idx_f, i = PNQP(dev(p["H"]), dev(p["q"]), dev(p["lower"]), dev(p["upper"]), x_init=x0, n_iter=20,
+                                batch_coupled=True)
+    np.testing.assert_array_equal(npy(idx_f), g[tag + "_idx_f"])
+    assert_close(npy(x), g[tag + "_x"], 1e-4, "x")
+    assert i == int(g[tag + "_it"])                                   # the batch-global iteration index, exactly
+    assert bool((PNQP.last_info["iters"] == i).all())
+    assert (len(w) > 0) == bool(g[tag + "_warned"])
+    if n == 1:
+        assert_close(npy(fac), g[tag + "_Hf"], 1e-4, "H_f")
+    else:
+        np.testing.assert_array_equal(fac[1].cpu().numpy(), g[tag + "_piv"])
+        assert_close(npy(fac[0]), g[tag + "_LU"], 1e-4, "LU")
+
+
+def test_batch_coupling_fork_matches_the_reference():
+    """n=8, B=256 (tests/golden/pnqp_n8_b256.npz): one grid, two workgroups.  Under the batch-global
+    tests a row that fails its Armijo test takes the failing step anyway once ANY other row passes; it ends O(1)
+    away from its batch-of-one answer and the batch runs into the iteration cap.  Both modes against the reference."""
+    g = np.load(os.path.join(GOLDEN, "pnqp_n8_b256.npz"))
+    B, n = int(g["B"]), int(g["n"])
+    p = synthetic.make_box_qp(B, n, seed=int(g["seed"]), bound=float(g["bound"]), reg=float(g["reg"]))
+    args = (dev(p["H"]), dev(p["q"]), dev(p["lower"]), dev(p["upper"]))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        x, (LU, piv), idx_f, i = PNQP(*args, n_iter=20, batch_coupled=True)
+    assert len(w) > 0 and bool(g["warned"]) and i == int(g["it"]) == 19
+    forked = np.abs(g["x"] - g["row_x"]).max(axis=1) > 1e-3
+    assert forked.sum() >= 1 and np.abs(g["x"] - g["row_x"]).max() > 1.0
+    assert_close(npy(x)[~forked], g["x"][~forked], 1e-4, "x, rows that do not fork")
+    # the forked rows oscillate between clamped Newton steps; float32 follows the same orbit
+    assert_close(npy(x)[forked], g["x"][forked], 2e-3, "x, forked rows")
+    np.testing.assert_array_equal(npy(idx_f), g["idx_f"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xr, _, _, ir = PNQP(*args, n_iter=20)
+    assert_close(npy(xr), g["row_x"], 1e-4, "per-row x")
+    assert float((xr - x).abs().max()) > 1.0
 
 
 @pytest.mark.parametrize("n", [2, 3, 5, 8])
