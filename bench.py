@@ -87,7 +87,7 @@ def kernel_name(T, B, nx, nu):
             2: "void dmpc::lqr_dma_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
             3: "void dmpc::lqr_asm_kernel<%d, %d, true, false, false, false>(dmpc::LqrArgs)" % (nx, nu),
             4: "void dmpc::lqr_asm_kernel<%d, %d, true, false, true, false>(dmpc::LqrArgs)" % (nx, nu),
-            5: "void dmpc::lqr_wave_mfma_backward<%d, %d>(dmpc::LqrArgs) + forward-only dmpc::lqr_kernel" % (nx, nu)
+            5: "void dmpc::lqr_wave_mfma_backward<%d, %d, false, true>(dmpc::LqrArgs)" % (nx, nu)
             }.get(path, "?")
 
 

@@ -11,7 +11,7 @@
 #include "lqr_dma_kernel.hpp"
 #include "lqr_generic.hpp"
 #include "lqr_kernels.hpp"
-#include "lqr_wave_mfma.hpp"
+#include "lqr_wave_api.hpp"
 
 namespace dmpc {
 
@@ -59,7 +59,7 @@ static int solve_path(int T, int B) {
     using Lay = LqrDmaLayout<NX, NU, kDmaDepthB, kDmaDepthF>;
     if (B >= 4 && T >= 2 && Lay::lds_bytes(T) <= kDmaLdsBudget && !dma_path_disabled()) return 2;
   }
-  if constexpr (L == 64 && NX % 4 == 0 && (NX + NU) % 4 == 0) {
+  if constexpr (L == 64 && NX % 4 == 0 && NU % 4 == 0) {
     if (!wave_mfma_disabled()) return 5;
   }
   return 1;
@@ -131,17 +131,14 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #undef DMPC_ASM_LAUNCH
     }
   }
-  if constexpr (L == 64 && NX % 4 == 0 && (NX + NU) % 4 == 0) {
-    // large shapes: backward sweep on the matrix cores (lqr_wave_mfma.hpp), gains through HBM, then the
-    // bandwidth-bound forward-only kernel
-    if (!masked && mode != kForwardOnly && !wave_mfma_disabled()) {
+  if constexpr (L == 64 && NX % 4 == 0 && NU % 4 == 0) {
+    // large shapes: backward sweep on the matrix cores (lqr_wave_mfma.hpp, its own translation unit; plain and
+    // LQR_active), gains through HBM, then the bandwidth-bound forward-only kernel
+    if (mode != kForwardOnly && !wave_mfma_disabled()) {
       LqrArgs s = a;
       if (s.Ks == nullptr && s.wsK == nullptr) return DMPC_E_WORKSPACE;
-      hipLaunchKernelGGL((lqr_wave_mfma_backward<NX, NU>), dim3((a.B + 3) / 4), block, 0, stream, s);
-      if (mode == kBackwardOnly) return (int)hipGetLastError();
-      if (s.Ks == nullptr) { s.Ks = s.wsK; s.ks = s.wsk; }
-      hipLaunchKernelGGL((lqr_kernel<NX, NU, L, false, kForwardOnly, false>), grid, block, 0, stream, s);
-      return (int)hipGetLastError();
+      // solve_recursion: the wavefront that finished a trajectory's backward sweep rolls it out in the same launch
+      return launch_lqr_wave_mfma_backward(NX, NU, masked, mode == kSolve, s, stream);
     }
   }
   if constexpr (L == 16) {

@@ -1,0 +1,26 @@
+// lqr_wave_api.hip - instances and launcher of lqr_wave_mfma_backward (LqrRecursion.backward, lqr/lqr_recursion.py:69-158,
+// and LQR_active's sweep, mpc/active_constrained_lqr.py:67-151, at the large shapes).
+#include <hip/hip_runtime.h>
+
+#include "../../include/dmpc.h"
+#include "lqr_wave_api.hpp"
+#include "lqr_wave_mfma.hpp"
+
+namespace dmpc {
+
+int launch_lqr_wave_mfma_backward(int nx, int nu, bool masked, bool rollout, const LqrArgs &a, hipStream_t stream) {
+  const dim3 grid((a.B + 3) / 4), block(256);   // four wavefronts (= trajectories) per workgroup, one per SIMD
+#define X(NX_, NU_)                                                                                       \
+  if (nx == NX_ && nu == NU_) {                                                                           \
+    if (masked && rollout) hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, true, true>), grid, block, 0, stream, a);   \
+    else if (masked) hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, true, false>), grid, block, 0, stream, a);        \
+    else if (rollout) hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, false, true>), grid, block, 0, stream, a);       \
+    else hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, false, false>), grid, block, 0, stream, a);                   \
+    return (int)hipGetLastError();                                                                        \
+  }
+  X(32, 8)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
+}  // namespace dmpc

@@ -1,0 +1,14 @@
+// lqr_wave_api.hpp - launcher of the matrix-core backward sweep for the large shapes (lqr_wave_mfma.hpp), kept in its
+// own translation unit (lqr_wave_api.hip) so that the kernel can be rebuilt without the generated streams of lqr_api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lqr_kernels.hpp"
+
+namespace dmpc {
+
+// Ks/ks of `a` receive the gains; with `rollout` the same launch goes on with the forward sweep (x, u of `a`).
+// Returns 0, a hipError_t or DMPC_E_UNSUPPORTED for a shape without an instance.
+int launch_lqr_wave_mfma_backward(int nx, int nu, bool masked, bool rollout, const LqrArgs &a, hipStream_t stream);
+
+}  // namespace dmpc

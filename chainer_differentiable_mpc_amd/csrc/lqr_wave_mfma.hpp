@@ -1,20 +1,33 @@
 // lqr_wave_mfma.hpp - backward Riccati sweep for the large shapes (one wavefront per trajectory, ns + 1 <= 64,
-// nx and ns multiples of 4 - (32,8) of BASELINE.json configs[4]) with every A^T B product on the matrix cores.
+// nx, nu and ns multiples of 4 - (32,8) of BASELINE.json configs[4]) with every A^T B product on the matrix cores.
 //
 // Same recursion and column-per-lane layout as lqr_kernel<NX, NU, 64, ...> (lqr/lqr_recursion.py:69-158): lane j
-// holds column j of [C|c], [F|f], [V|v]; the affine column is lane ns.  What changes is who multiplies:
+// holds column j of [C|c], [F|f], [V|v]; the affine column is lane ns.  Who multiplies:
 //   v_mfma_f32_4x4x1_16b_f32 with cbsz:4 abid:I takes 4 lanes (block I) of the A register and all 64 lanes of the B
 //   register and adds the outer product to a 4-row tile held in 4 consecutive registers:
 //       D[4I + i][j] += A[lane 4I + i] * B[lane j]                        (one trajectory per wavefront)
 //   i.e. it computes P^T R from column-per-lane P and R, one contraction index per instruction.  With the
 //   reference's own association  Q~ = C~ + (F^T V) F~  (lqr_recursion.py:89,96) both products have that shape:
-//       G  = V^^T F~        rows b = columns of [V|v] (tile 10, row 0 is the homogeneous row g1 = v^T F~)
+//       G  = V^^T F~        rows b = columns of [V|v] (tile TA, row 0 is the homogeneous row g1 = v^T F~)
 //       Q~ += G^T F~ + g1 (x) e_aff
-//   and so has K~^T (Q~u. + Quu K~) of the value update.  Qxu K~ (an A B product) gets its left factor as a row matrix XU = (F~^T G)[u rows] from the same pass.
-// At (32,8) that is 288 + 330 + 64 MFMAs per timestep instead of ~4,600 readlane/FMA pairs; the HIP kernel it
-// replaces spilled 1.5 KB of scratch per lane and ran at 0.03 of the HBM roof.
+//   and so has Qxu K~ of the value update once Qxu is held as a row matrix XU = (F~^T G)[u rows] (same pass).
+//
+// fp32 MFMA runs on the same FMA lanes as the VALU (their times add up, profiles/r01/microbench_mfma16_shadow.txt),
+// so a timestep costs (MFMAs x 8 + other instructions x 4) cycles plus whatever latency is exposed.  Round 2 removes
+// the "other" part and the exposed latency:
+//   * inputs of step t-1 are fetched while step t computes (two register banks, one wavefront per SIMD with the
+//     accumulation registers as the second half of the file), through buffer loads whose address is an SGPR
+//     descriptor + a per-lane constant + an immediate - no 64-bit pointer steps on the VALU; lanes beyond the
+//     matrix read out of range (= 0), lane ns gets c / f by one exec-masked block of 16-byte loads;
+//   * the gains come from a Gauss-Jordan elimination carried out ON the rows of [Qux | Quu | qu] as they lie
+//     (one readlane per multiplier, one FMA per row) instead of an 8 x 8 LU replicated in every lane; partial
+//     pivoting (LAPACK's choice of row) sits behind a uniform branch taken only when a row really has to move;
+//   * V~ = Q~x. + Qxu K~ : the fourth term K~^T (Q~u. + Quu K~) of lqr_recursion.py:151-152 multiplies the RESIDUAL of
+//     the gain solve (Quu K~ = -Q~u. up to rounding) and is left out here; the masked variant (LQR_active,
+//     mpc/active_constrained_lqr.py:110-145), where K~ solves the MASKED system and V~ uses the unmasked blocks,
+//     computes it in full.
 // The gains go to HBM (caller's Ks/ks or the workspace): at this size they do not fit in LDS; the rollout is the
-// forward-only lqr_kernel, which is already bandwidth bound.
+// forward-only lqr_kernel, which is bandwidth bound.
 #pragma once
 #include "colwise.hpp"
 #include "lqr_kernels.hpp"
@@ -22,223 +35,368 @@
 namespace dmpc {
 
 typedef float f4v __attribute__((ext_vector_type(4)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 template <int I>
 __device__ __forceinline__ f4v mfma_bcast(float a, float b, f4v c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, I, 0);  // cbsz = 4: block I of A feeds all 16 blocks
 }
 
-// LU with partial pivoting of a WAVE-UNIFORM matrix (every lane holds the same A - one trajectory per wavefront)
-// applied to the lane's own right-hand side: the pivot row is a scalar, so the interchange (select chains, 600
-// v_cndmask at n = 8 in lu_factor_inplace) sits behind a uniform branch that is taken only when a row really moves.
-// LAPACK getf2/getrs order: first maximum wins, one interchange per column, scaling by the reciprocal pivot.
-template <int N>
-__device__ __forceinline__ bool lu_factor_solve_uniform(float (&A)[N][N], float (&x)[N]) {
-  bool singular = false;
-  static_for<0, N>([&](auto kc) {
-    constexpr int k = kc.value;
-    float best = fabsf(A[k][k]);
-    int p = k;
-#pragma unroll
-    for (int i = k + 1; i < N; ++i) {
-      const float v = fabsf(A[i][k]);
-      const bool gt = v > best;
-      best = gt ? v : best;
-      p = gt ? i : p;
-    }
-    p = __builtin_amdgcn_readfirstlane(p);
-    if (p != k) {  // uniform and rare for the well-conditioned Quu of an LQR: one branch around the select chain
-#pragma unroll
-      for (int c = 0; c < N; ++c) {
-        const float ak = A[k][c];
-        float nk = ak;
-#pragma unroll
-        for (int i = k + 1; i < N; ++i) {
-          const bool sw = (p == i);
-          nk = sw ? A[i][c] : nk;
-          A[i][c] = sw ? ak : A[i][c];
-        }
-        A[k][c] = nk;
-      }
-      const float xk = x[k];
-      float nx_ = xk;
-#pragma unroll
-      for (int i = k + 1; i < N; ++i) {
-        const bool sw = (p == i);
-        nx_ = sw ? x[i] : nx_;
-        x[i] = sw ? xk : x[i];
-      }
-      x[k] = nx_;
-    }
-    const float d = A[k][k];
-    singular = singular || (d == 0.0f);
-    const float r = fast_rcp(d);
-#pragma unroll
-    for (int i = k + 1; i < N; ++i) {
-      const float l = A[i][k] * r;
-      A[i][k] = l;
-#pragma unroll
-      for (int c = k + 1; c < N; ++c) A[i][c] = fmaf(-l, A[k][c], A[i][c]);
-      x[i] = fmaf(-l, x[k], x[i]);  // forward substitution rides along (the interchanges of later columns
-                                     // permute x and the stored multipliers together, as getrs does)
-    }
-    A[k][k] = r;  // keep the reciprocal pivot
-  });
-#pragma unroll
-  for (int k = N - 1; k >= 0; --k) {
-    x[k] = x[k] * A[k][k];
-#pragma unroll
-    for (int i = 0; i < k; ++i) x[i] = fmaf(-A[i][k], x[k], x[i]);
-  }
-  return singular;
+// raw buffer descriptor (gfx9 layout: 48-bit base, stride 0, num_records in bytes, DATA_FORMAT 32): an access at or
+// beyond num_records returns 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const void *base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
+}
+template <int BYTE_OFF>
+__device__ __forceinline__ float wave_load(__amdgpu_buffer_rsrc_t r, int voff) {
+  // the immediate of a buffer load holds 12 bits: rows further down go through the scalar offset
+  constexpr int kImm = BYTE_OFF % 4096, kS = BYTE_OFF - kImm;
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + kImm, kS, 0));
 }
 
-template <int NX, int NU>
-__global__ __launch_bounds__(256, 2) void lqr_wave_mfma_backward(const LqrArgs a) {  // 2 waves per SIMD: <= 256 registers
+constexpr int kOutOfRange = 0x40000000;
+
+// Closed-loop rollout (LqrRecursion.forward, lqr/lqr_recursion.py:160-200) by the wavefront that has just finished the
+// backward sweep of the same trajectory: while it waits on memory here, the other wavefront of its SIMD is in the
+// compute-bound sweep of ANOTHER trajectory, so the bandwidth-bound and the compute-bound halves of the solve overlap
+// instead of running as two launches one after the other.  Row-per-lane: lane k < nx holds row k of [F_t | f_t], lane
+// nx+m row m of [K_t | 0 | k_t]; ONE pass  acc = aff + sum_i w[i] x_t[i]  (x_t[i] by readlane) gives the state part of
+// x_{t+1} in the F lanes and u_t in the K lanes, then  acc += w[nx+m] u_t[m]  completes x_{t+1}.  The gains were
+// written by this wavefront (other lanes) moments ago: they are read back with glc (from L2, never a stale L1 line).
+template <int NX, int NU, bool MASKED>
+__device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, const int lane, const bool live,
+                                             const float *Ks, const float *ks, int &info_bits) {
+  constexpr int NS = NX + NU, TS = NS / 4, TX = NX / 4;
+  using G64 = Group<64>;
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const bool has_f = a.f != nullptr;
+  const bool f_lane = lane < NX, g_lane = lane >= NX && lane < NS;
+  const int voff_f = f_lane ? lane * NS * 4 : kOutOfRange, voff_f1 = f_lane ? lane * 4 : kOutOfRange;
+  const int voff_k = g_lane ? (lane - NX) * NX * 4 : kOutOfRange, voff_k1 = g_lane ? (lane - NX) * 4 : kOutOfRange;
+  struct Row {   // NB: never __builtin_bit_cast a vector ELEMENT (hipcc 7.2 then reads element 0): whole vectors only
+    f4v w[TS];
+    float aff;
+    unsigned act;
+  };
+  auto fetch = [&](int t, Row &r) {
+    if (t >= T) return;   // uniform
+    const size_t tb = (size_t)t * B + b;
+    const __amdgpu_buffer_rsrc_t rK = wave_rsrc(Ks + tb * NU * NX, NU * NX * 4), rk = wave_rsrc(ks + tb * NU, NU * 4);
+    u4v wk[TX];
+#pragma unroll
+    for (int q = 0; q < TX; ++q) wk[q] = __builtin_amdgcn_raw_buffer_load_b128(rK, voff_k + 16 * q, 0, 1);   // glc
+    unsigned aff = __builtin_amdgcn_raw_buffer_load_b32(rk, voff_k1, 0, 1);
+    u4v wf[TS];
+    if (t < T - 1) {
+      const __amdgpu_buffer_rsrc_t rF = wave_rsrc(a.F + tb * NX * NS, NX * NS * 4);
+#pragma unroll
+      for (int q = 0; q < TS; ++q) wf[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, voff_f + 16 * q, 0, 0);
+      if (has_f) aff |= __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(a.f + tb * NX, NX * 4), voff_f1, 0, 0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < TS; ++q) wf[q] = u4v{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int q = 0; q < TS; ++q) {   // a lane is in one of the two row sets; the other load gave it 0
+      const u4v m = q < TX ? (wf[q] | wk[q < TX ? q : 0]) : wf[q];
+      r.w[q] = __builtin_bit_cast(f4v, m);
+    }
+    r.aff = __builtin_bit_cast(float, aff);
+    if constexpr (MASKED) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) bits |= (a.mask[tb * NU + m] != 0 ? 1u : 0u) << m;
+      r.act = __builtin_amdgcn_readfirstlane(bits);
+    }
+  };
+  float xv = f_lane ? a.x_init[(size_t)b * NX + lane] : 0.f;
+  bool bad = false;
+  auto fstep = [&](int t, const Row &r) {
+    const size_t tb = (size_t)t * B + b;
+    if (f_lane && live) a.x[tb * NX + lane] = xv;
+    float acc[4] = {r.aff, 0.f, 0.f, 0.f};
+    static_for<0, NX>([&](auto i) {
+      const float w = r.w[i.value / 4][i.value % 4];
+      acc[i.value % 4] = fmaf(w, G64::template bcast<i.value>(xv), acc[i.value % 4]);   // :177 and the state part of :189
+    });
+    float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    float uo = s;
+    if constexpr (MASKED) uo = (g_lane && ((r.act >> (lane - NX)) & 1u)) ? 0.f : s;       // :179-183
+    if (g_lane && live) a.u[tb * NU + (lane - NX)] = uo;
+    bad = bad || ((f_lane || g_lane) && !(fabsf(uo) <= 3.0e38f)) || (f_lane && !(fabsf(xv) <= 3.0e38f));
+    static_for<0, NU>([&](auto m) {
+      const float w = r.w[(NX + m.value) / 4][(NX + m.value) % 4];
+      s = fmaf(w, G64::template bcast<NX + m.value>(uo), s);                              // control part of :189
+    });
+    if (f_lane) xv = s;
+  };
+  // a step is ~100 instructions, a trip to HBM several times that: rows are requested kRing steps ahead
+  constexpr int kRing = 4;
+  Row ring[kRing];
+  static_for<0, kRing - 1>([&](auto j) { fetch(j.value, ring[j.value]); });
+  for (int t0 = 0; t0 < T; t0 += kRing) {
+    static_for<0, kRing>([&](auto j) {
+      const int t = t0 + j.value;
+      if (t < T) {   // uniform
+        fetch(t + kRing - 1, ring[(j.value + kRing - 1) % kRing]);
+        fstep(t, ring[j.value]);
+      }
+    });
+  }
+  if (bad) info_bits |= 2;
+}
+
+
+#ifndef DMPC_WAVE_PREFETCH
+#define DMPC_WAVE_PREFETCH 0
+#endif
+// DMPC_WAVE_PREFETCH 1: one wavefront per SIMD (512 registers), inputs of the next step in a second register bank;
+//                    0: two wavefronts per SIMD (256 registers each), each hides the other's latencies
+// ROLLOUT: the wavefront goes on with the forward sweep of its trajectory (solve_recursion in ONE launch)
+template <int NX, int NU, bool MASKED, bool ROLLOUT>
+__global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma_backward(const LqrArgs a) {
   constexpr int NS = NX + NU, AFF = NS;
-  static_assert(NX % 4 == 0 && NS % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
-  constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4;  // tiles: x rows, all rows, the tile whose row 0 is `aff`
+  static_assert(NX % 4 == 0 && NU % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
+  constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4, TU = NU / 4;
   using G64 = Group<64>;
 
   const int lane = threadIdx.x & 63;
   int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   const bool live = b < a.B;
   if (!live) b = a.B - 1;
+  b = __builtin_amdgcn_readfirstlane(b);
   const int T = a.T;
   const size_t B = (size_t)a.B;
   const bool has_f = a.f != nullptr;
   const bool col_aff = lane == AFF;
-  const int lane_c = lane < NS ? lane : NS - 1;
   const bool k_lane = lane < NX || col_aff;
   const float eaff = col_aff ? 1.f : 0.f;
+  const int voff_col = lane < NS ? lane * 4 : kOutOfRange;                  // column `lane` of a row of C / F
+  const int voff_xu = lane < NX ? lane * NS * 4 + NX * 4 : kOutOfRange;     // row `lane` of C, control columns
   float *Ks = a.Ks != nullptr ? a.Ks : a.wsK;
   float *ks = a.Ks != nullptr ? a.ks : a.wsk;
   int info_bits = 0;
 
+  struct Bank {
+    f4v Q4[TS];    // rows of [C_t | c_t], column-per-lane
+    float Fc[NX];  // rows of [F_t | f_t]
+    f4v XU4[TU];   // XU[m] = column nx+m of C_t's x rows as a ROW (lane i = C[i][nx+m])
+    unsigned act;  // MASKED: bit m = control m is clamped at this step
+  };
+
+  // The fetch of a step is issued in two parts (cost rows at the top of the previous step, dynamics rows after its
+  // first product): at most 63 vector-memory instructions can be outstanding per wavefront, a 64th stalls the
+  // wave until the oldest has returned.
+  auto fetch_cost = [&](int t, Bank &k) {
+    if (t < 0) return;   // uniform
+    const size_t tb = (size_t)t * B + b;
+    const __amdgpu_buffer_rsrc_t rc = wave_rsrc(a.C + tb * NS * NS, NS * NS * 4);
+    static_for<0, NS>([&](auto i) { k.Q4[i.value / 4][i.value % 4] = wave_load<i.value * NS * 4>(rc, voff_col); });
+    static_for<0, TU>([&](auto q) {
+      k.XU4[q.value] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rc, voff_xu + 16 * q.value, 0, 0));
+    });
+    if (col_aff) {   // the affine column: c_t is a contiguous run, fetched by lane ns alone
+      const f4v *cp = reinterpret_cast<const f4v *>(a.c + tb * NS);
+#pragma unroll
+      for (int I = 0; I < TS; ++I) k.Q4[I] = cp[I];
+    }
+    if constexpr (MASKED) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) bits |= (a.mask[tb * NU + m] != 0 ? 1u : 0u) << m;
+      k.act = __builtin_amdgcn_readfirstlane(bits);
+    }
+  };
+  auto fetch_dyn = [&](int t, Bank &k) {
+    if (t < 0 || t >= T - 1) return;   // uniform; there is no F_{T-1}
+    const size_t tb = (size_t)t * B + b;
+    const __amdgpu_buffer_rsrc_t rf = wave_rsrc(a.F + tb * NX * NS, NX * NS * 4);
+    static_for<0, NX>([&](auto r) { k.Fc[r.value] = wave_load<r.value * NS * 4>(rf, voff_col); });
+    if (col_aff && has_f) {
+      const f4v *fp = reinterpret_cast<const f4v *>(a.f + tb * NX);
+#pragma unroll
+      for (int I = 0; I < TX; ++I) {
+        const f4v v = fp[I];
+        k.Fc[4 * I] = v[0]; k.Fc[4 * I + 1] = v[1]; k.Fc[4 * I + 2] = v[2]; k.Fc[4 * I + 3] = v[3];
+      }
+    }
+  };
+
   f4v V4[TX];  // rows of [V | v]
 #pragma unroll
   for (int I = 0; I < TX; ++I) V4[I] = f4v{0.f, 0.f, 0.f, 0.f};
+#ifdef DMPC_WAVE_TIMING   // scripts/microbench/wave_phases.hip: s_memtime stamps, wave 0 reports through a.x
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define DMPC_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define DMPC_STAMP(i) do { } while (0)
+#endif
 
-  for (int t = T - 1; t >= 0; --t) {
+  auto step = [&](int t, Bank &k, Bank &next) {
     const size_t tb = (size_t)t * B + b;
-    // ---- [C_t | c_t] rows, column-per-lane
-    f4v Q4[TS];
-    {  // one load per row through a per-lane base and stride (lane ns walks c, the others a column of C) - a
-       // `col_aff ? c[i] : C[i][j]` per element makes hipcc emit an exec-masked branch diamond for every load
-      const char *qp = reinterpret_cast<const char *>(col_aff ? a.c + tb * NS : a.C + tb * NS * NS + lane_c);
-      const size_t qs = col_aff ? 4 : NS * 4;  // bytes to the next row (a running pointer: one 64-bit add per load)
-#pragma unroll
-      for (int I = 0; I < TS; ++I)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          Q4[I][r] = *reinterpret_cast<const float *>(qp);
-          qp += qs;
-        }
-    }
-    // ---- XU[m] = column nx+m of Q~x. as a ROW (lane i = Q[i][nx+m]): the A operand of Qxu K~ in the value update
-    constexpr bool kXU = NU % 4 == 0;
-    constexpr int TU = kXU ? NU / 4 : 1;
-    f4v XU4[TU];
-    if constexpr (kXU) {
-      float xu[NU];
-      load_contig<NU>(a.C + (tb * NS + (lane < NX ? lane : NX - 1)) * NS + NX, xu);
-#pragma unroll
-      for (int m = 0; m < NU; ++m) XU4[m / 4][m % 4] = xu[m];
-    }
+    f4v(&Q4)[TS] = k.Q4;
     if (t < T - 1) {
-      float Fc[NX];
-      {
-        const bool f_lane = col_aff && has_f;
-        // lane ns without f: any column, zeroed below
-        const char *fp = reinterpret_cast<const char *>(f_lane ? a.f + tb * NX : a.F + tb * NX * NS + lane_c);
-        const size_t fs = f_lane ? 4 : NS * 4;
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-          Fc[k] = *reinterpret_cast<const float *>(fp);
-          fp += fs;
-        }
-        if (!has_f) {
-#pragma unroll
-          for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? 0.f : Fc[k];
-        }
-      }
       // ---- G = [V|v]^T F~ : tiles 0..TX-1 (x columns of V) and TA (row 0 = v^T F~)
       f4v G4[TX + 1];
 #pragma unroll
       for (int I = 0; I <= TX; ++I) G4[I] = f4v{0.f, 0.f, 0.f, 0.f};
       static_for<0, NX>([&](auto a_) {
         const float va = V4[a_.value / 4][a_.value % 4];
-        const float fa = Fc[a_.value];
+        const float fa = k.Fc[a_.value];
         static_for<0, TX>([&](auto I) { G4[I.value] = mfma_bcast<I.value>(va, fa, G4[I.value]); });
         G4[TX] = mfma_bcast<TA>(va, fa, G4[TX]);
       });
-      // ---- Q~ += G^T F~ + g1 (x) e_aff
+      DMPC_STAMP(2);
+      if constexpr (DMPC_WAVE_PREFETCH) fetch_dyn(t - 1, next);
+      DMPC_STAMP(1);
+      // ---- Q~ += G^T F~ + g1 (x) e_aff ;  XU += (F~^T G)[u rows]
       static_for<0, NX>([&](auto b_) {
         const float gb = G4[b_.value / 4][b_.value % 4];
-        const float fb = Fc[b_.value];
+        const float fb = k.Fc[b_.value];
         static_for<0, TS>([&](auto I) { Q4[I.value] = mfma_bcast<I.value>(gb, fb, Q4[I.value]); });
-        if constexpr (kXU)  // (F~^T G)[nx+m][i] = (G^T F~)[i][nx+m]: A = F~[b] block of the control columns, B = G[b]
-          static_for<0, TU>([&](auto q) { XU4[q.value] = mfma_bcast<TX + q.value>(fb, gb, XU4[q.value]); });
+        static_for<0, TU>([&](auto q) { k.XU4[q.value] = mfma_bcast<TX + q.value>(fb, gb, k.XU4[q.value]); });
       });
       {
         const float g1 = G4[TX][0];
         static_for<0, TS>([&](auto I) { Q4[I.value] = mfma_bcast<I.value>(g1, eaff, Q4[I.value]); });
       }
     }
-    // ---- gains: every lane gets the full Quu (wave-uniform) and solves its own column  (:112-120)
-    float Quu[NU][NU];
-    static_for<0, NU>([&](auto l) {
+    DMPC_STAMP(3);
+    // ---- gains (:112-120): Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie.  Row m is one register
+    // across the lanes; the multiplier of row i at pivot k is ONE lane of it (lane nx+k).
+    float Kr[NU];
 #pragma unroll
-      for (int m = 0; m < NU; ++m) Quu[m][l.value] = G64::template bcast<NX + l.value>(Q4[(NX + m) / 4][(NX + m) % 4]);
+    for (int m = 0; m < NU; ++m) Kr[m] = Q4[(NX + m) / 4][(NX + m) % 4];
+    if constexpr (MASKED) {   // active_constrained_lqr.py:110-126: clamped controls leave the system
+      const unsigned act = k.act;
+      const bool act_col = lane >= NX && lane < NS && ((act >> (lane - NX)) & 1u);
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        const bool am = (act >> m) & 1u;                                   // uniform
+        const float free_row = act_col ? 0.f : Kr[m];                      // Quu_ off the free x free block = 0
+        Kr[m] = am ? ((lane == NX + m) ? 1e-8f : 0.f) : free_row;          // active: 1e-8 on the diagonal, qu_ = Qux_ = 0
+      }
+    }
+    static_for<0, NU>([&](auto kc) {
+      constexpr int kk = kc.value;
+      float p = G64::template bcast<NX + kk>(Kr[kk]);
+      float li[NU];
+      float mx = 0.f;
+#pragma unroll
+      for (int i = kk + 1; i < NU; ++i) {
+        li[i] = G64::template bcast<NX + kk>(Kr[i]);
+        mx = fmaxf(mx, fabsf(li[i]));
+      }
+      if (__builtin_expect(mx > fabsf(p), 0)) {   // uniform, rare: LAPACK's row interchange (first largest entry)
+        float best = fabsf(p);
+        int pr = kk;
+#pragma unroll
+        for (int i = kk + 1; i < NU; ++i) {
+          const bool gt = fabsf(li[i]) > best;
+          best = gt ? fabsf(li[i]) : best;
+          pr = gt ? i : pr;
+        }
+        pr = __builtin_amdgcn_readfirstlane(pr);
+#pragma unroll
+        for (int i = kk + 1; i < NU; ++i) {
+          if (pr == i) {
+            const float tmp = Kr[kk];
+            Kr[kk] = Kr[i];
+            Kr[i] = tmp;
+            li[i] = p;
+            p = G64::template bcast<NX + kk>(Kr[kk]);
+          }
+        }
+      }
+      if (p == 0.f) info_bits |= 1;
+      const float r = fast_rcp(p);
+      Kr[kk] *= r;
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        if (i == kk) continue;
+        const float l = i > kk ? li[i] : G64::template bcast<NX + kk>(Kr[i]);
+        Kr[i] = fmaf(-l, Kr[kk], Kr[i]);
+      }
     });
     float Kt[NU];
 #pragma unroll
-    for (int m = 0; m < NU; ++m) Kt[m] = Q4[(NX + m) / 4][(NX + m) % 4];
-    {
-      float A[NU][NU];
-#pragma unroll
-      for (int m = 0; m < NU; ++m)
-#pragma unroll
-        for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
-      if (lu_factor_solve_uniform<NU>(A, Kt)) info_bits |= 1;
-#pragma unroll
-      for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
-    }
+    for (int m = 0; m < NU; ++m) Kt[m] = -Kr[m];
     if (k_lane && live) {
+      float *kp = col_aff ? ks + tb * NU : Ks + tb * NU * NX + lane;
+      const int kstride = col_aff ? 1 : NX;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) {
-        if (col_aff) ks[tb * NU + m] = Kt[m];
-        else Ks[(tb * NU + m) * NX + lane] = Kt[m];
-      }
+      for (int m = 0; m < NU; ++m) kp[m * kstride] = Kt[m];
     }
+    DMPC_STAMP(4);
     if (t > 0) {
-      // ---- value update, all four terms (:151-152): V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~)
-      float R[NU];
-#pragma unroll
-      for (int m = 0; m < NU; ++m) {
-        R[m] = Q4[(NX + m) / 4][(NX + m) % 4];
-#pragma unroll
-        for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
-      }
+      // ---- value update (:151-152): V~ = Q~x. + Qxu K~ (+ K~^T (Q~u. + Quu K~) when the gains are masked)
 #pragma unroll
       for (int I = 0; I < TX; ++I) V4[I] = Q4[I];
-      if constexpr (kXU) {  // Qxu K~ = XU^T K~, the A^T B shape
+      static_for<0, NU>([&](auto m) {  // Qxu K~ = XU^T K~, the A^T B shape
+        const float xm = k.XU4[m.value / 4][m.value % 4];
+        static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(xm, Kt[m.value], V4[I.value]); });
+      });
+      if constexpr (MASKED) {
+        float R[NU];
         static_for<0, NU>([&](auto m) {
-          const float xm = XU4[m.value / 4][m.value % 4];
-          static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(xm, Kt[m.value], V4[I.value]); });
+          R[m.value] = Q4[(NX + m.value) / 4][(NX + m.value) % 4];
+          static_for<0, NU>([&](auto l) {
+            const float quu = G64::template bcast<NX + l.value>(Q4[(NX + m.value) / 4][(NX + m.value) % 4]);
+            R[m.value] = fmaf(quu, Kt[l.value], R[m.value]);
+          });
         });
-      } else {
-        static_for<0, NU>([&](auto m) {  // Qxu K~ as an A B product (v_readlane broadcast of column nx+m)
-#pragma unroll
-          for (int I = 0; I < TX; ++I)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) V4[I][r] = fmaf(G64::template bcast<NX + m.value>(Q4[I][r]), Kt[m.value], V4[I][r]);
+        static_for<0, NU>([&](auto m) {  // K~^T R
+          static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(Kt[m.value], R[m.value], V4[I.value]); });
         });
       }
-      static_for<0, NU>([&](auto m) {  // K~^T R
-        static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(Kt[m.value], R[m.value], V4[I.value]); });
-      });
     }
+  };
+
+#if !DMPC_WAVE_PREFETCH
+  Bank ka;
+  for (int t = T - 1; t >= 0; --t) {
+    fetch_cost(t, ka);
+    fetch_dyn(t, ka);
+    DMPC_STAMP(1);
+    step(t, ka, ka);
+  }
+#else
+  Bank ka, kb;
+  fetch_cost(T - 1, ka);
+  for (int t = T - 1; t >= 0; t -= 2) {
+    DMPC_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // bank A has landed (it was requested a whole step ago) ...
+    DMPC_STAMP(0);
+    fetch_cost(t - 1, kb);                             // ... so the next requests queue behind nothing
+    if (t == T - 1) fetch_dyn(t - 1, kb);              // the last step has no first product to hide behind
+    DMPC_STAMP(1);
+    step(t, ka, kb);
+    if (t - 1 >= 0) {
+      DMPC_STAMP(5);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      DMPC_STAMP(0);
+      fetch_cost(t - 2, ka);
+      DMPC_STAMP(1);
+      step(t - 1, kb, ka);
+    }
+  }
+#endif
+#ifdef DMPC_WAVE_TIMING
+  DMPC_STAMP(5);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(a.x);
+    unsigned long long tot = 0;
+    for (int i = 0; i < 6; ++i) { out[i] = tacc[i]; tot += tacc[i]; }
+    out[6] = tot;
+  }
+#endif
+  if constexpr (ROLLOUT) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gain stores of this wavefront have reached L2
+#ifdef DMPC_DBG_FENCE
+    __threadfence();
+#endif
+    wave_rollout<NX, NU, MASKED>(a, b, lane, live, Ks, ks, info_bits);
   }
   if (a.info != nullptr && live && info_bits != 0) atomicOr(&a.info[b], info_bits);
 }

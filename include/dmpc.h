@@ -52,7 +52,8 @@ int dmpc_lqr_kernel_family(int nx, int nu);
  *   0 lqr_generic_kernel (runtime dims, LDS)      1 lqr_kernel (HIP, register prefetch)
  *   2 lqr_dma_kernel (HIP, LDS-DMA ring)          3 lqr_asm_kernel, ring (generated stream, F fetched twice)
  *   4 lqr_asm_kernel, stash (generated stream, F kept in accumulation registers)
- *   5 lqr_wave_mfma_backward + forward-only lqr_kernel (one wavefront per trajectory, e.g. (32,8))   <0 unsupported */
+ *   5 lqr_wave_mfma_backward (one wavefront per trajectory, e.g. (32,8): MFMA backward sweep, then the same wavefront
+ *     rolls its trajectory out)   <0 unsupported */
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
 
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active
