@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
 #pragma unroll
     for (int m = 0; m < NU; ++m) Kt[m] = qp.free_[m] ? Q[NX + m] : 0.f;
     if constexpr (NU == 1) {
-      Kt[0] = -((1.0f / qp.fac[0][0]) * Kt[0]);
+      Kt[0] = -(qp.rinv[0] * Kt[0]);
     } else {
-      lu_solve_inplace<NU>(qp.fac, qp.piv, Kt);
+      lu_solve_rinv<NU>(qp.fac, qp.piv, qp.rinv, Kt);
 #pragma unroll
       for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
     }

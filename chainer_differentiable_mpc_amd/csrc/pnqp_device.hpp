@@ -58,6 +58,7 @@ __host__ __device__ constexpr size_t pnqp_sync_slots(int n_iter) { return (size_
 template <int N>
 struct PnqpResult {
   float fac[N][N];  // LU of the last free-set Hessian H_f (N == 1: H_f itself)      pnqp.py:144,201
+  float rinv[N];    // reciprocal pivots of that LU (N == 1: 1 / H_f): solves multiply, an IEEE divide is ~10 issue slots
   int piv[N];       // LAPACK 1-based pivots of that factorisation
   bool free_[N];    // Index_f
   int it;           // the reference's returned `i`
@@ -85,18 +86,18 @@ __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (
                                            PnqpResult<N> &res, QpTermination &term) {
   if (!warm) {  // x_init = -H^-1 q                                                   pnqp.py:75-83
     if constexpr (N == 1) {
-      x[0] = -(1.0f / H[0][0]) * q[0];
+      x[0] = -fast_rcp(H[0][0]) * q[0];
     } else {
-      float A[N][N];
+      float A[N][N], ri[N];
       int piv[N];
 #pragma unroll
       for (int r = 0; r < N; ++r)
 #pragma unroll
         for (int c = 0; c < N; ++c) A[r][c] = H[r][c];
-      lu_factor_inplace<N>(A, piv);
+      lu_factor_rinv<N>(A, piv, ri);
 #pragma unroll
       for (int r = 0; r < N; ++r) x[r] = q[r];
-      lu_solve_inplace<N>(A, piv, x);
+      lu_solve_rinv<N>(A, piv, ri, x);
 #pragma unroll
       for (int r = 0; r < N; ++r) x[r] = -x[r];
     }
@@ -109,6 +110,7 @@ __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (
   for (int r = 0; r < N; ++r) {
     res.free_[r] = true;
     res.piv[r] = r + 1;
+    res.rinv[r] = 0.f;
 #pragma unroll
     for (int c = 0; c < N; ++c) res.fac[r][c] = 0.f;
   }
@@ -137,12 +139,13 @@ __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (
         res.fac[r][c] = v;
       }
     if constexpr (N == 1) {
-      dx[0] = -(1.0f / res.fac[0][0]) * gf[0];  // :134
+      res.rinv[0] = fast_rcp(res.fac[0][0]);
+      dx[0] = -res.rinv[0] * gf[0];  // :134
     } else {
-      lu_factor_inplace<N>(res.fac, res.piv);  // :136
+      lu_factor_rinv<N>(res.fac, res.piv, res.rinv);  // :136
 #pragma unroll
       for (int r = 0; r < N; ++r) dx[r] = gf[r];
-      lu_solve_inplace<N>(res.fac, res.piv, dx);
+      lu_solve_rinv<N>(res.fac, res.piv, res.rinv, dx);
 #pragma unroll
       for (int r = 0; r < N; ++r) dx[r] = -dx[r];
     }
@@ -179,7 +182,7 @@ __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (
         for (int c = 0; c < N; ++c) hd = fmaf(H[r][c], d[c], hd);
         dHd = fmaf(d[r], hd, dHd);
       }
-      const float lhs = 1.0f + 0.5f * dHd / gd;             // :175-176
+      const float lhs = fmaf(0.5f * dHd, fast_rcp(gd), 1.0f);   // :175-176 (gd = 0 -> NaN or inf, as the quotient would be)
       // a row that has already converged carries GAMMA + 1e-6 (:174): it passes, and keeps its alpha
       const bool fails = large && lhs <= kPnqpGamma;        // false for NaN, like numpy's max(nan) <= GAMMA
       if (fails) alpha *= kPnqpDecay;                       // :185-186
