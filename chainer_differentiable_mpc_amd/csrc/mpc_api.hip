@@ -262,7 +262,7 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(f_hat)) return DMPC_E_BADARG;
   if (batch_coupled && (!ws || ws_bytes < coupled_bytes(T, n_qp_iter_max))) return DMPC_E_WORKSPACE;
   MpcBackArgs ba{T, B, C_hat, c_hat, F_hat, f_hat, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
-                 n_qp_iter, info, nullptr, batch_coupled ? static_cast<unsigned *>(ws) : nullptr};
+                 n_qp_iter, info, nullptr, batch_coupled ? static_cast<unsigned *>(ws) : nullptr, nullptr};
   return launch_mpc_back(nx, nu, ba, static_cast<hipStream_t>(stream_));
 }
 
@@ -335,18 +335,12 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
   if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   char *base = static_cast<char *>(ws);
+  // Taylor re-centring (c_hat <- C [x;u] + c, f_hat <- None, mpc_step.py:305-317) happens inside the backward sweep
   const float *c_use = c_hat;
-  const float *f_use = f_hat;
-  if (need_expand) {  // Taylor re-centring: c_hat <- C [x;u] + c, f_hat <- None           mpc_step.py:305-317
-    float *c_back = reinterpret_cast<float *>(base + w.c_back);
-    const size_t rows = (size_t)T * B;
-    hipLaunchKernelGGL(taylor_c_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, C_hat,
-                       c_hat, states, controls, c_back);
-    c_use = c_back;
-    f_use = nullptr;
-  }
+  const float *f_use = need_expand ? nullptr : f_hat;
   MpcBackArgs ba{T, B, C_hat, c_use, F_hat, f_use, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
-                 n_qp_iter, info, nullptr, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr};
+                 n_qp_iter, info, nullptr, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
+                 need_expand ? states : nullptr};
   int rc = launch_mpc_back(nx, nu, ba, stream);
   if (rc != 0) return rc;
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
@@ -412,12 +406,12 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     } else {
       hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
                          f, xs, done);
-      hipLaunchKernelGGL(taylor_c_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, C, c,
-                         xs, u_cur, c_back);
     }
     // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
-    MpcBackArgs ba{T, B, C, c_back, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks, ip(w.nqp), info,
-                   done, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr};
+    // pendulum: c_back was re-centred by the rollout kernel; LinDx: the backward sweep re-centres c itself
+    MpcBackArgs ba{T, B, C, dyn_kind == 1 ? c_back : c, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks,
+                   ip(w.nqp), info, done, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
+                   dyn_kind == 1 ? nullptr : xs};
     int rc = launch_mpc_back(nx, nu, ba, stream);
     if (rc != 0) return rc;
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,

@@ -59,7 +59,14 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
     const size_t tb = (size_t)t * B + b;
     const float *Cp = a.C + tb * ns * ns;
     for (int e = lane; e < ns * ns; e += 64) Qt[(e / ns) * nc + (e % ns)] = Cp[e];
-    for (int i = lane; i < ns; i += 64) Qt[i * nc + ns] = a.c[tb * ns + i];
+    for (int i = lane; i < ns; i += 64) {
+      float ci = a.c[tb * ns + i];
+      if (a.states != nullptr) {   // need_expand inside the sweep: c_hat = C [x_t; u_t] + c          :305-317
+        for (int j = 0; j < nx; ++j) ci = fmaf(Cp[i * ns + j], a.states[tb * nx + j], ci);
+        for (int m = 0; m < NU; ++m) ci = fmaf(Cp[i * ns + nx + m], a.controls[tb * NU + m], ci);
+      }
+      Qt[i * nc + ns] = ci;
+    }
     if (t < T - 1) {
       const float *Fp = a.F + tb * nx * ns;
       for (int e = lane; e < nx * ns; e += 64) Ft[(e / ns) * nc + (e % ns)] = Fp[e];

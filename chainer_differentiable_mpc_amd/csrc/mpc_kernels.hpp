@@ -36,6 +36,9 @@ struct MpcBackArgs {
   // batch-coupled PNQP termination (pnqp.py:139-144,172,187): zeroed decision slots, T * pnqp_sync_slots(n_qp_iter) of
   // them; nullptr = per-trajectory termination.  With slots the kernel must be launched cooperatively.
   unsigned *sync;
+  // need_expand (mpc_step.py:305-317) inside the sweep: with `states` [T,B,nx] given, `c` is the ORIGINAL linear term
+  // and the kernel forms c_hat_t = C_t [x_t; u_t] + c_t from the C rows it holds anyway (nullptr: c is used as given)
+  const float *states;
 };
 
 template <int NX, int NU, int L>
@@ -76,7 +79,9 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   struct Slot {
     float Q[NS], Fc[NX];      // [C_t | c_t] rows, [F_t | f_t] rows
     float uc[NU], lb[NU], ub[NU];
+    float tau;                // lane j < ns: [x_t; u_t][j] (need_expand), else 0
   };
+  const bool expand = a.states != nullptr;
   auto load = [&](int t, Slot &sl) {
     t = t < 0 ? 0 : t;  // prefetch past t = 0: step 0 again (never consumed)
     const size_t tb = (size_t)t * B + b;
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
       sl.lb[m] = a.lower[tb * NU + m];
       sl.ub[m] = a.upper[tb * NU + m];
     }
+    sl.tau = 0.f;
+    if (expand && lane < NS) sl.tau = lane < NX ? a.states[tb * NX + lane] : a.controls[tb * NU + (lane - NX)];
   };
 
   auto step = [&](int t, const Slot &sl) {
@@ -111,6 +118,13 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
     float Q[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) Q[i] = sl.Q[i];
+    if (expand) {   // c_hat = C tau + c: row sums over the matrix columns land in the affine column   :305-317
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const float s = group_sum<L>(lane < NS ? Q[i] * sl.tau : 0.f);
+        Q[i] = col_aff ? Q[i] + s : Q[i];
+      }
+    }
     if (t < T - 1) {
       float Fc[NX];
 #pragma unroll
