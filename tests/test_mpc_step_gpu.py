@@ -206,11 +206,12 @@ def test_headline_shape_properties():
     assert float((u == lo).float().mean() + (u == hi).float().mean()) > 0.05  # the box is active somewhere
 
 
+@pytest.mark.parametrize("coupled", [False, True], ids=["per_row", "batch_coupled"])
 @pytest.mark.parametrize("shape", [(6, 7, 5, 2, 0.25), (5, 6, 4, 3, 0.375), (4, 8, 7, 1, 0.5), (3, 5, 10, 5, 0.25),
                                    (3, 6, 32, 8, 0.25), (4, 6, 20, 6, 0.375)])   # bounds exact in float32
-def test_shapes_without_a_specialisation_against_the_oracle(shape):
+def test_shapes_without_a_specialisation_against_the_oracle(shape, coupled):
     """runtime-dimension MPC kernels (mpc_generic.hpp): forward (backward_rec with PNQP + line search) and the
-    analytic backward for shapes outside the register-resident list, against the per-trajectory oracle"""
+    analytic backward for shapes outside the register-resident list, against the oracle in both termination modes"""
     B, T, nx, nu, bound = shape
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7, with_f=True)
     lo, hi = -bound * np.ones((T, B, nu)), bound * np.ones((T, B, nu))
@@ -221,12 +222,14 @@ def test_shapes_without_a_specialisation_against_the_oracle(shape):
     x0 = np.stack(xs).astype(np.float32).astype(np.float64)
     xr, ur, bo, fo, Ksr, ksr = ompc.mpc_forward(p["C"], p["c"], p["F"], p["f"], u0, x0, lo, hi,
                                                 ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"]), 0.2, 5,
-                                                T, nx, nu, need_expand=True, batch_coupled=False)
+                                                T, nx, nu, need_expand=True, batch_coupled=coupled)
     step = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(p["C"]), dev(p["c"])),
-                   LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=True)
+                   LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=True, batch_coupled=coupled)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         x, u = step.forward((dev(x0[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    if coupled:
+        assert step.back_out.n_total_qp_iter == bo.n_total_qp_iter
     assert_close(npy(step.ks), ksr, TOL, "ks")
     assert_close(npy(step.Ks), Ksr, TOL, "Ks")
     assert_close(npy(u), ur, TOL, "u")
@@ -242,3 +245,37 @@ def test_shapes_without_a_specialisation_against_the_oracle(shape):
         if want is None:
             continue
         assert_close(npy(got), want, 5e-4, key)
+
+
+def test_batch_coupled_needs_the_batch_resident_and_says_so():
+    """the grid-wide termination needs every workgroup resident (cooperative launch): a batch that cannot be is
+    refused with DMPC_E_UNSUPPORTED instead of deadlocking; per-trajectory termination takes any batch"""
+    from chainer_differentiable_mpc_amd import DmpcError, PNQP
+    B, n = 1 << 20, 2                       # 4096 workgroups of 256 QPs: more than 256 CUs can hold at once
+    p = synthetic.make_box_qp(B, n, seed=5)
+    args = (dev(p["H"]), dev(p["q"]), dev(p["lower"]), dev(p["upper"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, _, _, _ = PNQP(*args)
+        assert bool(torch.isfinite(x).all())
+        with pytest.raises(DmpcError):
+            PNQP(*args, batch_coupled=True)
+
+
+def test_box_ddp_device_loop_batch_coupled_matches_the_reference_trace():
+    """`dmpc_box_ddp(batch_coupled=1)`: the reference's BoxDDP run (tests/golden/boxddp_trace.npz) is a batched run,
+    i.e. with batch-global PNQP termination inside every step"""
+    from chainer_differentiable_mpc_amd import BoxDDP
+    g = np.load(os.path.join(GOLDEN, "boxddp_trace.npz"))
+    B, T, nx, nu = int(g["B"]), int(g["T"]), int(g["nx"]), int(g["nu"])
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=int(g["seed"]), with_f=True)
+    for device_loop in (True, False):
+        solver = BoxDDP(T, -float(g["bound"]), float(g["bound"]), B, nx, nu, None, max_iter=10, quiet=True,
+                        batch_coupled=True, device_loop=device_loop)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, costs = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
+        assert solver.status in str(g["stdout"])
+        assert_close(npy(u), g["u"], 5e-4, "u")
+        assert_close(npy(x), g["x"], 5e-4, "x")
+        assert_close(npy(costs), g["costs"], 5e-4, "costs")
