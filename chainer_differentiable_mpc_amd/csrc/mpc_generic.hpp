@@ -196,6 +196,7 @@ __global__ __launch_bounds__(64) void mpc_generic_forward_kernel(const MpcFwdArg
     if (lane < nx) xh[lane] = a.states[(size_t)b * nx + lane];                           // :198
     __syncthreads();
     cost = 0.f;
+    float delta = 0.f;   // current_cost - OLD_COST, per timestep and without cancellation (see mpc_forward_rec_kernel)
     for (int t = 0; t < T; ++t) {
       const size_t tb = (size_t)t * B + b;
       if (lane < nu) {
@@ -219,21 +220,25 @@ __global__ __launch_bounds__(64) void mpc_generic_forward_kernel(const MpcFwdArg
         a.x[tb * nx + lane] = xh[lane];
       }
       __syncthreads();
-      float part = 0.f, part0 = 0.f;
+      float part = 0.f, part0 = 0.f, partd = 0.f;
       if (lane < ns) {                                                                   // :246-251, util.py:162-198
         const float *Cr = a.C + (tb * ns + lane) * ns;
-        float qi = 0.f, q0 = 0.f;
+        float qi = 0.f, q0 = 0.f, qd = 0.f;
         for (int j = 0; j < ns; ++j) {
           const float cij = Cr[j];
           qi = fmaf(cij, tau[j], qi);
           q0 = fmaf(cij, tau0[j], q0);
+          qd = fmaf(cij, tau[j] - tau0[j], qd);
         }
         const float ci = a.c[tb * ns + lane];
+        const float di = tau[lane] - tau0[lane];
         part = tau[lane] * fmaf(0.5f, qi, ci);
         part0 = tau0[lane] * fmaf(0.5f, q0, ci);
+        partd = fmaf(di, fmaf(0.5f, qi, ci), 0.5f * tau0[lane] * qd);
       }
       const float obj = wave_sum64(part);
       cost += obj;
+      delta += wave_sum64(partd);
       if (n_pass == 0) old_cost += wave_sum64(part0);                                    // :191
       if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
       float xn = 0.f;
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(64) void mpc_generic_forward_kernel(const MpcFwdArg
       __syncthreads();
     }
     ++n_pass;
-    worse = cost > old_cost;             // :266
+    worse = delta > 0.f;                 // :266  current_cost > OLD_COST
     if (worse) alpha *= a.ls_decay;      // :268
   }
   int info_bits = 0;

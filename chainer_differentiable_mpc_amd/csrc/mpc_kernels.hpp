@@ -224,10 +224,18 @@ __device__ __forceinline__ PendulumModel pendulum_model(float g, float m, float 
 __device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, float s, float w, float u, float &cn,
                                               float &sn, float &wn, float &nth) {
   const float uc = fminf(fmaxf(u, -p.max_torque), p.max_torque);
-  const float th = atan2f(s, c);
   wn = w + p.dt * (p.kg * s + p.ku * uc);
-  nth = th + wn * p.dt;
-  sincosf(nth, &sn, &cn);  // one argument reduction for both
+  // (cos, sin)(atan2(s, c) + delta) = R(delta) (c, s) / |(c, s)|: the reference's atan2 -> add -> cos/sin
+  // (pendulum.py:88-98) is a rotation of the normalised state by delta = wn * dt; no atan2, and the angle whose
+  // sine and cosine are taken is the small increment, not the absolute angle.  atan2(0, 0) = 0 there: unit vector (1, 0).
+  const float r2 = fmaf(c, c, s * s);
+  const float ri = r2 > 0.f ? rsqrtf(r2) : 0.f;
+  const float cu = r2 > 0.f ? c * ri : 1.f, su = s * ri;
+  float sd, cd;
+  sincosf(wn * p.dt, &sd, &cd);
+  cn = fmaf(cu, cd, -su * sd);
+  sn = fmaf(su, cd, cu * sd);
+  nth = 0.f;   // the absolute angle is not formed any more (callers use cn, sn)
 }
 
 struct MpcFwdArgs {
@@ -275,7 +283,12 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   const int lane_x = is_x ? lane : NX - 1;
   const int lane_t = is_tau ? lane : NS - 1;
 
-  // OLD_COST of (states, controls) (mpc_step.py:191) is accumulated during the first pass from the same rows of C
+  // OLD_COST of (states, controls) (mpc_step.py:191) is accumulated during the first pass from the same rows of C.
+  // The test `current_cost > OLD_COST` (:196,266) is NOT taken on the two rounded totals: near a fixed point their
+  // difference is far below float32's resolution of the totals (the reference decides it in float64).  Per timestep
+  //     obj(tau') - obj(tau) = 1/2 d'(C tau') + 1/2 tau'(C d) + c'd ,   d = tau' - tau
+  // is exact algebra for any (also non-symmetric) C and has no cancellation: its rounding error scales with |d|, not
+  // with the cost.  A candidate that has collapsed onto the nominal trajectory gives d = 0, hence exactly 0.
   float old_cost = 0.f;
 
   // Inputs of one timestep of a pass; the loads of step t+2 are issued before step t is computed (see the backward
@@ -309,11 +322,11 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       sl.fi = has_f ? a.f[tbF * NX + lane_x] : 0.f;
     }
   };
-  auto slot_cost = [&](const Slot &sl, float tau) {  // 1/2 tau'C tau + c'tau of one timestep          util.py:162-198
-    float qi = 0.f;
-    Blk::dot_x(qi, tau, sl.Crow);  // broadcast-FMAs fused into one DPP instruction each
-    Blk::dot_u(qi, tau, sl.Crow);
-    return group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f);
+  auto row_dot = [&](const Slot &sl, float v) {   // (C v)[lane]: broadcast-FMAs fused into one DPP instruction each
+    float q = 0.f;
+    Blk::dot_x(q, v, sl.Crow);
+    Blk::dot_u(q, v, sl.Crow);
+    return q;
   };
 
   float alpha = 1.0f;
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   while (worse && n_pass < a.ls_cap) {  // :196 - until this trajectory is not worse than before
     float xh = is_x ? a.states[(size_t)b * NX + lane] : 0.f;  // new_x[0] = states[0]     :198
     cost = 0.f;
+    float delta = 0.f;                  // current_cost - OLD_COST, summed per timestep
     auto step = [&](int t, const Slot &sl) {
       const size_t tb = (size_t)t * B + b;
       const float xt = is_x ? sl.xt : 0.f;
@@ -339,14 +353,16 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       float tau = xh;  // [new_x_t ; new_u_t], element per lane
 #pragma unroll
       for (int m = 0; m < NU; ++m) tau = (lane == NX + m) ? un[m] : tau;
-      const float obj = slot_cost(sl, tau);                                          // :246-251
-      cost += obj;
-      if (n_pass == 0) {  // cost of the iterate the step started from                                  :191
-        float tau0 = sl.xt;
+      float tau0 = sl.xt;  // the iterate the step started from
 #pragma unroll
-        for (int m = 0; m < NU; ++m) tau0 = (lane == NX + m) ? sl.uc[m] : tau0;
-        old_cost += slot_cost(sl, tau0);
-      }
+      for (int m = 0; m < NU; ++m) tau0 = (lane == NX + m) ? sl.uc[m] : tau0;
+      const float dt_ = is_tau ? tau - tau0 : 0.f;
+      const float qi = row_dot(sl, tau), qd = row_dot(sl, dt_);
+      const float obj = group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f);   // :246-251, util.py:162-198
+      cost += obj;
+      delta += group_sum<L>(is_tau ? fmaf(dt_, fmaf(0.5f, qi, sl.ci), 0.5f * tau0 * qd) : 0.f);
+      if (n_pass == 0)     // cost of the iterate, from C tau = C tau' - C d                                 :191
+        old_cost += group_sum<L>(is_tau ? tau0 * fmaf(0.5f, qi - qd, sl.ci) : 0.f);
       if (live) {  // outputs are overwritten by later passes; the last one is the accepted one
         if (is_x) a.x[tb * NX + lane] = xh;
         else if (lane < NS) a.u[tb * NU + (lane - NX)] = tau;
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       }
     }
     ++n_pass;
-    worse = cost > old_cost;             // :266
+    worse = delta > 0.f;                 // :266  current_cost > OLD_COST
     if (worse) alpha *= a.ls_decay;      // :268
   }
   int info_bits = 0;
@@ -452,13 +468,33 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(cons
     }
     return obj;
   };
+  // obj(tau) - obj(tau0) without cancellation (see mpc_forward_rec_kernel): 1/2 d'(C tau) + 1/2 tau0'(C d) + c'd
+  auto quad_diff = [&](const Slot &sl, const float (&tau)[NS], const float (&tau0)[NS]) {
+    float d[NS], acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) d[i] = tau[i] - tau0[i];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      float qi = 0.f, qd = 0.f;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) {
+        qi = fmaf(sl.C[i][j], tau[j], qi);
+        qd = fmaf(sl.C[i][j], d[j], qd);
+      }
+      acc = fmaf(d[i], fmaf(0.5f, qi, sl.cc[i]), acc);
+      acc = fmaf(0.5f * tau0[i], qd, acc);
+    }
+    return acc;
+  };
   // one rollout with step size alpha; mode 0: cost only, 1: also the cost of the nominal trajectory and (candidate 0)
-  // the controls of the alpha = 1 pass, 2: write the trajectory
+  // the controls of the alpha = 1 pass, 2: write the trajectory.  `delta` = cost - OLD_COST summed per timestep.
+  float delta = 0.f;
   auto pass = [&](float alpha, int mode, float &cost, float &old_cost) {
     float xh[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xh[i] = a.states[(size_t)b * NX + i];                       // :198
     cost = 0.f;
+    delta = 0.f;
     if (mode == 1) old_cost = 0.f;
     auto step = [&](int t, const Slot &sl) {
       const size_t tb = (size_t)t * B + b;
@@ -472,8 +508,9 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(cons
       const float tau[NS] = {xh[0], xh[1], xh[2], v};
       const float obj = quad(sl, tau);
       cost += obj;
+      const float tau0[NS] = {sl.xt[0], sl.xt[1], sl.xt[2], sl.uc};
+      if (mode != 2) delta += quad_diff(sl, tau, tau0);
       if (mode == 1) {
-        const float tau0[NS] = {sl.xt[0], sl.xt[1], sl.xt[2], sl.uc};
         old_cost += quad(sl, tau0);                                                          // :191
         if (k == 0 && live && a.u_first != nullptr) a.u_first[tb] = v;                       // :260-263
       }
@@ -518,7 +555,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(cons
       pass(alpha, r == 0 ? 1 : 0, cost, oc);
       if (r == 0) old_cost = oc;
     }
-    const bool accept = searching && p < a.ls_cap && !(cost > old_cost);                     // :266
+    const bool accept = searching && p < a.ls_cap && !(delta > 0.f);                         // :266  cost > OLD_COST
     const unsigned mask = (unsigned)((__ballot(accept) >> base) & 0xFFFFull);
     if (searching && mask != 0u) {
       const int ks = __ffs(mask) - 1;

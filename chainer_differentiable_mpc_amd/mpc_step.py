@@ -261,10 +261,11 @@ class MPCstep:
                     new_x.append(nxt)
             X, U = torch.stack(new_x), torch.stack(new_u)
             cost, per = cost_of(X, U)
-            if per is None:
-                tau = torch.cat((X, U), dim=2)
+            if isinstance(true_cost, QuadCost):
                 C_ = _lib.f32c(_as_tensor(true_cost.C), self._dev)
                 c_ = _lib.f32c(_as_tensor(true_cost.c), self._dev)
+            if per is None:
+                tau = torch.cat((X, U), dim=2)
                 per = 0.5 * torch.einsum("tbi,tbij,tbj->tb", tau, C_, tau) + (tau * c_).sum(dim=2)
             if best is None:
                 best = [X.clone(), U.clone(), cost.clone(), per.clone()]
@@ -273,7 +274,17 @@ class MPCstep:
                 m = active
                 best[0][:, m], best[1][:, m], best[2][m], best[3][:, m] = X[:, m], U[:, m], cost[m], per[:, m]
             nls += active.to(torch.int32)
-            worse = (cost > old) & active
+            if isinstance(true_cost, QuadCost):
+                # current_cost > OLD_COST on the difference, formed per timestep without cancellation (as the kernels do:
+                # obj(tau') - obj(tau) = 1/2 d'(C tau') + 1/2 tau'(C d) + c'd): the totals agree to float32 rounding
+                # near a fixed point, where the reference decides in float64
+                tau1, tau0 = torch.cat((X, U), dim=2), torch.cat((xs, u0), dim=2)
+                d = tau1 - tau0
+                delta = (d * (0.5 * torch.einsum("tbij,tbj->tbi", C_, tau1) + c_)).sum(dim=(0, 2)) + \
+                    0.5 * (tau0 * torch.einsum("tbij,tbj->tbi", C_, d)).sum(dim=(0, 2))
+                worse = (delta > 0) & active
+            else:
+                worse = (cost > old) & active
             alphas = torch.where(worse, alphas * ls_decay, alphas)
             active = worse
             if not bool(active.any()):
