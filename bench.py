@@ -388,7 +388,8 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
-                traffic_src = "recorded, not measured in this run: " + str(tj.get("_source", tpath))
+                if traffic is not None:
+                    traffic_src = "recorded, not measured in this run: " + str(tj.get("_source", tpath))
             except Exception:
                 traffic = None
         out = {
