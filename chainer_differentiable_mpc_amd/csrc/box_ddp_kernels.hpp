@@ -59,7 +59,10 @@ struct DdpSelectArgs {
 constexpr int kDdpCopyHereMaxB = 2048;
 constexpr int kDdpSelectThreads = 1024;
 
-__global__ __launch_bounds__(kDdpSelectThreads) void box_ddp_select_kernel(const DdpSelectArgs a) {
+// NT threads of ONE workgroup
+template <int NT>
+__device__ __forceinline__ void box_ddp_select_body(const DdpSelectArgs &a) {
+  constexpr int kDdpSelectThreads = NT;
   __shared__ float s_max[kDdpSelectThreads / 64];
   __shared__ int s_any[kDdpSelectThreads / 64];
   __shared__ unsigned char s_keep[kDdpCopyHereMaxB];
@@ -180,6 +183,10 @@ __global__ __launch_bounds__(kDdpSelectThreads) void box_ddp_select_kernel(const
       b = (b + kDdpSelectThreads) % a.B;
     }
   }
+}
+
+__global__ __launch_bounds__(kDdpSelectThreads) void box_ddp_select_kernel(const DdpSelectArgs a) {
+  box_ddp_select_body<kDdpSelectThreads>(a);
 }
 
 __global__ __launch_bounds__(256) void box_ddp_keep_kernel(int T, int B, int nx, int nu, const int32_t *__restrict__ keep,

@@ -41,8 +41,9 @@ struct MpcBackArgs {
   const float *states;
 };
 
+// `block` = the workgroup's index among the 256-thread workgroups that share the batch (blockIdx.x for the kernel below)
 template <int NX, int NU, int L>
-__global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs a) {
+__device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, const int block, const unsigned n_blocks) {
   constexpr int NS = NX + NU;
   static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
   constexpr int GPB = 256 / L;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
   const int lane = threadIdx.x % L;
   const int grp = threadIdx.x / L;
-  int b = blockIdx.x * GPB + grp;
+  int b = block * GPB + grp;
   const bool live = b < a.B;
   if (!live) b = a.B - 1;
   const int T = a.T;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
   int info_bits = 0;
   QpTermination term;
   term.slots = a.sync;
-  term.n_blocks = gridDim.x;
+  term.n_blocks = n_blocks;
 
   // Inputs of one timestep, column-per-lane.  One wavefront per SIMD: nothing else hides HBM latency, so the loads
   // of step t-2 are issued before step t is computed (three banks rotated statically - hipcc drains vmcnt at a loop
@@ -210,6 +211,11 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
     a.n_qp_total[b] = n_total;
     if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
   }
+}
+
+template <int NX, int NU, int L>
+__global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs a) {
+  mpc_backward_rec_body<NX, NU, L>(a, blockIdx.x, gridDim.x);
 }
 
 // The pendulum of env_dx/pendulum.py:84-98 (simple model), state (cos th, sin th, dth), one torque.  One definition
@@ -424,12 +430,12 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
 // them before the candidate collapses onto the nominal trajectory.  One lane per (trajectory, candidate): the 16
 // lanes of a group roll 16 consecutive step sizes out at once, the first one that is not worse than the old cost is
 // the one the sequential search stops at, and one more pass writes its trajectory.  Two passes instead of p* + 1.
-__global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(const MpcFwdArgs a) {
+__device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdArgs &a, const int block) {
   constexpr int NX = 3, NU = 1, NS = 4, NC = 16;
   if (a.done != nullptr && *a.done != 0) return;
   const int k = threadIdx.x & (NC - 1);
   const int base = (threadIdx.x & 63) & ~(NC - 1);  // first lane of the group within the wavefront
-  int b = blockIdx.x * (256 / NC) + (threadIdx.x / NC);
+  int b = block * (256 / NC) + (threadIdx.x / NC);
   const bool live = b < a.B;
   if (!live) b = a.B - 1;
   const int T = a.T;
@@ -592,6 +598,10 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(cons
   }
 }
 
+__global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(const MpcFwdArgs a) {
+  mpc_forward_rec_pendulum_spec_body(a, blockIdx.x);
+}
+
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
 // (env_dx/pendulum.py:84-98, simple model), F_t = d x_{t+1} / d [x_t; u_t], f_t = x_{t+1} - F_t [x_t; u_t] - what
 // BoxDDP obtains from get_traj (util.py:201-277) followed by linearize_dynamics (mpc/approximate.py:77-119, there
@@ -608,8 +618,7 @@ struct PendulumArgs {
   float *c_back;             // [T,B,4] or nullptr
 };
 
-__global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const PendulumArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pendulum_rollout_linearize_body(const PendulumArgs &a, const int b) {
   if (b >= a.B) return;
   if (a.done != nullptr && *a.done != 0) return;
   const size_t B = (size_t)a.B;
@@ -693,6 +702,10 @@ __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const Pe
     s = sn;
     w = nw;
   }
+}
+
+__global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const PendulumArgs a) {
+  pendulum_rollout_linearize_body(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // c_back[t][b][i] = sum_j C[t][b][i][j] tau[t][b][j] + c[t][b][i]        (mpc_step.py:305-317), one lane per (t,b,i)
