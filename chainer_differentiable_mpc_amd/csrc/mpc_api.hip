@@ -123,10 +123,15 @@ static bool spec_line_search_disabled() {  // DMPC_NO_SPEC_LS=1: sequential line
   return off;
 }
 
-static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a, hipStream_t stream) {
+static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t stream) {
+  MpcFwdArgs a = a_in;
   if (a.dyn_kind == 1 && nx == 3 && nu == 1 && !spec_line_search_disabled()) {
-    // the pendulum's line search usually walks ten or more step sizes: 16 candidates per trajectory at once
-    hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel, dim3((a.B + 15) / 16), dim3(256), 0, stream, a);
+    // the pendulum's line search usually walks ten or more step sizes: 16 candidates per trajectory at once; every
+    // candidate keeps its trajectory in LDS (T * 4 KB per workgroup) when that fits
+    const size_t lds = (size_t)a.T * 4 * 256 * sizeof(float);
+    a.traj_in_lds = lds <= 96 * 1024 ? 1 : 0;
+    hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel, dim3((a.B + 15) / 16), dim3(256),
+                       a.traj_in_lds ? lds : 0, stream, a);
     return (int)hipGetLastError();
   }
 #define X(NX_, NU_, L_)                                                                                      \
@@ -396,37 +401,48 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   e = hipMemcpyAsync(u_buf[0], u_init, rows * nu * sizeof(float), hipMemcpyDeviceToDevice, stream);
   if (e != hipSuccess) return (int)e;
   const int32_t *done = state + kDdpDone;
+  // Pendulum: the trajectory the line search accepts IS the next iteration's nominal one, and the search writes its
+  // linearisation and re-centred cost while it writes the trajectory - the rollout + linearisation kernel runs for
+  // the first iteration only, the nominal states ping-pong between the two state buffers.
+  const bool fuse_lin = dyn_kind == 1 && !spec_line_search_disabled();
+  float *x_buf[2] = {xs, x_new};
   for (int it = 0; it < max_iter; ++it) {
     const float *u_cur = u_buf[it & 1];
     float *u_new = u_buf[(it & 1) ^ 1];
+    float *xs_it = fuse_lin ? x_buf[it & 1] : xs;
+    float *xn_it = fuse_lin ? x_buf[(it & 1) ^ 1] : x_new;
     // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
     if (dyn_kind == 1) {
-      PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs, fp(w.F), fp(w.f), done, C, c, c_back};
-      hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, pa);
+      if (it == 0 || !fuse_lin) {
+        PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs_it, fp(w.F), fp(w.f), done, C, c, c_back};
+        hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, pa);
+      }
     } else {
       hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
-                         f, xs, done);
+                         f, xs_it, done);
     }
     // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
-    // pendulum: c_back was re-centred by the rollout kernel; LinDx: the backward sweep re-centres c itself
+    // pendulum: c_back was re-centred by the rollout kernel / the previous line search; LinDx: the backward sweep
+    // re-centres c itself
     MpcBackArgs ba{T, B, C, dyn_kind == 1 ? c_back : c, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks,
                    ip(w.nqp), info, done, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
-                   dyn_kind == 1 ? nullptr : xs};
+                   dyn_kind == 1 ? nullptr : xs_it};
     int rc = launch_mpc_back(nx, nu, ba, stream);
     if (rc != 0) return rc;
-    MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
-                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, x_new, u_new, u1, costs, old,
-                  alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done};
+    MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs_it, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
+                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1, costs, old,
+                  alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done,
+                  fuse_lin ? fp(w.F) : nullptr, fuse_lin ? fp(w.f) : nullptr, fuse_lin ? c_back : nullptr};
     rc = launch_mpc_fwd(nx, nu, fa, stream);
     if (rc != 0) return rc;
     const bool copy_here = B <= kDdpCopyHereMaxB && rows * (size_t)(nx + nu) <= (size_t)64 * 1024;
     DdpSelectArgs sa{it, T, B, nx, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
-                     costs_best, du_norm_best, du_norm_last, ip(w.keep), state, copy_here ? 1 : 0, x_new, u_new,
+                     costs_best, du_norm_best, du_norm_last, ip(w.keep), state, copy_here ? 1 : 0, xn_it, u_new,
                      x_best, u_best};
     hipLaunchKernelGGL(box_ddp_select_kernel, dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
     if (!copy_here)
       hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
-                         ip(w.keep), x_new, u_new, x_best, u_best);
+                         ip(w.keep), xn_it, u_new, x_best, u_best);
   }
   return (int)hipGetLastError();
 }

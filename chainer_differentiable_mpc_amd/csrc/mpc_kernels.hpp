@@ -244,6 +244,34 @@ __device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, f
   nth = 0.f;   // the absolute angle is not formed any more (callers use cn, sn)
 }
 
+// F = d pendulum_next / d [c, s, w, u] (3 x 4, row-major at Fp) and f = next - F [c, s, w, u] (at fq, may be null):
+// what linearize_dynamics (mpc/approximate.py:77-119) obtains through chainer.grad.  One definition for the rollout
+// kernel and for the line search's accepted pass (which hands the next iLQR iteration its model).
+__device__ __forceinline__ void pendulum_jacobian_store(const PendulumModel &p, float c, float s, float w, float u, float cn,
+                                                        float sn, float nw, float *Fp, float *fq) {
+  const float inside = (u >= -p.max_torque && u <= p.max_torque) ? 1.f : 0.f;   // closed interval, as F.clip's backward
+  const float r2 = c * c + s * s;
+  const float dnw[4] = {0.f, p.dt * p.kg, 1.f, p.dt * p.ku * inside};
+  const float dnth[4] = {-s / r2 + p.dt * dnw[0], c / r2 + p.dt * dnw[1], p.dt * dnw[2], p.dt * dnw[3]};
+  const float xin[4] = {c, s, w, u};
+  float f0 = cn, f1 = sn, f2 = nw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float r0 = -sn * dnth[j], r1 = cn * dnth[j], r2_ = dnw[j];
+    Fp[j] = r0;
+    Fp[4 + j] = r1;
+    Fp[8 + j] = r2_;
+    f0 = fmaf(-r0, xin[j], f0);
+    f1 = fmaf(-r1, xin[j], f1);
+    f2 = fmaf(-r2_, xin[j], f2);
+  }
+  if (fq != nullptr) {
+    fq[0] = f0;
+    fq[1] = f1;
+    fq[2] = f2;
+  }
+}
+
 struct MpcFwdArgs {
   int T, B;
   const float *Ks, *ks;                  // gains from backward_rec
@@ -264,6 +292,13 @@ struct MpcFwdArgs {
   int dyn_kind;
   float pend_g, pend_m, pend_l, pend_dt, pend_max_torque;
   const int32_t *done;                   // device flag of the BoxDDP loop: non-zero -> no-op
+  // The accepted trajectory IS the next iLQR iteration's nominal one (BoxDDP re-rolls it with get_traj and linearises
+  // it, mpc/box_ddp.py:123-136): the speculative pendulum search can write that model while it writes the
+  // trajectory - F_next [T-1,B,3,4], f_next [T-1,B,3], c_next [T,B,4] = C tau + c (mpc_step.py:305-317); nullptr = no.
+  float *F_next, *f_next, *c_next;
+  // speculative search: every candidate keeps its trajectory in LDS (T * 4 floats per lane, T * 4 KB per workgroup)
+  // and the accepted one is copied out instead of being rolled out a second time; 0 = no such buffer was given
+  int traj_in_lds;
 };
 
 template <int NX, int NU, int L>
@@ -441,6 +476,8 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
   const int T = a.T;
   const size_t B = (size_t)a.B;
   const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+  extern __shared__ float traj[];                            // [T][4][256] when a.traj_in_lds
+  const bool keep_traj = a.traj_in_lds != 0 && a.objs == nullptr;
 
   struct Slot {  // inputs of one timestep (the same for every candidate of the trajectory)
     float xt[NX], K[NX], kk, uc, lb, ub, C[NS][NS], cc[NS];
@@ -516,6 +553,10 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
       cost += obj;
       const float tau0[NS] = {sl.xt[0], sl.xt[1], sl.xt[2], sl.uc};
       if (mode != 2) delta += quad_diff(sl, tau, tau0);
+      if (mode != 2 && keep_traj) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) traj[(t * NS + i) * 256 + threadIdx.x] = tau[i];
+      }
       if (mode == 1) {
         old_cost += quad(sl, tau0);                                                          // :191
         if (k == 0 && live && a.u_first != nullptr) a.u_first[tb] = v;                       // :260-263
@@ -525,10 +566,22 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
         for (int i = 0; i < NX; ++i) a.x[tb * NX + i] = xh[i];
         a.u[tb] = v;
         if (a.objs != nullptr) a.objs[tb] = obj;
+        if (a.c_next != nullptr) {
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            float acc = sl.cc[i];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) acc = fmaf(sl.C[i][j], tau[j], acc);
+            a.c_next[tb * NS + i] = acc;
+          }
+        }
       }
       if (t < T - 1) {
         float cn, sn, wn, nth;
         pendulum_next(pm, xh[0], xh[1], xh[2], v, cn, sn, wn, nth);
+        if (mode == 2 && k == 0 && live && a.F_next != nullptr)
+          pendulum_jacobian_store(pm, xh[0], xh[1], xh[2], v, cn, sn, wn, a.F_next + tb * 12,
+                                  a.f_next != nullptr ? a.f_next + tb * 3 : nullptr);
         xh[0] = cn;
         xh[1] = sn;
         xh[2] = wn;
@@ -568,6 +621,39 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
       p_sel = r * NC + ks;
       alpha_sel = __shfl(alpha, base + ks);
       cost_sel = __shfl(cost, base + ks);
+      if (keep_traj) {
+        // the accepted candidate's trajectory is in LDS (lane ks of this group wrote it during the pass above; a
+        // wavefront executes in lock step, so its writes are complete): the 16 lanes of the group share the steps
+        const int src = (int)(threadIdx.x & ~(NC - 1)) + ks;
+        for (int t = k; t < T; t += NC) {
+          const size_t tb = (size_t)t * B + b;
+          float tau[NS];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) tau[i] = traj[(t * NS + i) * 256 + src];
+          if (live) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) a.x[tb * NX + i] = tau[i];
+            a.u[tb] = tau[NX];
+            if (a.c_next != nullptr) {
+#pragma unroll
+              for (int i = 0; i < NS; ++i) {
+                float crow[NS];
+                load_contig<NS>(a.C + (tb * NS + i) * NS, crow);
+                float acc = a.c[tb * NS + i];
+#pragma unroll
+                for (int j = 0; j < NS; ++j) acc = fmaf(crow[j], tau[j], acc);
+                a.c_next[tb * NS + i] = acc;
+              }
+            }
+            if (t < T - 1 && a.F_next != nullptr) {
+              const float cn = traj[((t + 1) * NS + 0) * 256 + src], sn = traj[((t + 1) * NS + 1) * 256 + src],
+                          wn = traj[((t + 1) * NS + 2) * 256 + src];
+              pendulum_jacobian_store(pm, tau[0], tau[1], tau[2], tau[3], cn, sn, wn, a.F_next + tb * 12,
+                                      a.f_next != nullptr ? a.f_next + tb * 3 : nullptr);
+            }
+          }
+        }
+      }
     }
   }
   int info_bits = 0;
@@ -585,8 +671,10 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
     pass(al, 2, c2, dummy);
   } else {
     n_pass = p_sel + 1;
-    float dummy = 0.f, c2 = 0.f;
-    pass(alpha_sel, 2, c2, dummy);
+    if (!keep_traj) {   // no LDS copy of the candidates: roll the accepted one out again and write it
+      float dummy = 0.f, c2 = 0.f;
+      pass(alpha_sel, 2, c2, dummy);
+    }
   }
   if (!is_finite(cost_sel)) info_bits |= 2;
   if (live && k == 0) {
@@ -624,7 +712,6 @@ __device__ __forceinline__ void pendulum_rollout_linearize_body(const PendulumAr
   const size_t B = (size_t)a.B;
   float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
   const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque);
-  const float kg = pm.kg, ku = pm.ku;
   const bool taylor = a.c_back != nullptr;
   // inputs of step t + 1 are fetched while step t runs its atan2 / sin / cos (one lane per trajectory: nothing else
   // hides the latency)
@@ -672,32 +759,10 @@ __device__ __forceinline__ void pendulum_rollout_linearize_body(const PendulumAr
       }
     }
     if (t == a.T - 1) break;
-    const float inside = (ur >= -a.max_torque && ur <= a.max_torque) ? 1.f : 0.f;
-    const float r2 = c * c + s * s;
     float cn, sn, nw, nth;
     pendulum_next(pm, c, s, w, ur, cn, sn, nw, nth);
-    if (a.F != nullptr) {
-      const float dnw[4] = {0.f, a.dt * kg, 1.f, a.dt * ku * inside};
-      const float dnth[4] = {-s / r2 + a.dt * dnw[0], c / r2 + a.dt * dnw[1], a.dt * dnw[2], a.dt * dnw[3]};
-      float *Fp = a.F + tb * 12;
-      const float xin[4] = {c, s, w, ur};
-      float f0 = cn, f1 = sn, f2 = nw;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float r0 = -sn * dnth[j], r1 = cn * dnth[j], r2_ = dnw[j];
-        Fp[j] = r0;
-        Fp[4 + j] = r1;
-        Fp[8 + j] = r2_;
-        f0 = fmaf(-r0, xin[j], f0);
-        f1 = fmaf(-r1, xin[j], f1);
-        f2 = fmaf(-r2_, xin[j], f2);
-      }
-      if (a.f != nullptr) {
-        a.f[tb * 3 + 0] = f0;
-        a.f[tb * 3 + 1] = f1;
-        a.f[tb * 3 + 2] = f2;
-      }
-    }
+    if (a.F != nullptr)
+      pendulum_jacobian_store(pm, c, s, w, ur, cn, sn, nw, a.F + tb * 12, a.f != nullptr ? a.f + tb * 3 : nullptr);
     c = cn;
     s = sn;
     w = nw;
