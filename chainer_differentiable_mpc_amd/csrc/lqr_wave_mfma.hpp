@@ -115,10 +115,15 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
   auto fstep = [&](int t, const Row &r) {
     const size_t tb = (size_t)t * B + b;
     if (f_lane && live) a.x[tb * NX + lane] = xv;
+    // x_t into NX scalar registers first, the FMAs after: one scalar register reused for every broadcast puts a
+    // wait state and a write-after-read stall between each readlane and its FMA
+    float xb[NX];
+    static_for<0, NX>([&](auto i) { xb[i.value] = G64::template bcast<i.value>(xv); });
+    asm volatile("" ::: "memory");
     float acc[4] = {r.aff, 0.f, 0.f, 0.f};
     static_for<0, NX>([&](auto i) {
       const float w = r.w[i.value / 4][i.value % 4];
-      acc[i.value % 4] = fmaf(w, G64::template bcast<i.value>(xv), acc[i.value % 4]);   // :177 and the state part of :189
+      acc[i.value % 4] = fmaf(w, xb[i.value], acc[i.value % 4]);   // :177 and the state part of :189
     });
     float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     float uo = s;
