@@ -399,11 +399,15 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       for (int m = 0; m < NU; ++m) tau0 = (lane == NX + m) ? sl.uc[m] : tau0;
       const float dt_ = is_tau ? tau - tau0 : 0.f;
       const float qi = row_dot(sl, tau), qd = row_dot(sl, dt_);
-      const float obj = group_sum<L>(is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f);   // :246-251, util.py:162-198
-      cost += obj;
-      delta += group_sum<L>(is_tau ? fmaf(dt_, fmaf(0.5f, qi, sl.ci), 0.5f * tau0 * qd) : 0.f);
+      // per-lane partial sums over the timesteps; the lanes of the group are added up ONCE after the pass (only the
+      // optional per-step output `objs` needs the sum of a single step)                          :246-251, util.py:162-198
+      const float obj_l = is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f;
+      cost += obj_l;
+      delta += is_tau ? fmaf(dt_, fmaf(0.5f, qi, sl.ci), 0.5f * tau0 * qd) : 0.f;
       if (n_pass == 0)     // cost of the iterate, from C tau = C tau' - C d                                 :191
-        old_cost += group_sum<L>(is_tau ? tau0 * fmaf(0.5f, qi - qd, sl.ci) : 0.f);
+        old_cost += is_tau ? tau0 * fmaf(0.5f, qi - qd, sl.ci) : 0.f;
+      float obj = 0.f;
+      if (a.objs != nullptr) obj = group_sum<L>(obj_l);
       if (live) {  // outputs are overwritten by later passes; the last one is the accepted one
         if (is_x) a.x[tb * NX + lane] = xh;
         else if (lane < NS) a.u[tb * NU + (lane - NX)] = tau;
@@ -441,6 +445,9 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
         step(t + 2, sc);
       }
     }
+    cost = group_sum<L>(cost);
+    delta = group_sum<L>(delta);
+    if (n_pass == 0) old_cost = group_sum<L>(old_cost);
     ++n_pass;
     worse = delta > 0.f;                 // :266  current_cost > OLD_COST
     if (worse) alpha *= a.ls_decay;      // :268
