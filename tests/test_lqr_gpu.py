@@ -289,3 +289,35 @@ def test_single_timestep_horizon(shape):
     x, u = LqrRecursion(d["x_init"], d["C"], d["c"], F0, None, 1, nx, nu).solve_recursion()
     assert_close(npy(x), xr, TOL_PRIMAL, "x")
     assert_close(npy(u), ur, TOL_PRIMAL, "u")
+
+
+def test_two_streams_do_not_share_scratch():
+    """the per-device scratch of round 1 was shared by every call whatever stream it ran on; it is keyed on the stream
+    now: two (32,8) solves (gains through the workspace) and two KKT gradients enqueued on two streams at once give
+    the answers of the same calls made one after the other"""
+    from chainer_differentiable_mpc_amd.differentiable_lqr import kkt_grad_device
+    from chainer_differentiable_mpc_amd.lqr_recursion import _ws_cache, solve_device
+    probs = []
+    for seed, (B, T, nx, nu) in ((1, (96, 12, 32, 8)), (2, (64, 12, 32, 8))):
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=seed)
+        probs.append((to_dev(p), T, nx, nu))
+    ref = []
+    for d, T, nx, nu in probs:
+        x, u, _, _ = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)
+        g = kkt_grad_device(d["C"], d["c"], d["F"], x, u, torch.ones_like(x), torch.ones_like(u), T, nx, nu)
+        ref.append((x.clone(), u.clone(), [t.clone() for t in g]))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = [None, None]
+    for rep in range(3):
+        for i, ((d, T, nx, nu), st) in enumerate(zip(probs, streams)):
+            with torch.cuda.stream(st):
+                x, u, _, _ = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)
+                g = kkt_grad_device(d["C"], d["c"], d["F"], x, u, torch.ones_like(x), torch.ones_like(u), T, nx, nu)
+                out[i] = (x, u, g)
+    torch.cuda.synchronize()
+    assert len({k[2] for k in _ws_cache}) >= 3          # default stream + the two side streams own separate buffers
+    for (x, u, g), (xr, ur, gr) in zip(out, ref):
+        assert torch.equal(x, xr) and torch.equal(u, ur)
+        for a, b in zip(g, gr):
+            assert torch.equal(a, b)
