@@ -8,19 +8,10 @@
 // Follows DiffLqr.backward, lqr/differentiable_lqr.py:85-134, and MPCstep.backward, mpc/mpc_step.py:383-446.
 #pragma once
 #include "costate_kernels.hpp"
+#include "dma_gather.hpp"
 #include "lqr_dma_kernel.hpp"
 
 namespace dmpc {
-
-// One LDS-DMA instruction of the per-lane gather form: lane l copies the 16 bytes at its own global address to LDS at
-// M0 + OFFSET + 16 l.  The instruction offset moves the global address as well, so the pointers carry -OFFSET.
-template <int OFFSET>
-__device__ __forceinline__ void dma16_gather(unsigned long long ptr) {
-  asm volatile("global_load_lds_dwordx4 %0, off offset:%1" ::"v"(ptr), "n"(OFFSET) : "memory");
-}
-__device__ __forceinline__ void set_m0(unsigned lds_dst) {  // + the wait state an LDS-DMA needs after an M0 write
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory");
-}
 
 // NCH 16-byte chunks staged in LDS (written row-wise by the lanes that own the rows) -> one contiguous run of HBM,
 // a chunk per lane and instruction.  The LDS queue of a wavefront is in order, so the reads see the writes above.

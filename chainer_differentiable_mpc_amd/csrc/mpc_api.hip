@@ -8,6 +8,7 @@
 #include "api_util.hpp"
 #include "costate_args.hpp"
 #include "box_ddp_kernels.hpp"
+#include "mpc_dma_kernels.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_kernels.hpp"
 
@@ -82,6 +83,15 @@ static size_t coupled_bytes(int T, int n_qp_iter) { return round_up((size_t)T * 
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16)
 #endif
 
+static bool mpc_dma_disabled() {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_DMA"); return e && e[0] == '1'; }();
+  return off;
+}
+template <class... P>
+static bool aligned16(const P *...p) {   // nullptr counts as aligned
+  return ((reinterpret_cast<uintptr_t>(p) | ...) & 15u) == 0;
+}
+
 static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t stream) {
   MpcBackArgs a = a_in;
   if (a.sync != nullptr) {   // fresh decision slots for this launch
@@ -89,9 +99,23 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     if (e != hipSuccess) return (int)e;
   }
   void *args1[] = {&a};
+  // per-trajectory termination, whole wavefronts of four trajectories, 16-byte aligned runs: inputs through the LDS-DMA
+  // ring of mpc_dma_kernels.hpp (DMPC_NO_MPC_DMA=1: the register-bank kernel, for A/B timing)
+  const bool dma_ok = a.sync == nullptr && a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
+                      aligned16(a.C, a.c, a.F, a.f, a.controls, a.lower, a.upper, a.states);
 #define X(NX_, NU_, L_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                               \
     constexpr int GPB = 256 / L_;                                                                             \
+    if constexpr (L_ == 16) {                                                                                 \
+      constexpr int kD = MpcBackDmaLayout<NX_, NU_, 2>::kDma, DB_ = kD == 1 ? 8 : kD <= 4 ? 4 : 2;            \
+      if constexpr (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes() <= 65536) {                                  \
+        if (dma_ok) {                                                                                         \
+          hipLaunchKernelGGL((mpc_backward_rec_dma_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16), dim3(256),  \
+                             (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes()), stream, a);                      \
+          return (int)hipGetLastError();                                                                      \
+        }                                                                                                     \
+      }                                                                                                       \
+    }                                                                                                         \
     if (a.sync != nullptr)                                                                                    \
       return launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, L_>),       \
                                 dim3((a.B + GPB - 1) / GPB), dim3(256), args1, 0, stream);                    \

@@ -73,6 +73,12 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
   QpTermination term;
   term.slots = a.sync;
   term.n_blocks = n_blocks;
+#ifdef DMPC_MPC_TIMING   // scripts/microbench/mpc_phases.hip: s_memtime stamps (100 MHz), workgroup 0 / thread 0 reports through a.info
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#define DMPC_MSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define DMPC_MSTAMP(i) do { } while (0)
+#endif
 
   // Inputs of one timestep, column-per-lane.  One wavefront per SIMD: nothing else hides HBM latency, so the loads
   // of step t-2 are issued before step t is computed (three banks rotated statically - hipcc drains vmcnt at a loop
@@ -116,9 +122,14 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
 
   auto step = [&](int t, const Slot &sl) {
     const size_t tb = (size_t)t * B + b;
+    DMPC_MSTAMP(6);
     float Q[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) Q[i] = sl.Q[i];
+#ifdef DMPC_MPC_TIMING
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMPC_MPC_TIMING_VMCNT) : "memory");
+    DMPC_MSTAMP(0);
+#endif
     if (expand) {   // c_hat = C tau + c: row sums over the matrix columns land in the affine column   :305-317
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
@@ -136,6 +147,7 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
       Blk::vf(W, V, Fc);   // mpc_step.py:110,116
       Blk::ftw(Q, Fc, W);
     }
+    DMPC_MSTAMP(1);
     // every lane gets Quu and qu                                             :119-124
     float Quu[NU][NU], qu[NU], lo[NU], hi[NU];
     static_for<0, NU>([&](auto l) {
@@ -153,7 +165,9 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
     float kt[NU];
 #pragma unroll
     for (int m = 0; m < NU; ++m) kt[m] = kprev[m];
+    DMPC_MSTAMP(2);
     pnqp_solve<NU>(Quu, qu, lo, hi, kt, /*warm=*/t != T - 1, a.n_qp_iter, qp, term);
+    DMPC_MSTAMP(3);
     n_total += 1 + qp.it;
     if (!qp.converged) info_bits |= 4;
 #pragma unroll
@@ -178,6 +192,7 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
         else if (lane < NX) a.Ks[(tb * NU + m) * NX + lane] = Kt[m];
       }
     }
+    DMPC_MSTAMP(4);
     if (t > 0) {  // V, v from the UNMASKED blocks                                :165-166
       float R[NU];
 #pragma unroll
@@ -190,6 +205,7 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
       for (int i = 0; i < NX; ++i) V[i] = Q[i];
       Blk::vupd(V, Q, Kt, R);
     }
+    DMPC_MSTAMP(5);
   };
 
   Slot sa, sb, sc;
@@ -211,6 +227,12 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
     a.n_qp_total[b] = n_total;
     if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
   }
+#ifdef DMPC_MPC_TIMING
+  if (block == 0 && threadIdx.x == 0) {
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(a.info);
+    for (int i = 0; i < 8; ++i) out[i] = tacc[i];
+  }
+#endif
 }
 
 template <int NX, int NU, int L>

@@ -79,11 +79,146 @@ __device__ __forceinline__ float pnqp_obj(const float (&H)[N][N], const float (&
   return fmaf(0.5f, quad, lin);
 }
 
+// sqrtf(n2) >= kPnqpDxTol  <=>  n2 >= kPnqpDxTolSq: sqrtf is correctly rounded and monotonic, and this is the smallest
+// float32 whose root reaches the tolerance (0x322BCC76 = 9.99999905e-09; its predecessor's root is below 1e-4f).
+// Same decisions, NaN included (both comparisons are false), without the ~20 instructions of an IEEE square root.
+constexpr unsigned kPnqpDxTolSqBits = 0x322BCC76u;
+
+template <int N>
+__device__ __forceinline__ void pnqp_cold_start(const float (&H)[N][N], const float (&q)[N], float (&x)[N]) {
+  if constexpr (N == 1) {  // x_init = -H^-1 q                                        pnqp.py:75-83
+    x[0] = -fast_rcp(H[0][0]) * q[0];
+  } else {
+    float A[N][N], ri[N];
+    int piv[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) A[r][c] = H[r][c];
+    lu_factor_rinv<N>(A, piv, ri);
+#pragma unroll
+    for (int r = 0; r < N; ++r) x[r] = q[r];
+    lu_solve_rinv<N>(A, piv, ri, x);
+#pragma unroll
+    for (int r = 0; r < N; ++r) x[r] = -x[r];
+  }
+}
+
+// Per-row termination, written for a wavefront whose lanes carry different rows (or the same row redundantly): both
+// loops are WAVE-UNIFORM (they run while any lane still needs them, decided by one ballot and a scalar branch) and the
+// lanes that are finished keep their state by construction instead of being masked off -
+//   * a row that has converged keeps its x, so every later pass recomputes the same gradient, free set and
+//     factorisation from it: `res` ends up as the pass that converged left it, with no per-field selects;
+//   * a row whose Armijo test has passed keeps its alpha, so every later trial recomputes the same candidate; the
+//     trial counter is common to all rows, so rows that stop on the cap stop together with the loop.
+// hipcc structurises the data-dependent loops of the straightforward form below (kept for the batch-coupled mode) into
+// nested exec-mask bookkeeping that costs more than the arithmetic: 42-47 % of mpc_backward_rec's time went there
+// (scripts/microbench/mpc_phases.hip).  Same arithmetic, same order, same results as that form with slots == nullptr.
+template <int N>
+__device__ __forceinline__ void pnqp_solve_rows(const float (&H)[N][N], const float (&q)[N], const float (&lo)[N],
+                                                const float (&hi)[N], float (&x)[N], bool warm, int n_iter,
+                                                PnqpResult<N> &res) {
+  if (!warm) pnqp_cold_start<N>(H, q, x);
+#pragma unroll
+  for (int r = 0; r < N; ++r) x[r] = fminf(fmaxf(x[r], lo[r]), hi[r]);  // :93
+  res.converged = false;
+  res.it = n_iter - 1;
+#pragma unroll
+  for (int r = 0; r < N; ++r) {
+    res.free_[r] = true;
+    res.piv[r] = r + 1;
+    res.rinv[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < N; ++c) res.fac[r][c] = 0.f;
+  }
+  const float tol_sq = __builtin_bit_cast(float, kPnqpDxTolSqBits);
+  bool done = false;
+  for (int i = 0; i < n_iter; ++i) {
+    float g[N], gf[N], dx[N];
+    bool clampd[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {  // grad = Hx + q                                    :98
+      float acc = q[r];
+#pragma unroll
+      for (int c = 0; c < N; ++c) acc = fmaf(H[r][c], x[c], acc);
+      g[r] = acc;
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r) {  // exact float equality, as the reference           :110
+      clampd[r] = ((x[r] == lo[r]) && (g[r] > 0.f)) || ((x[r] == hi[r]) && (g[r] < 0.f));
+      gf[r] = clampd[r] ? 0.f : g[r];
+      res.free_[r] = !clampd[r];
+    }
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+      for (int c = 0; c < N; ++c) {  // H_f = H on free x free, 0 elsewhere, + 1e-11 I     :124-129
+        float v = (clampd[r] || clampd[c]) ? 0.f : H[r][c];
+        if (r == c) v += kPnqpReg;
+        res.fac[r][c] = v;
+      }
+    if constexpr (N == 1) {
+      res.rinv[0] = fast_rcp(res.fac[0][0]);
+      dx[0] = -res.rinv[0] * gf[0];  // :134
+    } else {
+      lu_factor_rinv<N>(res.fac, res.piv, res.rinv);  // :136
+#pragma unroll
+      for (int r = 0; r < N; ++r) dx[r] = gf[r];
+      lu_solve_rinv<N>(res.fac, res.piv, res.rinv, dx);
+#pragma unroll
+      for (int r = 0; r < N; ++r) dx[r] = -dx[r];
+    }
+    float n2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < N; ++r) n2 = fmaf(dx[r], dx[r], n2);
+    const bool large = n2 >= tol_sq;               // :139-140 (a NaN norm counts as converged there too)
+    if (!done && !large) {                         // :141-144: this row no longer moves
+      res.it = i;
+      res.converged = true;
+    }
+    done = done || !large;
+    if (__builtin_amdgcn_ballot_w64(!done) == 0) return;
+    // backtracking line search (:162-190), lhs as in the form below
+    float alpha = 1.0f;
+    float xh[N];
+    bool searching = !done;
+    int count = 0;
+    do {
+      float d[N];
+      float gd = 0.f, dHd = 0.f;
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        xh[r] = fminf(fmaxf(fmaf(alpha, dx[r], x[r]), lo[r]), hi[r]);  // :173
+        d[r] = xh[r] - x[r];
+        gd = fmaf(g[r], d[r], gd);
+      }
+#pragma unroll
+      for (int r = 0; r < N; ++r) {
+        float hd = 0.f;
+#pragma unroll
+        for (int c = 0; c < N; ++c) hd = fmaf(H[r][c], d[c], hd);
+        dHd = fmaf(d[r], hd, dHd);
+      }
+      const float lhs = fmaf(0.5f * dHd, fast_rcp(gd), 1.0f);   // :175-176
+      const bool fails = searching && lhs <= kPnqpGamma;        // false for NaN, like numpy's max(nan) <= GAMMA
+      alpha = fails ? alpha * kPnqpDecay : alpha;               // :185-186
+      ++count;
+      searching = fails && count < kPnqpMaxLs;                  // :172
+    } while (__builtin_amdgcn_ballot_w64(searching) != 0);
+#pragma unroll
+    for (int r = 0; r < N; ++r) x[r] = done ? x[r] : xh[r];    // :190
+  }
+}
+
 // x: in = warm start (if warm) ; out = solution.
 template <int N>
 __device__ __forceinline__ void pnqp_solve(const float (&H)[N][N], const float (&q)[N], const float (&lo)[N],
                                            const float (&hi)[N], float (&x)[N], bool warm, int n_iter,
                                            PnqpResult<N> &res, QpTermination &term) {
+  if (term.slots == nullptr) {   // uniform
+    pnqp_solve_rows<N>(H, q, lo, hi, x, warm, n_iter, res);
+    return;
+  }
   if (!warm) {  // x_init = -H^-1 q                                                   pnqp.py:75-83
     if constexpr (N == 1) {
       x[0] = -fast_rcp(H[0][0]) * q[0];
