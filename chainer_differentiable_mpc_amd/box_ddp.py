@@ -63,6 +63,7 @@ class BoxDDP(torch.nn.Module):
         self.status = None
         self.info = None            # MPC step flags of the device loop, per trajectory
         self._bounds_on = None
+        self._u_zero = None
         self._best_norm_max = None
         self.n_iter = 0
         if isinstance(u_lower, (int, float)):       # scalar bounds are broadcast to [T,B,nu] (:68-90)
@@ -106,7 +107,7 @@ class BoxDDP(torch.nn.Module):
         if isinstance(dynamics, LinDx):
             kind, params, Fd, fd = 0, None, dynamics.F, dynamics.f
         elif hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x_init, u) and (nx, nu) == (3, 1):
-            g_, m_, l_ = (float(v) for v in dynamics.params.detach().cpu().tolist())
+            g_, m_, l_ = dynamics.host_params()
             params = (ctypes.c_float * 5)(g_, m_, l_, float(dynamics.dt), float(dynamics.max_torque))
             kind, Fd, fd = 1, None, None
         else:
@@ -125,13 +126,14 @@ class BoxDDP(torch.nn.Module):
         if f is not None and list(f.shape) != [T - 1, B, nx]:
             return None
         u0, lo_, hi_ = _lib.f32c(u, d), _lib.f32c(lo, d), _lib.f32c(hi, d)
-        # MPCstep's input asserts (mpc_step.py:133-138), evaluated on the device and read with the loop state
-        bad_in = torch.stack((torch.isnan(u0).any(), (lo_ > hi_).any()))
-        f32 = dict(dtype=torch.float32, device=d)
-        bx, bu = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32)
-        bc, bn, ln = torch.empty((B,), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
-        state = torch.empty((8,), dtype=torch.int32, device=d)
-        info = torch.zeros((B,), dtype=torch.int32, device=d)
+        # one float and one int32 allocation per solve; the input asserts of MPCstep (mpc_step.py:133-138) and the
+        # reductions over info / full_du_norm come back in state[4:8] with the loop state (box_ddp_summary_kernel)
+        n_x, n_u = T * B * nx, T * B * nu
+        out = torch.empty((n_x + n_u + 3 * B,), dtype=torch.float32, device=d)
+        bx, bu = out[:n_x].view(T, B, nx), out[n_x:n_x + n_u].view(T, B, nu)
+        bc, bn, ln = out[n_x + n_u:].view(3, B).unbind(0)
+        ints = torch.zeros((B + 8,), dtype=torch.int32, device=d)
+        info, state = ints[:B], ints[B:]
         need = lib.dmpc_box_ddp_workspace_bytes(T, B, nx, nu)
         ws = _workspace(need, d)
         with torch.cuda.device(d):
@@ -146,10 +148,7 @@ class BoxDDP(torch.nn.Module):
         if rc == _lib.E_UNSUPPORTED:
             return None
         _lib.check(rc, "dmpc_box_ddp")
-        n_bad = ((info & _lib.INFO_NONFINITE) != 0).sum()
-        summary = torch.cat((state[:4], bad_in.to(torch.int32), n_bad.to(torch.int32)[None],
-                             (bn.max() > self.eps).to(torch.int32)[None]))
-        st = summary.cpu().tolist()               # the one synchronisation of the loop
+        st = state.cpu().tolist()                 # the one synchronisation of the loop
         self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
         assert not st[4]
         assert not st[5], " lower is larger than upper"
@@ -175,7 +174,9 @@ class BoxDDP(torch.nn.Module):
             self._bounds_on = (key, self.u_lower.to(device=dev, dtype=dt), self.u_upper.to(device=dev, dtype=dt))
         lo, hi = self._bounds_on[1], self._bounds_on[2]
         if self.u_init is None:
-            u = torch.zeros((T, B, nu), dtype=dt, device=dev)
+            if self._u_zero is None or self._u_zero[0] != key:   # read-only for every consumer below: made once
+                self._u_zero = (key, torch.zeros((T, B, nu), dtype=dt, device=dev))
+            u = self._u_zero[1]
         else:
             u = _as_tensor(self.u_init).to(device=dev, dtype=dt)
             if list(u.shape) == [T, nu]:
@@ -260,8 +261,25 @@ class BoxDDP(torch.nn.Module):
                 self._say("Not Converged ")
         x, u = best['x'], best['u']
         costs = best['costs']
+        unconverged = self._best_norm_max if last_norm is not None and self._best_norm_max is not None \
+            else (float(best['full_du_norm'].max()) > self.eps)
+        fused = hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x[0], u) and isinstance(cost, QuadCost)
+        # Can anything upstream receive a gradient?  Decidable before the Taylor models are built when both models are
+        # plain tensors: then, with nothing to differentiate, the no-op node and the detach blend below (which returns
+        # its input unchanged when there is no graph) are skipped - no launches after the loop's one read-back.
+        leaves = None
+        if isinstance(cost, QuadCost) and (fused or isinstance(dynamics, LinDx)):
+            leaves = [x_init, cost.C, cost.c] + ([dynamics.F, dynamics.f] if isinstance(dynamics, LinDx) else [])
+        if not torch.is_grad_enabled() or (leaves is not None and not any(
+                isinstance(t, torch.Tensor) and t.requires_grad for t in leaves)):
+            if self.detach_unconverged and unconverged:
+                if self.verbose:
+                    print("LQR Warning: All examples did not converge to a fixed point.")
+                    print("Detaching and *not* backpropping through the bad examples.")
+                warnings.warn("LQR Warning: All examples did not converge to a fixed point.")
+            return x, u, costs
         # Taylor models at the best point and a no-op MPCstep node that carries the gradient (:234-259)
-        if hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x[0], u) and isinstance(cost, QuadCost):
+        if fused:
             _, Fm, fm = dynamics.rollout_linearize(x[0], u)   # constants of the graph: the pendulum is not learnt
             Cm, cm = cost.C, cost.c
         else:
@@ -277,8 +295,6 @@ class BoxDDP(torch.nn.Module):
         needs_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (Cm, cm, Fm, fm, x_init))
         if needs_graph:
             x, u = node.apply((x[0].detach(), Cm, cm, Fm, fm))
-        unconverged = self._best_norm_max if last_norm is not None and self._best_norm_max is not None \
-            else (float(best['full_du_norm'].max()) > self.eps)
         if self.detach_unconverged and unconverged:                                        # :263-289
             if self.verbose:
                 print("LQR Warning: All examples did not converge to a fixed point.")

@@ -8,7 +8,10 @@
 //   box_ddp_keep_kernel      best x / u <- the step's x / u where the sample improved
 //
 // The loop state lives in `state[8]` (int32): [0] done, [1] n_iter, [2] status (1 Converged, 2 Not improved lim,
-// 3 Not Converged), [3] n_not_improved.  Once `done` is set every later launch of the chain returns at once (the
+// 3 Not Converged), [3] n_not_improved; the last launch of the chain (box_ddp_summary_kernel) adds what the caller
+// would otherwise reduce with a dozen small launches of its own: [4] NaN among the initial controls, [5] some
+// lower > upper (MPCstep's input asserts, mpc_step.py:133-138), [6] trajectories flagged non-finite, [7] the best
+// iterate's full_du_norm exceeds eps somewhere (box_ddp.py:263).  Once `done` is set every later launch of the chain returns at once (the
 // MPC kernels test the same flag), so the host may enqueue max_iter iterations blindly and synchronise once.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -187,6 +190,38 @@ __device__ __forceinline__ void box_ddp_select_body(const DdpSelectArgs &a) {
 
 __global__ __launch_bounds__(kDdpSelectThreads) void box_ddp_select_kernel(const DdpSelectArgs a) {
   box_ddp_select_body<kDdpSelectThreads>(a);
+}
+
+// one workgroup; n_u = T * B * nu
+__global__ __launch_bounds__(1024) void box_ddp_summary_kernel(size_t n_u, int B, const float *__restrict__ u_init,
+                                                               const float *__restrict__ lower, const float *__restrict__ upper,
+                                                               const int32_t *__restrict__ info, int nonfinite_bit,
+                                                               const float *__restrict__ best_norm, float eps,
+                                                               int32_t *__restrict__ state) {
+  int nan_u = 0, bad_box = 0, n_bad = 0, above = 0;
+  for (size_t e = threadIdx.x; e < n_u; e += blockDim.x) {
+    const float v = u_init[e];
+    nan_u |= !(v == v);
+    bad_box |= lower[e] > upper[e];
+  }
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    if (info != nullptr) n_bad += (info[b] & nonfinite_bit) != 0;
+    above |= best_norm[b] > eps;
+  }
+  nan_u = __syncthreads_or(nan_u);
+  bad_box = __syncthreads_or(bad_box);
+  above = __syncthreads_or(above);
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  if (n_bad != 0) atomicAdd(&s_cnt, n_bad);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    state[4] = nan_u != 0;
+    state[5] = bad_box != 0;
+    state[6] = s_cnt;
+    state[7] = above != 0;
+  }
 }
 
 __global__ __launch_bounds__(256) void box_ddp_keep_kernel(int T, int B, int nx, int nu, const int32_t *__restrict__ keep,

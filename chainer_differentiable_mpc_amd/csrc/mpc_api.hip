@@ -422,8 +422,6 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   const size_t rows = (size_t)T * B;
   hipError_t e = hipMemsetAsync(state, 0, 8 * sizeof(int32_t), stream);
   if (e != hipSuccess) return (int)e;
-  e = hipMemcpyAsync(u_buf[0], u_init, rows * nu * sizeof(float), hipMemcpyDeviceToDevice, stream);
-  if (e != hipSuccess) return (int)e;
   const int32_t *done = state + kDdpDone;
   // Pendulum: the trajectory the line search accepts IS the next iteration's nominal one, and the search writes its
   // linearisation and re-centred cost while it writes the trajectory - the rollout + linearisation kernel runs for
@@ -431,7 +429,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   const bool fuse_lin = dyn_kind == 1 && !spec_line_search_disabled();
   float *x_buf[2] = {xs, x_new};
   for (int it = 0; it < max_iter; ++it) {
-    const float *u_cur = u_buf[it & 1];
+    const float *u_cur = it == 0 ? u_init : u_buf[it & 1];   // the first iteration reads the caller's controls in place
     float *u_new = u_buf[(it & 1) ^ 1];
     float *xs_it = fuse_lin ? x_buf[it & 1] : xs;
     float *xn_it = fuse_lin ? x_buf[(it & 1) ^ 1] : x_new;
@@ -468,6 +466,8 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
       hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
                          ip(w.keep), xn_it, u_new, x_best, u_best);
   }
+  hipLaunchKernelGGL(box_ddp_summary_kernel, dim3(1), dim3(1024), 0, stream, rows * nu, B, u_init, u_lower, u_upper, info,
+                     (int)DMPC_INFO_NONFINITE, du_norm_best, eps, state);
   return (int)hipGetLastError();
 }
 

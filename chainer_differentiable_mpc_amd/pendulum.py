@@ -85,6 +85,13 @@ class PendulumDx(torch.nn.Module):
         return (self.simple and isinstance(x_init, torch.Tensor) and x_init.is_cuda and u.is_cuda and
                 not self.params.requires_grad and not x_init.requires_grad and not u.requires_grad)
 
+    def host_params(self):
+        """(g, m, l) as Python floats; read back from the parameter tensor only when it has changed"""
+        key = (self.params.data_ptr(), self.params._version)
+        if getattr(self, "_host_params", None) is None or self._host_params[0] != key:
+            self._host_params = (key, tuple(float(v) for v in self.params.detach().cpu().tolist()[:3]))
+        return self._host_params[1]
+
     def rollout_linearize(self, x_init, u, want_model=True):
         """(x [T,B,3], F [T-1,B,3,4], f [T-1,B,3]) from x_init [B,3], u [T,B,1] in one kernel launch
         (`dmpc_pendulum_rollout_linearize`): get_traj + linearize_dynamics of the reference's BoxDDP loop"""
@@ -96,7 +103,7 @@ class PendulumDx(torch.nn.Module):
         x = torch.empty((T, B, 3), dtype=torch.float32, device=d)
         F = torch.empty((max(T - 1, 0), B, 3, 4), dtype=torch.float32, device=d) if want_model else None
         f = torch.empty((max(T - 1, 0), B, 3), dtype=torch.float32, device=d) if want_model else None
-        g_, m_, l_ = (float(v) for v in self.params.detach().cpu().tolist())
+        g_, m_, l_ = self.host_params()
         with torch.cuda.device(d):
             rc = lib.dmpc_pendulum_rollout_linearize(T, B, _lib.ptr(x0), _lib.ptr(ud), g_, m_, l_, float(self.dt),
                                                      float(self.max_torque), _lib.ptr(x), _lib.ptr(F), _lib.ptr(f),

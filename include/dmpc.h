@@ -186,7 +186,10 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
  * (:223-230), all decided on the device: max_iter iterations are enqueued, those after the stop are no-ops.
  *   u_init [T,B,nu];  outputs x_best [T,B,nx], u_best [T,B,nu], costs_best [B], du_norm_best [B] (full_du_norm of
  *   the best iterate), du_norm_last [B] (of the last executed step, box_ddp.py:263-289 reads it);
- *   state [8] int32: [0] stopped early, [1] iterations run, [2] 1 Converged / 2 Not improved lim / 3 Not Converged;
+ *   state [8] int32: [0] stopped early, [1] iterations run, [2] 1 Converged / 2 Not improved lim / 3 Not Converged,
+ *   [3] iterations without improvement, and - reduced by the last launch of the chain, so that a caller needs ONE
+ *   read-back per solve - [4] NaN in u_init, [5] some u_lower > u_upper (the input asserts of mpc_step.py:133-138),
+ *   [6] trajectories whose info carries DMPC_INFO_NONFINITE (0 without info), [7] du_norm_best > eps somewhere;
  *   scrambled_norm != 0 reproduces the reference's reshape in full_du_norm (mpc_step.py:261-263);
  *   batch_coupled != 0: batch-global PNQP termination inside every step (as dmpc_mpc_backward_rec);
  *   info [B] accumulates the MPC step flags of every iteration (caller zeroes it).                              */
