@@ -92,7 +92,18 @@ static bool aligned16(const P *...p) {   // nullptr counts as aligned
   return ((reinterpret_cast<uintptr_t>(p) | ...) & 15u) == 0;
 }
 
-static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t stream) {
+// workgroups that share the bookkeeping of one box-DDP iteration inside the fused sweep launch: 256 rows each
+static int select_parts(int B) { const int n = (B + 255) / 256; return n < 1 ? 1 : (n > 8 ? 8 : n); }
+
+// can launch_mpc_back stage this problem's inputs through the LDS-DMA ring?
+static bool mpc_back_dma_ok(const MpcBackArgs &a) {
+  return a.sync == nullptr && a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
+         aligned16(a.C, a.c, a.F, a.f, a.controls, a.lower, a.upper, a.states);
+}
+
+// sel != nullptr (nx = 3, nu = 1 and mpc_back_dma_ok only): one more workgroup runs box_ddp_select_body(*sel)
+static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t stream, const DdpSelectArgs *sel = nullptr,
+                           unsigned *sel_sync = nullptr) {
   MpcBackArgs a = a_in;
   if (a.sync != nullptr) {   // fresh decision slots for this launch
     const hipError_t e = hipMemsetAsync(a.sync, 0, coupled_bytes(a.T, a.n_qp_iter), stream);
@@ -101,14 +112,20 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   void *args1[] = {&a};
   // per-trajectory termination, whole wavefronts of four trajectories, 16-byte aligned runs: inputs through the LDS-DMA
   // ring of mpc_dma_kernels.hpp (DMPC_NO_MPC_DMA=1: the register-bank kernel, for A/B timing)
-  const bool dma_ok = a.sync == nullptr && a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
-                      aligned16(a.C, a.c, a.F, a.f, a.controls, a.lower, a.upper, a.states);
+  const bool dma_ok = mpc_back_dma_ok(a);
 #define X(NX_, NU_, L_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                               \
     constexpr int GPB = 256 / L_;                                                                             \
     if constexpr (L_ == 16) {                                                                                 \
       constexpr int kD = MpcBackDmaLayout<NX_, NU_, 2>::kDma, DB_ = kD == 1 ? 8 : kD <= 4 ? 4 : 2;            \
       if constexpr (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes() <= 65536) {                                  \
+        if (dma_ok && sel != nullptr) {                                                                       \
+          const int n_sel = select_parts(a.B);                                                                \
+          hipLaunchKernelGGL((mpc_backward_rec_dma_select_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16 + n_sel), \
+                             dim3(256), (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes()), stream, a, *sel, n_sel, \
+                             sel_sync);                                                                       \
+          return (int)hipGetLastError();                                                                      \
+        }                                                                                                     \
         if (dma_ok) {                                                                                         \
           hipLaunchKernelGGL((mpc_backward_rec_dma_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16), dim3(256),  \
                              (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes()), stream, a);                      \
@@ -123,6 +140,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
                        a);                                                                                    \
     return (int)hipGetLastError();                                                                            \
   }
+  if (sel != nullptr && !(dma_ok && nx == 3 && nu == 1 && sel_sync != nullptr)) return DMPC_E_BADARG;   // callers ask mpc_back_dma_ok first
   DMPC_MPC_SHAPES(X)
 #undef X
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
@@ -154,8 +172,14 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     // candidate keeps its trajectory in LDS (T * 4 KB per workgroup) when that fits
     const size_t lds = (size_t)a.T * 4 * 256 * sizeof(float);
     a.traj_in_lds = lds <= 96 * 1024 ? 1 : 0;
-    hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel, dim3((a.B + 15) / 16), dim3(256),
-                       a.traj_in_lds ? lds : 0, stream, a);
+    const bool dma = a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
+                     aligned16(a.C, a.c, a.Ks, a.ks, a.controls, a.lower, a.upper, a.states);
+    if (dma)
+      hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel<true>, dim3((a.B + 15) / 16), dim3(256),
+                         (a.traj_in_lds ? lds : 0) + SpecDmaLayout::lds_bytes(), stream, a);
+    else
+      hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel<false>, dim3((a.B + 15) / 16), dim3(256),
+                         a.traj_in_lds ? lds : 0, stream, a);
     return (int)hipGetLastError();
   }
 #define X(NX_, NU_, L_)                                                                                      \
@@ -203,7 +227,7 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
 
 // workspace of the device-driven box-DDP loop (dmpc_box_ddp)
 struct DdpWs {
-  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, sync, total;
+  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, info_back, sel_sync, sync, total;
 };
 static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   const size_t ns = nx + nu, TB = (size_t)T * B, fl = sizeof(float);
@@ -230,6 +254,8 @@ static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   w.nqp = take((size_t)B * sizeof(int32_t));
   w.nls = take((size_t)B * sizeof(int32_t));
   w.keep = take((size_t)B * sizeof(int32_t));
+  w.info_back = take((size_t)B * sizeof(int32_t));
+  w.sel_sync = take(4 * sizeof(unsigned));
   w.sync = take(coupled_bytes(T, kSyncQpIterMax));
   w.total = off;
   return w;
@@ -428,6 +454,9 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   // the first iteration only, the nominal states ping-pong between the two state buffers.
   const bool fuse_lin = dyn_kind == 1 && !spec_line_search_disabled();
   float *x_buf[2] = {xs, x_new};
+  const bool copy_here = B <= kDdpCopyHereMaxB && rows * (size_t)(nx + nu) <= kDdpCopyHereMaxElems;
+  bool fused_select = false;   // decided at the first sweep: the bookkeeping of iteration i rides in sweep i + 1's launch
+  DdpSelectArgs sa{};
   for (int it = 0; it < max_iter; ++it) {
     const float *u_cur = it == 0 ? u_init : u_buf[it & 1];   // the first iteration reads the caller's controls in place
     float *u_new = u_buf[(it & 1) ^ 1];
@@ -448,26 +477,47 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     // re-centres c itself
     MpcBackArgs ba{T, B, C, dyn_kind == 1 ? c_back : c, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks,
                    ip(w.nqp), info, done, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
-                   dyn_kind == 1 ? nullptr : xs_it};
-    int rc = launch_mpc_back(nx, nu, ba, stream);
+                   dyn_kind == 1 ? nullptr : xs_it, 0};
+    if (it == 0) fused_select = fuse_lin && nx == 3 && nu == 1 && copy_here && mpc_back_dma_ok(ba);
+    if (fused_select && info != nullptr) {   // the sweep may run ahead of `done`: its flags count only if the search follows
+      ba.info = ip(w.info_back);
+      ba.info_store = 1;
+    }
+    if (it == 0 && fused_select) {   // the words the bookkeeping workgroups meet at
+      e = hipMemsetAsync(base + w.sel_sync, 0, 4 * sizeof(unsigned), stream);
+      if (e != hipSuccess) return (int)e;
+    }
+    int rc = launch_mpc_back(nx, nu, ba, stream, fused_select && it > 0 ? &sa : nullptr,
+                             reinterpret_cast<unsigned *>(base + w.sel_sync));
     if (rc != 0) return rc;
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs_it, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
                   dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1, costs, old,
                   alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done,
-                  fuse_lin ? fp(w.F) : nullptr, fuse_lin ? fp(w.f) : nullptr, fuse_lin ? c_back : nullptr};
+                  fuse_lin ? fp(w.F) : nullptr, fuse_lin ? fp(w.f) : nullptr, fuse_lin ? c_back : nullptr, 0,
+                  fused_select && info != nullptr ? ip(w.info_back) : nullptr};
     rc = launch_mpc_fwd(nx, nu, fa, stream);
     if (rc != 0) return rc;
-    const bool copy_here = B <= kDdpCopyHereMaxB && rows * (size_t)(nx + nu) <= (size_t)64 * 1024;
-    DdpSelectArgs sa{it, T, B, nx, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
-                     costs_best, du_norm_best, du_norm_last, ip(w.keep), state, copy_here ? 1 : 0, xn_it, u_new,
-                     x_best, u_best};
-    hipLaunchKernelGGL(box_ddp_select_kernel, dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
+    // best-so-far update and stop tests of this iteration                                   box_ddp.py:200-230
+    sa = DdpSelectArgs{it, T, B, nx, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
+                       costs_best, du_norm_best, du_norm_last, ip(w.keep), state, copy_here ? 1 : 0, xn_it, u_new,
+                       x_best, u_best};
+    if (fused_select) continue;   // rides in the next sweep's launch (the last one: in the summary launch)
+    if (nx == 3 && nu == 1)
+      hipLaunchKernelGGL((box_ddp_select_kernel<3, 1>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
+    else
+      hipLaunchKernelGGL((box_ddp_select_kernel<0, 0>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
     if (!copy_here)
       hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
                          ip(w.keep), xn_it, u_new, x_best, u_best);
   }
+  // fused chain: the last iteration's bookkeeping - with the summary when one workgroup does it, else as the fused
+  // launch splits it
+  const bool split_last = fused_select && select_parts(B) > 1;
+  if (split_last)
+    hipLaunchKernelGGL((box_ddp_select_parts_kernel<3, 1>), dim3(select_parts(B)), dim3(256), 0, stream, sa,
+                       reinterpret_cast<unsigned *>(base + w.sel_sync));
   hipLaunchKernelGGL(box_ddp_summary_kernel, dim3(1), dim3(1024), 0, stream, rows * nu, B, u_init, u_lower, u_upper, info,
-                     (int)DMPC_INFO_NONFINITE, du_norm_best, eps, state);
+                     (int)DMPC_INFO_NONFINITE, du_norm_best, eps, state, sa, fused_select && !split_last ? 1 : 0);
   return (int)hipGetLastError();
 }
 

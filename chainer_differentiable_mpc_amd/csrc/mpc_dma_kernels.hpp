@@ -10,6 +10,7 @@
 // fetched by kDma (1 / 4) DMA instructions whose per-lane source pointers step back by one timestep, DB - 1 steps
 // ahead of the arithmetic, and nothing the compiler tracks is in flight across the loop.
 #pragma once
+#include "box_ddp_kernels.hpp"
 #include "dma_gather.hpp"
 #include "lqr_dma_kernel.hpp"
 #include "mpc_kernels.hpp"
@@ -31,7 +32,7 @@ struct MpcBackDmaLayout {
 
 // requires B % 4 == 0, 16-byte aligned arrays, a.sync == nullptr (checked by the launcher)
 template <int NX, int NU, int DB>
-__global__ __launch_bounds__(256) void mpc_backward_rec_dma_kernel(const MpcBackArgs a) {
+__device__ __forceinline__ void mpc_backward_rec_dma_body(const MpcBackArgs &a, const int block) {
   using Lay = MpcBackDmaLayout<NX, NU, DB>;
   constexpr int NS = NX + NU, L = 16;
   static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_dma_kernel(const MpcBack
   const int lane64 = threadIdx.x & 63;
   const int r = lane64 >> 4;  // trajectory within the wave
   const int lane = lane64 & 15;
-  const int b0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + wave) * 4);
+  const int b0 = __builtin_amdgcn_readfirstlane((block * 4 + wave) * 4);
   if (b0 >= a.B) return;      // whole wavefront (B % 4 == 0); no workgroup barrier below
   const int b = b0 + r;
   const bool has_f = a.f != nullptr;
@@ -236,8 +237,38 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_dma_kernel(const MpcBack
   wait_vmcnt<0>();
   if (lane == 0) {
     a.n_qp_total[b] = n_total;
-    if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+    if (a.info != nullptr) {
+      if (a.info_store) a.info[b] = info_bits;   // this sweep's flags alone (the caller merges them if the sweep counts)
+      else if (info_bits != 0) atomicOr(&a.info[b], info_bits);
+    }
   }
+}
+
+template <int NX, int NU, int DB>
+__global__ __launch_bounds__(256) void mpc_backward_rec_dma_kernel(const MpcBackArgs a) {
+  mpc_backward_rec_dma_body<NX, NU, DB>(a, blockIdx.x);
+}
+
+// The sweep of box-DDP iteration i + 1 with the bookkeeping of iteration i (box_ddp_select_body: best-so-far update, stop
+// tests) in ONE launch: the last n_sel workgroups do the bookkeeping (256 rows each) while the others sweep.  The sweep
+// needs nothing from it but the `done` flag, and a sweep that runs although the loop has just stopped only fills gains
+// nobody reads (the line search that follows is a separate launch and sees the flag); its flags go to a side buffer
+// for that reason.
+template <int NX, int NU, int DB>
+__global__ __launch_bounds__(256) void mpc_backward_rec_dma_select_kernel(const MpcBackArgs a, const DdpSelectArgs s,
+                                                                          const int n_sel, unsigned *sel_sync) {
+  const int n_back = (int)gridDim.x - n_sel;
+  if ((int)blockIdx.x >= n_back) {
+    box_ddp_select_body<256, NX, NU>(s, (int)blockIdx.x - n_back, n_sel, sel_sync);
+    return;
+  }
+  mpc_backward_rec_dma_body<NX, NU, DB>(a, blockIdx.x);
+}
+
+// the bookkeeping workgroups of the fused launch on their own (the last iteration has no next sweep to ride in)
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void box_ddp_select_parts_kernel(const DdpSelectArgs s, unsigned *sel_sync) {
+  box_ddp_select_body<256, NX, NU>(s, blockIdx.x, gridDim.x, sel_sync);
 }
 
 }  // namespace dmpc

@@ -11,7 +11,9 @@
 //   active_mask_kernel        active = |u-lo| <= 1e-8 | |u-hi| <= 1e-8 (:363-364) and -[dl_dx;dl_du].
 #pragma once
 #include "colwise.hpp"
+#include "dma_gather.hpp"
 #include "dpp_blocks_gen.hpp"
+#include "lqr_dma_kernel.hpp"
 #include "lqr_kernels.hpp"
 #include "pnqp_device.hpp"
 #include "riccati_blocks.hpp"
@@ -39,6 +41,7 @@ struct MpcBackArgs {
   // need_expand (mpc_step.py:305-317) inside the sweep: with `states` [T,B,nx] given, `c` is the ORIGINAL linear term
   // and the kernel forms c_hat_t = C_t [x_t; u_t] + c_t from the C rows it holds anyway (nullptr: c is used as given)
   const float *states;
+  int info_store;                       // != 0: info[b] = this sweep's flags (plain store) instead of an atomic OR
 };
 
 // `block` = the workgroup's index among the 256-thread workgroups that share the batch (blockIdx.x for the kernel below)
@@ -249,6 +252,22 @@ struct PendulumModel {
 __device__ __forceinline__ PendulumModel pendulum_model(float g, float m, float l, float dt, float max_torque) {
   return PendulumModel{3.f * g / (2.f * l), 3.f / (m * (l * l)), dt, max_torque};
 }
+// sin and cos of a small angle.  The rotation below takes them of the per-step increment wn * dt (|.| < pi/4 for any
+// angular velocity below 15 rad/s at dt = 0.05): no argument reduction is needed there, and the library routine's
+// reduction and its branches are a quarter of a rollout step's instructions.  Minimax kernels of the Cephes sinf / cosf
+// on [-pi/4, pi/4] (error below one ulp of the result); anything larger goes to the library.
+__device__ __forceinline__ void sincos_increment(float x, float &sn, float &cs) {
+  if (fabsf(x) <= 0.785398163f) {
+    const float z = x * x;
+    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    sn = fmaf(x * z, ps, x);
+    cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  } else {
+    sincosf(x, &sn, &cs);
+  }
+}
+
 __device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, float s, float w, float u, float &cn,
                                               float &sn, float &wn, float &nth) {
   const float uc = fminf(fmaxf(u, -p.max_torque), p.max_torque);
@@ -260,7 +279,7 @@ __device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, f
   const float ri = r2 > 0.f ? rsqrtf(r2) : 0.f;
   const float cu = r2 > 0.f ? c * ri : 1.f, su = s * ri;
   float sd, cd;
-  sincosf(wn * p.dt, &sd, &cd);
+  sincos_increment(wn * p.dt, sd, cd);
   cn = fmaf(cu, cd, -su * sd);
   sn = fmaf(su, cd, cu * sd);
   nth = 0.f;   // the absolute angle is not formed any more (callers use cn, sn)
@@ -321,6 +340,7 @@ struct MpcFwdArgs {
   // speculative search: every candidate keeps its trajectory in LDS (T * 4 floats per lane, T * 4 KB per workgroup)
   // and the accepted one is copied out instead of being rolled out a second time; 0 = no such buffer was given
   int traj_in_lds;
+  const int32_t *info_in;                // [B] flags to merge into info (the backward sweep's, when it ran ahead of `done`)
 };
 
 template <int NX, int NU, int L>
@@ -494,6 +514,18 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
 // them before the candidate collapses onto the nominal trajectory.  One lane per (trajectory, candidate): the 16
 // lanes of a group roll 16 consecutive step sizes out at once, the first one that is not worse than the old cost is
 // the one the sequential search stops at, and one more pass writes its trajectory.  Two passes instead of p* + 1.
+// DMA: the inputs of a timestep (the same for the 16 candidates of a trajectory, and one contiguous run per array for the
+// four trajectories of a wavefront) come through a ring of LDS slots filled by ONE per-lane gather LDS-DMA per step,
+// kSpecDmaDepth - 1 steps ahead (the scheme of mpc_dma_kernels.hpp); needs B % 4 == 0 and 16-byte aligned arrays.  The
+// ring sits behind the candidates' trajectories in dynamic LDS.
+constexpr int kSpecDmaDepth = 4;
+struct SpecDmaLayout {  // 16-byte chunks of one wave-step: [C | c | Ks | ks | u | lower | upper | x]
+  static constexpr int CH_C = 0, CH_c = 16, CH_K = 20, CH_k = 23, CH_u = 24, CH_lo = 25, CH_hi = 26, CH_x = 27, CH_END = 30;
+  static constexpr int SLOT = 256;  // floats per wave and timestep
+  static constexpr size_t lds_bytes() { return (size_t)4 * kSpecDmaDepth * SLOT * 4; }
+};
+
+template <bool DMA>
 __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdArgs &a, const int block) {
   constexpr int NX = 3, NU = 1, NS = 4, NC = 16;
   if (a.done != nullptr && *a.done != 0) return;
@@ -527,6 +559,60 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
     for (int i = 0; i < NS; ++i) {
       load_contig<NS>(a.C + (tb * NS + i) * NS, sl.C[i]);
       sl.cc[i] = a.c[tb * NS + i];
+    }
+  };
+  // ---- DMA ring (DMA only)
+  using Lay = SpecDmaLayout;
+  constexpr int DB = kSpecDmaDepth;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r4 = lane64 >> 4;
+  const int b0 = __builtin_amdgcn_readfirstlane((block * 4 + wave) * 4);
+  float *ring = traj + (a.traj_in_lds != 0 ? (size_t)T * NS * 256 : 0) + wave * (DB * Lay::SLOT);
+  unsigned ring_addr = 0;
+  unsigned long long ptr0 = 0, ptr = 0, str = 0;
+  if constexpr (DMA) {
+    if (b0 >= a.B) return;   // whole wavefront (B % 4 == 0); no workgroup barrier below
+    ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+    const int g = lane64;
+    const char *base_p = (const char *)a.C;
+    size_t per = 64;
+    int g0 = g;   // padding lanes: chunk 0 of C again
+    if (g < Lay::CH_c) { g0 = Lay::CH_C; }
+    else if (g < Lay::CH_K) { base_p = (const char *)a.c; per = 16; g0 = Lay::CH_c; }
+    else if (g < Lay::CH_k) { base_p = (const char *)a.Ks; per = 12; g0 = Lay::CH_K; }
+    else if (g < Lay::CH_u) { base_p = (const char *)a.ks; per = 4; g0 = Lay::CH_k; }
+    else if (g < Lay::CH_lo) { base_p = (const char *)a.controls; per = 4; g0 = Lay::CH_u; }
+    else if (g < Lay::CH_hi) { base_p = (const char *)a.lower; per = 4; g0 = Lay::CH_lo; }
+    else if (g < Lay::CH_x) { base_p = (const char *)a.upper; per = 4; g0 = Lay::CH_hi; }
+    else if (g < Lay::CH_END) { base_p = (const char *)a.states; per = 12; g0 = Lay::CH_x; }
+    ptr0 = (unsigned long long)base_p + (size_t)b0 * per + (size_t)(g - g0) * 16;
+    str = (unsigned long long)(B * per);
+  }
+  int ti = 0;  // timesteps the pointers may still advance
+  auto issue_next = [&](int slot) {
+    set_m0(__builtin_amdgcn_readfirstlane(ring_addr + (unsigned)slot * (Lay::SLOT * 4)));
+    dma16_gather<0>(ptr);
+    if (ti > 0) {  // past the horizon the last blocks are fetched again (never consumed): the count per step stays exact
+      ptr += str;
+      --ti;
+    }
+  };
+  auto read_slot = [&](const float *slot, Slot &sl) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      sl.xt[i] = slot[Lay::CH_x * 4 + r4 * NX + i];
+      sl.K[i] = slot[Lay::CH_K * 4 + r4 * NX + i];
+    }
+    sl.kk = slot[Lay::CH_k * 4 + r4];
+    sl.uc = slot[Lay::CH_u * 4 + r4];
+    sl.lb = slot[Lay::CH_lo * 4 + r4];
+    sl.ub = slot[Lay::CH_hi * 4 + r4];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+      for (int j = 0; j < NS; ++j) sl.C[i][j] = slot[Lay::CH_C * 4 + (r4 * NS + i) * NS + j];
+      sl.cc[i] = slot[Lay::CH_c * 4 + r4 * NS + i];
     }
   };
   auto quad = [&](const Slot &sl, const float (&tau)[NS]) {  // 1/2 tau'C tau + c'tau                util.py:162-198
@@ -617,13 +703,41 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
       }
     };
     Slot sa, sb;
-    load(0, sa);
-    for (int t = 0; t < T; t += 2) {
-      load(t + 1, sb);
-      step(t, sa);
-      if (t + 1 < T) {
-        load(t + 2, sa);
-        step(t + 1, sb);
+    if constexpr (DMA) {
+      // the software pipeline of mpc_backward_rec_dma_kernel, forward in time; the stores of a pass only make the
+      // counted wait more conservative
+      ptr = ptr0;
+      ti = T - 1;
+      static_for<0, DB>([&](auto j) { issue_next(j.value); });
+      wait_vmcnt<DB - 1>();
+      read_slot(ring, sa);
+      for (int t0 = 0; t0 < T; t0 += DB) {
+        static_for<0, DB>([&](auto j) {
+          const int t = t0 + j.value;
+          if (t < T) {
+            constexpr int nslot = (j.value + 1) % DB;
+            issue_next(j.value);
+            wait_vmcnt<DB - 1>();
+            if constexpr (j.value % 2 == 0) {
+              read_slot(ring + nslot * Lay::SLOT, sb);
+              step(t, sa);
+            } else {
+              read_slot(ring + nslot * Lay::SLOT, sa);
+              step(t, sb);
+            }
+          }
+        });
+      }
+      wait_vmcnt<0>();   // the ring is refilled from t = 0 by the next pass
+    } else {
+      load(0, sa);
+      for (int t = 0; t < T; t += 2) {
+        load(t + 1, sb);
+        step(t, sa);
+        if (t + 1 < T) {
+          load(t + 2, sa);
+          step(t + 1, sb);
+        }
       }
     }
   };
@@ -707,6 +821,7 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
   }
   if (!is_finite(cost_sel)) info_bits |= 2;
   if (live && k == 0) {
+    if (a.info_in != nullptr) info_bits |= a.info_in[b];
     a.costs[b] = cost_sel;
     if (a.old_costs != nullptr) a.old_costs[b] = old_cost;
     a.alphas[b] = alpha_sel;
@@ -715,8 +830,9 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
   }
 }
 
+template <bool DMA>
 __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(const MpcFwdArgs a) {
-  mpc_forward_rec_pendulum_spec_body(a, blockIdx.x);
+  mpc_forward_rec_pendulum_spec_body<DMA>(a, blockIdx.x);
 }
 
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
