@@ -220,13 +220,21 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash, masked=False):
+def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
     """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
     is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
-    rollout needs no change); the value update keeps the unmasked blocks (:143-145)."""
+    rollout needs no change); the value update keeps the unmasked blocks (:143-145).
+    mpc: MPCstep.backward_rec (mpc/mpc_step.py:70-173), backward sweep only - the clamped set of every step is not an
+    input but the result of the box QP min 1/2 k'Quu k + qu'k, lower - u <= k <= upper - u, solved IN the stream by the
+    projected-Newton iteration of mpc/pnqp.py:37-201 (per-trajectory termination, warm-started from the later step,
+    wave-uniform loops as pnqp_solve_rows of pnqp_device.hpp); k_t is its solution, K_t the masked solve with 1e-11 on
+    the diagonal (the QP's own last factorisation, :147-157), the value update keeps the unmasked blocks (:165-166).
+    u, lower, upper of the wave's four trajectories arrive as 12 nu dwords in the slot padding (the flag DMA of the
+    masked variant, one float per lane)."""
     L = Layout(nx, nu)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
+    assert not mpc or (masked and write_k and not stash)
     P = Prog()
     R = Regs(VBASE)
     # ---- operand names (C++ side: struct LqrAsmIn of lqr_asm_gen.hpp, filled by lqr_asm_kernel.hpp)
@@ -245,7 +253,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     NQ = 4 * ((ns + 3) // 4)            # MFMA accumulator tiles are 4 consecutive rows
     Q = [R.take(NQ if mfma else ns, align=4) for _ in range(3)]
     F = [R.take(nx) for _ in range(3)]
-    W = R.take(max(nx, 4), align=4)     # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V)
+    W = R.take(max(nx, 8 if mpc else 4), align=4)     # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V); mpc: the QP's temporaries
     G10 = R.take(1)[0]                  # MFMA path: row "1" of G^ = F^T v
     A = [R.take(nu) for _ in range(nu)]
     Kt = R.take(nu)
@@ -253,8 +261,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = R.take(13)
     MINPIV = R.take(1)[0]
     XV0 = R.take(1)[0]                  # x_init (lanes < nx), loaded by the stream itself
-    ACT = [R.take(nu) for _ in range(3)] if masked else None   # clamped-control flags of the slot in each register set
-    EPS = R.take(1)[0] if masked else None
+    ACT = [R.take(nu) for _ in range(3)] if masked and not mpc else None   # clamped-control flags of the slot in each register set
+    EPS = R.take(1)[0] if masked and not mpc else None
+    UC = [R.take(nu) for _ in range(3)] if mpc else None      # mpc: u_t, lower_t, upper_t of the slot in each register set
+    LB = [R.take(nu) for _ in range(3)] if mpc else None
+    UB = [R.take(nu) for _ in range(3)] if mpc else None
+    XK = R.take(nu) if mpc else None                          # QP iterate / k_t (the next step's warm start)
+    QU = R.take(nu) if mpc else None                          # qu in every lane
+    NQP = R.take(1)[0] if mpc else None                       # sum over t of the QP passes run          (mpc_step.py:145)
+    QINFO = R.take(1)[0] if mpc else None                     # 4 once a QP ran into the iteration cap
     Am = [R.take(nu) for _ in range(nu)] if masked else None   # masked Quu
     Rm = R.take(nu) if masked else None                        # masked right-hand side rows
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
@@ -280,6 +295,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     S_N, S_TF = "s70", "%[tf]"   # tf: time strides the DMA pointers may still take (an operand: it crosses the two asm blocks)
     S_KM, S_SM, S_UM, S_XM, S_HI = "s[72:73]", "s[74:75]", "s[76:77]", "s[88:89]", "s[90:91]"
     S_RET, S_STUB, S_JMP, S_TMP = "s[78:79]", "s[80:81]", "s[82:83]", "s84"
+    S_AFF = "s[100:101]"        # mpc: the lanes `aff` (the stash pairs above are the QP's masks there - no stash in that mode)
 
     def mask64(lanes):
         m16 = sum(1 << l for l in lanes)
@@ -356,11 +372,158 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
             P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][i], aq[i], off))
         for k in range(nx):
             P.raw("ds_read_b32 %s, %s offset:%d" % (F[s][k], af[k], off))
-        if masked:
+        if mpc:
+            P.uses(UC[s] + LB[s] + UB[s])
+            for a_, regs in enumerate((UC[s], LB[s], UB[s])):     # [u | lower | upper], 4 nu floats each
+                for m in range(nu):
+                    P.raw("ds_read_b32 %s, %%[am] offset:%d" % (regs[m], off + PADM + (a_ * 4 * nu + m) * 4))
+        elif masked:
             for m in range(nu):
                 P.raw("ds_read_u8 %s, %%[am] offset:%d" % (ACT[s][m], off + PADM + m))
 
-    def gains(s):
+    S_ACT = ["s[92:93]", "s[94:95]"]
+    QP_REG = "0x2d2febff"       # 1e-11f  (pnqp.py:73)
+    QP_TOLSQ = "0x322bcc76"     # smallest float32 whose root reaches 1e-4f (pnqp.py:140; pnqp_device.hpp kPnqpDxTolSqBits)
+    QP_GAMMA = "0x3dcccccd"     # 0.1f: GAMMA (pnqp.py:23) and the step decay (:163)
+    QP_MAXLS = 10               # pnqp.py:172
+
+    def rcp_newton(dst, src, tmp):
+        """dst = 1/src, v_rcp_f32 + one Newton step (fast_rcp of colwise.hpp: the QP's tests sit on these quotients)"""
+        P.v("v_rcp_f32_e32 %s, %s" % (dst, src), writes=(dst,), reads=(src,), trans=True)
+        P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tmp, src, dst), writes=(tmp,), reads=(src, dst))
+        P.v("v_fmac_f32_e32 %s, %s, %s" % (dst, tmp, dst), writes=(dst,), reads=(tmp, dst))
+
+    def neg_solve(Au, rhs, out):
+        """out = -Au^-1 rhs, nu x nu with partial pivoting in the operation order of lu_factor_rinv / lu_solve_rinv
+        (colwise.hpp; LAPACK getf2 / getrs), reciprocal pivots with a Newton step"""
+        if nu == 1:
+            rcp_newton(tRP, Au[0][0], tT)
+            P.v("v_mul_f32_e64 %s, %s, -%s" % (out[0], rhs[0], tRP), writes=(out[0],), reads=(rhs[0], tRP))
+            return
+        a00, a01, a10, a11 = Au[0][0], Au[0][1], Au[1][0], Au[1][1]
+        P.v("v_cmp_gt_f32_e64 vcc, |%s|, |%s|" % (a10, a00), reads=(a10, a00))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tP, a00, a10), writes=(tP,), reads=(a00, a10))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tL0, a10, a00), writes=(tL0,), reads=(a00, a10))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tPQ, a01, a11), writes=(tPQ,), reads=(a01, a11))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tM1, a11, a01), writes=(tM1,), reads=(a01, a11))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRA, rhs[0], rhs[1]), writes=(tRA,), reads=(rhs[0], rhs[1]))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tRB, rhs[1], rhs[0]), writes=(tRB,), reads=(rhs[0], rhs[1]))
+        rcp_newton(tRP, tP, tT)
+        P.v("v_mul_f32_e32 %s, %s, %s" % (tLL, tL0, tRP), writes=(tLL,), reads=(tL0, tRP))
+        P.v("v_fma_f32 %s, -%s, %s, %s" % (tD2, tLL, tPQ, tM1), writes=(tD2,), reads=(tLL, tPQ, tM1))
+        P.v("v_fma_f32 %s, -%s, %s, %s" % (tY1, tLL, tRA, tRB), writes=(tY1,), reads=(tLL, tRA, tRB))
+        rcp_newton(tRD, tD2, tT)
+        P.v("v_mul_f32_e64 %s, %s, -%s" % (out[1], tY1, tRD), writes=(out[1],), reads=(tY1, tRD))
+        P.v("v_fma_f32 %s, %s, %s, %s" % (tT2, tPQ, out[1], tRA), writes=(tT2,), reads=(tPQ, out[1], tRA))
+        P.v("v_mul_f32_e64 %s, %s, -%s" % (out[0], tT2, tRP), writes=(out[0],), reads=(tT2, tRP))
+
+    def masked_hessian(reg):
+        """Am = Quu on free x free, 0 elsewhere, + `reg` on the diagonal (a register or a literal), from S_ACT"""
+        if nu == 2:
+            P.raw("s_or_b64 s[96:97], s[92:93], s[94:95]")
+        for m in range(nu):
+            for l in range(nu):
+                if m == l:
+                    P.v("v_cndmask_b32_e64 %s, %s, 0, %s" % (Am[m][l], A[m][l], S_ACT[m]), writes=(Am[m][l],), reads=(A[m][l],))
+                    P.v("v_add_f32_e32 %s, %s, %s" % (Am[m][l], reg, Am[m][l]), writes=(Am[m][l],), reads=(Am[m][l],))
+                else:
+                    P.v("v_cndmask_b32_e64 %s, %s, 0, s[96:97]" % (Am[m][l], A[m][l]), writes=(Am[m][l],), reads=(A[m][l],))
+
+    def box_qp(s, first):
+        """PNQP (mpc/pnqp.py:37-201) on H = A (Quu, in every lane), q = QU, bounds LB/UB - UC of register set s; warm
+        start XK (first: cold start -H^-1 q, :75-83).  Leaves the solution in XK and the clamped set of the last pass in
+        S_ACT.  Every lane of a 16-lane row runs it on its trajectory's data; both loops are wave-uniform (they run
+        while any lane needs them) and finished lanes keep their state by construction - see pnqp_solve_rows."""
+        uniq[0] += 1
+        u_ = uniq[0]
+        LO, HI = LB[s], UB[s]                       # turned into the QP's bounds in place
+        Gv, DXv, XH, GD = W[0:nu], W[2:2 + nu], W[4:4 + nu], W[6:6 + nu]   # W is idle between the Q update and the next step
+        AL = G10
+        S_DONE, S_SRCH, S_T0, S_T1, S_T2 = "s[78:79]", "s[80:81]", "s[82:83]", "s[86:87]", "s[98:99]"
+        S_I, S_CNT = S_TMP, "s85"
+        for m in range(nu):
+            P.v("v_sub_f32_e32 %s, %s, %s" % (LO[m], LO[m], UC[s][m]), writes=(LO[m],), reads=(LO[m], UC[s][m]))   # mpc_step.py:136-138
+            P.v("v_sub_f32_e32 %s, %s, %s" % (HI[m], HI[m], UC[s][m]), writes=(HI[m],), reads=(HI[m], UC[s][m]))
+        if first:
+            neg_solve(A, QU, XK)
+        for m in range(nu):                                                                   # pnqp.py:93
+            P.v("v_max_f32_e32 %s, %s, %s" % (XK[m], XK[m], LO[m]), writes=(XK[m],), reads=(XK[m], LO[m]))
+            P.v("v_min_f32_e32 %s, %s, %s" % (XK[m], XK[m], HI[m]), writes=(XK[m],), reads=(XK[m], HI[m]))
+        P.raw("s_mov_b64 %s, 0" % S_DONE)
+        P.raw("s_mov_b32 %s, 0" % S_I)
+        P.label("Lqp%d_%%=" % u_, reset=False)   # (the back edge leaves no DPP / transcendental hazard open)
+        # grad = Hx + q (:98); clamped = at a bound with the gradient pushing outwards (:110, exact equality)
+        for m in range(nu):
+            P.v("v_fma_f32 %s, %s, %s, %s" % (Gv[m], A[m][0], XK[0], QU[m]), writes=(Gv[m],), reads=(A[m][0], XK[0], QU[m]))
+            for l in range(1, nu):
+                P.v("v_fmac_f32_e32 %s, %s, %s" % (Gv[m], A[m][l], XK[l]), writes=(Gv[m],), reads=(A[m][l], XK[l], Gv[m]))
+        for m in range(nu):
+            P.v("v_cmp_eq_f32_e64 %s, %s, %s" % (S_T0, XK[m], LO[m]), reads=(XK[m], LO[m]))
+            P.v("v_cmp_lt_f32_e64 %s, 0, %s" % (S_T1, Gv[m]), reads=(Gv[m],))
+            P.v("v_cmp_eq_f32_e64 %s, %s, %s" % (S_T2, XK[m], HI[m]), reads=(XK[m], HI[m]))
+            P.v("v_cmp_gt_f32_e64 vcc, 0, %s" % Gv[m], reads=(Gv[m],))
+            P.raw("s_and_b64 %s, %s, %s" % (S_T0, S_T0, S_T1))
+            P.raw("s_and_b64 %s, %s, vcc" % (S_T2, S_T2))
+            P.raw("s_or_b64 %s, %s, %s" % (S_ACT[m], S_T0, S_T2))
+        for m in range(nu):
+            P.v("v_cndmask_b32_e64 %s, %s, 0, %s" % (GD[m], Gv[m], S_ACT[m]), writes=(GD[m],), reads=(Gv[m],))
+        masked_hessian(QP_REG)                                                                # :124-129
+        neg_solve(Am, GD, DXv)                                                                # :134-136
+        P.v("v_mul_f32_e32 %s, %s, %s" % (tT, DXv[0], DXv[0]), writes=(tT,), reads=(DXv[0],))
+        for m in range(1, nu):
+            P.v("v_fmac_f32_e32 %s, %s, %s" % (tT, DXv[m], DXv[m]), writes=(tT,), reads=(DXv[m], tT))
+        P.v("v_cmp_le_f32_e32 vcc, %s, %s" % (QP_TOLSQ, tT), reads=(tT,))                     # large = |dx| >= 1e-4 (:139-140)
+        # one more pass counted for every lane that had not converged before this one (sum = 1 + it, mpc_step.py:145)
+        P.raw("s_not_b64 %s, %s" % (S_T0, S_DONE))
+        P.v("v_addc_co_u32_e64 %s, %s, %s, 0, %s" % (NQP, S_T1, NQP, S_T0), writes=(NQP,), reads=(NQP,))
+        P.raw("s_orn2_b64 %s, %s, vcc" % (S_DONE, S_DONE))                                    # done |= !large  (:141-144)
+        P.raw("s_cmp_eq_u64 %s, -1" % S_DONE)
+        P.raw("s_cbranch_scc1 Lqpx%d_%%=" % u_)
+        # backtracking line search (:162-190); lhs = 1 + 0.5 d'Hd / g'd as in pnqp_device.hpp
+        P.v("v_mov_b32_e32 %s, 1.0" % AL, writes=(AL,))
+        P.raw("s_not_b64 %s, %s" % (S_SRCH, S_DONE))
+        P.raw("s_mov_b32 %s, 0" % S_CNT)
+        P.label("Lls%d_%%=" % u_, reset=False)
+        for m in range(nu):
+            P.v("v_fma_f32 %s, %s, %s, %s" % (XH[m], AL, DXv[m], XK[m]), writes=(XH[m],), reads=(AL, DXv[m], XK[m]))   # :173
+            P.v("v_max_f32_e32 %s, %s, %s" % (XH[m], XH[m], LO[m]), writes=(XH[m],), reads=(XH[m], LO[m]))
+            P.v("v_min_f32_e32 %s, %s, %s" % (XH[m], XH[m], HI[m]), writes=(XH[m],), reads=(XH[m], HI[m]))
+        for m in range(nu):
+            P.v("v_sub_f32_e32 %s, %s, %s" % (GD[m], XH[m], XK[m]), writes=(GD[m],), reads=(XH[m], XK[m]))
+        P.v("v_mul_f32_e32 %s, %s, %s" % (tRA, Gv[0], GD[0]), writes=(tRA,), reads=(Gv[0], GD[0]))       # g'd
+        for m in range(1, nu):
+            P.v("v_fmac_f32_e32 %s, %s, %s" % (tRA, Gv[m], GD[m]), writes=(tRA,), reads=(Gv[m], GD[m], tRA))
+        for m in range(nu):                                                                    # d'Hd
+            P.v("v_mul_f32_e32 %s, %s, %s" % (tRB, A[m][0], GD[0]), writes=(tRB,), reads=(A[m][0], GD[0]))
+            for l in range(1, nu):
+                P.v("v_fmac_f32_e32 %s, %s, %s" % (tRB, A[m][l], GD[l]), writes=(tRB,), reads=(A[m][l], GD[l], tRB))
+            if m == 0:
+                P.v("v_mul_f32_e32 %s, %s, %s" % (tLL, GD[0], tRB), writes=(tLL,), reads=(GD[0], tRB))
+            else:
+                P.v("v_fmac_f32_e32 %s, %s, %s" % (tLL, GD[m], tRB), writes=(tLL,), reads=(GD[m], tRB, tLL))
+        rcp_newton(tRD, tRA, tT)
+        P.v("v_mul_f32_e32 %s, 0.5, %s" % (tLL, tLL), writes=(tLL,), reads=(tLL,))
+        P.v("v_fma_f32 %s, %s, %s, 1.0" % (tLL, tLL, tRD), writes=(tLL,), reads=(tLL, tRD))              # :175-176
+        P.v("v_cmp_ge_f32_e32 vcc, %s, %s" % (QP_GAMMA, tLL), reads=(tLL,))                               # lhs <= GAMMA
+        P.raw("s_and_b64 vcc, vcc, %s" % S_SRCH)                                                          # fails
+        P.v("v_mul_f32_e32 %s, %s, %s" % (tT, QP_GAMMA, AL), writes=(tT,), reads=(AL,))
+        P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (AL, AL, tT), writes=(AL,), reads=(AL, tT))            # :185-186
+        P.raw("s_add_u32 %s, %s, 1" % (S_CNT, S_CNT))
+        P.raw("s_cmp_lt_u32 %s, %d" % (S_CNT, QP_MAXLS))
+        P.raw("s_cselect_b64 %s, vcc, 0" % S_SRCH)                                                        # :172
+        P.raw("s_cmp_lg_u64 %s, 0" % S_SRCH)
+        P.raw("s_cbranch_scc1 Lls%d_%%=" % u_)
+        for m in range(nu):                                                                                # :190
+            P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (XK[m], XH[m], XK[m], S_DONE), writes=(XK[m],), reads=(XH[m], XK[m]))
+        P.raw("s_add_u32 %s, %s, 1" % (S_I, S_I))
+        P.raw("s_cmp_lt_u32 %s, %%[nqp_iter]" % S_I)
+        P.raw("s_cbranch_scc1 Lqp%d_%%=" % u_)
+        # iteration cap (:192): lanes that never converged
+        P.v("v_cndmask_b32_e64 %s, 4, 0, %s" % (tT, S_DONE), writes=(tT,))
+        P.v("v_or_b32_e32 %s, %s, %s" % (QINFO, tT, QINFO), writes=(QINFO,), reads=(tT, QINFO))
+        P.label("Lqpx%d_%%=" % u_, reset=False)
+
+    def gains(s, first=False):
         """K~ = -Quu^-1 [Qux | Quu | qu] per lane (lqr_recursion.py:112-120); leaves A (Quu), Kt, and MINPIV"""
         Qs = Q[s]
         for m in range(nu):
@@ -368,8 +531,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
                 P.mov_dpp(A[m][l], Qs[nx + m], nx + l)
         rhs = [Qs[nx + m] for m in range(nu)]
         Au = A
-        if masked:
-            S_ACT = ["s[92:93]", "s[94:95]"]
+        if mpc:
+            for m in range(nu):
+                P.mov_dpp(QU[m], Qs[nx + m], aff)
+            box_qp(s, first)
+            for m in range(nu):      # K_t: rows of clamped controls zero, the QP's last H_f (mpc_step.py:147-157)
+                P.v("v_cndmask_b32_e64 %s, %s, 0, %s" % (Rm[m], Qs[nx + m], S_ACT[m]), writes=(Rm[m],), reads=(Qs[nx + m],))
+            masked_hessian(QP_REG)
+            rhs = Rm
+            Au = Am
+        elif masked:
             for m in range(nu):
                 P.v("v_cmp_ne_u32_e64 %s, 0, %s" % (S_ACT[m], ACT[s][m]), reads=(ACT[s][m],))
             if nu == 2:
@@ -418,11 +589,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
             P.v("v_mul_f32_e64 %s, %s, -%s" % (Kt[1], tY1, tRD), writes=(Kt[1],), reads=(tY1, tRD))
             P.v("v_fma_f32 %s, %s, %s, %s" % (tT2, tPQ, Kt[1], tRA), writes=(tT2,), reads=(tPQ, Kt[1], tRA))
             P.v("v_mul_f32_e64 %s, %s, -%s" % (Kt[0], tT2, tRP), writes=(Kt[0],), reads=(tT2, tRP))
+        if mpc:   # k_t is the QP's solution (lane aff), not the masked solve's          mpc_step.py:141-146
+            for m in range(nu):
+                P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (Kt[m], Kt[m], XK[m], S_AFF), writes=(Kt[m],), reads=(Kt[m], XK[m]))
         # gain rows -> LDS (and HBM when the caller wants Ks/ks), still under the K mask
-        for m in range(nu):
-            off = (" offset:%d" % (m * KROW * 4)) if m else ""
-            P.raw("ds_write_b32 %%[ak], %s%s" % (Kt[m], off))
+        if not mpc:
+            for m in range(nu):
+                off = (" offset:%d" % (m * KROW * 4)) if m else ""
+                P.raw("ds_write_b32 %%[ak], %s%s" % (Kt[m], off))
         if write_k:
+            P.uses(Kt)
             for m in range(nu):
                 P.raw("global_store_dword %s, %s, off" % (pk[m], Kt[m]))
         P.raw("s_mov_b64 exec, -1")
@@ -430,7 +606,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
         if write_k:
             for m in range(nu):
                 P.v("v_lshl_add_u64 %s, %s, 0, %%[dk]" % (pk[m], pk[m]))
-        P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
+        if not mpc:
+            P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
 
     def vupdate(s):
         """V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~) in place in Q[s][0..nx-1]   (lqr_recursion.py:151-152)"""
@@ -518,7 +695,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
                 order = list(range(ns)) if k < nx - 1 else list(range(nx, ns)) + list(range(nx))
                 for i in order:
                     P.fmac_dpp(Q[s][i], F[s][k], W[k], i)
-        gains(s)
+        gains(s, first)
         vupdate(s)
 
     callsite = [0]
@@ -546,7 +723,13 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     for m in range(nu):
         P.v("v_mov_b32_e32 %s, 0" % Kt[m], writes=(Kt[m],))
     P.v("v_mov_b32_e32 %s, 0x7f7fffff" % MINPIV, writes=(MINPIV,))
-    if masked:
+    if mpc:
+        for r_ in XK + [NQP, QINFO]:
+            P.v("v_mov_b32_e32 %s, 0" % r_, writes=(r_,))
+        lo_aff = int(S_AFF[2:S_AFF.index(":")])
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_aff, mask64([aff]) & 0xffffffff))
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_aff + 1, mask64([aff]) & 0xffffffff))
+    elif masked:
         P.v("v_mov_b32_e32 %s, 0x322bcc77" % EPS, writes=(EPS,))   # 1e-8f (active_constrained_lqr.py:121-122)
     if stash:
         lo = int(S_STUB[2:S_STUB.index(":")])
@@ -582,15 +765,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     n_extra += 1
     # zero this wave's gain rows while the first slots are in flight (columns nx..ns-1 and the pad of every row
     # are never written afterwards; the region is padded to whole 1 KB pieces by lqr_asm_kernel.hpp)
-    for i in range(4):
-        P.v("v_mov_b32_e32 %s, 0" % W[i], writes=(W[i],))
-    P.raw("s_mov_b32 %s, %%[nz]" % S_TMP)
-    P.label("Lzero_%=", reset=False)
-    P.raw("ds_write_b128 %%[gz], %s" % vrange(W[0:4]))
-    P.v("v_add_u32_e32 %[gz], 0x400, %[gz]")
-    P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
-    P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
-    P.raw("s_cbranch_scc1 Lzero_%=")
+    if not mpc:
+        for i in range(4):
+            P.v("v_mov_b32_e32 %s, 0" % W[i], writes=(W[i],))
+        P.raw("s_mov_b32 %s, %%[nz]" % S_TMP)
+        P.label("Lzero_%=", reset=False)
+        P.raw("ds_write_b128 %%[gz], %s" % vrange(W[0:4]))
+        P.v("v_add_u32_e32 %[gz], 0x400, %[gz]")
+        P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
+        P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
+        P.raw("s_cbranch_scc1 Lzero_%=")
     if stash and X_WARM_STUBS and not X_RET_DIRECT:
         lo = int(S_STUB[2:S_STUB.index(":")])
         P.raw("s_mov_b64 s[82:83], %s" % S_STUB)
@@ -623,6 +807,11 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     P.label("Lbwd_done_%=")
     in_loop[0] = False
     n_bwd = P.n_instr
+    if mpc:      # backward sweep only
+        P.v("v_mov_b32_e32 %[xvout], 0")
+        P.v("v_mov_b32_e32 %%[nqp], %s" % NQP)
+        P.v("v_mov_b32_e32 %%[qpinfo], %s" % QINFO)
+        P.raw("s_branch Ldone_%=")
 
     # =============================================================== forward rollout
     def read_rows(c, a, aff_too=True):
@@ -846,6 +1035,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
 
     # ---- operand lists
     outs = [("xvout", '"=&v"(xvout)'), ("minpiv", '"=&v"(minpiv)')]
+    if mpc:
+        outs += [("nqp", '"=&v"(nqp)'), ("qpinfo", '"=&v"(qpinfo)')]
     if X_TIMING:
         outs += [("ts%d" % i, '"=&v"(in.ts[%d])' % i) for i in range(4)]
     rw = []
@@ -885,11 +1076,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     if masked:
         ins += [("dm", '"v"(in.dm)'), ("am", '"v"(in.am)')]
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)'), ("bwd_only", '"v"(in.bwd_only)')]
+    if mpc:
+        ins.append(("nqp_iter", '"s"(in.n_qp_iter)'))
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
-        ['"s%d"' % i for i in ([70] + list(range(72, 98)))] + ['"vcc"', '"scc"', '"memory"']
+        ['"s%d"' % i for i in ([70] + list(range(72, 102 if mpc else 98)))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
     name = "LqrAsm<%d, %d, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked))
+    if mpc:
+        name = "MpcAsm<%d, %d>" % (nx, nu)
     o = []
     o.append("// (%d,%d) write_k=%d stash=%d masked=%d: %d instructions in prologue + 4 backward steps, %d in %d unrolled forward steps\n"
              % (nx, nu, write_k, stash, masked, n_bwd, n_fwd, n_fwd_steps))
@@ -920,7 +1115,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False):
     o.append("        : " + ", ".join("[%s] %s" % x for x in ins1) + "\n")
     o.append('        : "scc", "memory");\n')
     o.append("  }\n")
-    o.append("  static __device__ __forceinline__ void run(LqrAsmIn<%d, %d> &in, float &xvout, float &minpiv) {\n" % (nx, nu))
+    o.append("  static __device__ __forceinline__ void run(LqrAsmIn<%d, %d> &in, float &xvout, float &minpiv%s) {\n"
+             % (nx, nu, ", int &nqp, int &qpinfo" if mpc else ""))
     o.append("    asm volatile(\n")
     for ln in P.text():
         o.append('        "%s\\n\\t"\n' % ln)
@@ -956,6 +1152,7 @@ struct LqrAsmIn {
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
   unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
+  int n_qp_iter;                     // mpc (wave-uniform): iteration cap of the box QP
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
   uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
@@ -972,6 +1169,12 @@ struct LqrAsmIn {
 
 template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false>
 struct LqrAsm {
+  static constexpr bool kAvailable = false;
+};
+
+// MPCstep.backward_rec: backward sweep with the box QP in the stream (gains to HBM, no rollout)
+template <int NX, int NU>
+struct MpcAsm {
   static constexpr bool kAvailable = false;
 };
 
@@ -993,6 +1196,8 @@ def main():
                 out.append(gen_kernel(nx, nu, write_k, stash))
                 if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding
                     out.append(gen_kernel(nx, nu, write_k, stash, masked=True))
+                if write_k and not stash and L0.SLOT_B - 16 * L0.nchunk_b >= 256:
+                    out.append(gen_kernel(nx, nu, True, False, masked=True, mpc=True))
     out.append("}  // namespace dmpc\n")
     with open(OUT, "w") as fh:
         fh.write("".join(out))

@@ -40,6 +40,60 @@ constexpr size_t lqr_asm_lds_bytes(int T) {
          4 * round_up((size_t)4 * T * NU * G::KROW * 4, 1024);  // per wave: whole 1 KB pieces (zero fill)
 }
 
+// Per-lane LDS-DMA sources of the backward groups: chunk g = q*64 + lane64 of the slot [C | c | F | f | padding]
+// (shared by the LQR kernels and the MPC backward kernel of mpc_asm_kernel.hpp).
+template <int NX, int NU, class G, bool HAS_F>
+__device__ __forceinline__ void lqr_asm_backward_sources(LqrAsmIn<NX, NU> &in, const float *C, const float *c, const float *F,
+                                                         const float *f, int T, size_t B, int b0, int lane64) {
+  constexpr int NS = NX + NU;
+  constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
+  const char *Cb = reinterpret_cast<const char *>(C), *cb = reinterpret_cast<const char *>(c);
+  const char *Fb = reinterpret_cast<const char *>(F);
+  const char *fb = HAS_F ? reinterpret_cast<const char *>(f) : reinterpret_cast<const char *>(dmpc_zero_chunks);
+  constexpr size_t per_f = HAS_F ? (size_t)NX * 4 : 0;  // bytes of f per trajectory and timestep (0: the zero chunks)
+  static_assert(nf <= 16, "dmpc_zero_chunks too small");
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q >= G::NDB) {
+      in.ptr[q] = in.str1[q] = in.str[q] = 0;
+      continue;
+    }
+    // which array does chunk g of the slot [C | c | F | f | padding] belong to?  (selects, no branches: this
+    // set-up runs once per wave but sits on the critical path of the first DMA)
+    const int g = q * 64 + lane64;
+    const bool isC = g < nC, isc = !isC && g < nC + nc, isF = !isC && !isc && g < nC + nc + nF;
+    const bool isf = !isC && !isc && !isF && g < nC + nc + nF + nf;
+    const bool dyn = isF || isf;  // arrays without a slice T-1
+    const uint64_t base = isc ? reinterpret_cast<uint64_t>(cb) : isF ? reinterpret_cast<uint64_t>(Fb)
+                          : isf ? reinterpret_cast<uint64_t>(fb) : reinterpret_cast<uint64_t>(Cb);
+    const size_t per = isc ? (size_t)NS * 4 : isF ? (size_t)NX * NS * 4 : isf ? per_f : (size_t)NS * NS * 4;
+    const int g0 = isC ? 0 : isc ? nC : isF ? nC + nc : isf ? nC + nc + nF : g;  // padding lanes: chunk 0 of C again
+    const size_t off = (size_t)(g - g0) * 16;
+    const int t0 = dyn ? T - 2 : T - 1;
+    const uint64_t p = base + ((size_t)t0 * B + (size_t)b0) * per + off;
+    in.ptr[q] = p - (uint64_t)q * 1024u;  // the instruction offset q*1024 moves the global address as well
+    const uint64_t s = (uint64_t)0 - (uint64_t)(B * per);
+    in.str[q] = s;
+    in.str1[q] = dyn ? 0 : s;  // there is no F_{T-1}: the first group fetches F_{T-2} (unused), as does the second
+  }
+}
+
+// LDS read addresses (ring slot 0) of a lane's rows: lane j < ns walks column j of [C] / [F] (stride ns floats), lane ns
+// walks c / f themselves (stride 1)
+template <int NX, int NU, class G>
+__device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsigned ring, int r, int lane) {
+  constexpr int NS = NX + NU;
+  const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
+  const bool col_aff = lane == NS;
+  const unsigned q0 = ring + (col_aff ? (unsigned)(G::OFF_c + r * NS * 4) : (unsigned)(G::OFF_C + (r * NS * NS + lane_c) * 4));
+  const unsigned f0 = ring + (col_aff ? (unsigned)(G::OFF_f + r * NX * 4) : (unsigned)(G::OFF_F + (r * NX * NS + lane_c) * 4));
+  const unsigned st = col_aff ? 4u : (unsigned)(NS * 4);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) in.aq[i] = q0 + (unsigned)i * st;
+#pragma unroll
+  for (int k = 0; k < NX; ++k) in.af[k] = f0 + (unsigned)k * st;
+}
+
 // MASKED: LQR_active (mpc/active_constrained_lqr.py) - a.mask [T,B,nu] uint8 marks the clamped controls; needs
 // B * nu to be a multiple of 4 (the flags of a wave's four trajectories are fetched as whole dwords).
 // a.x == nullptr: backward sweep only (LqrRecursion.backward(), gains to a.Ks / a.ks - WRITE_K).
@@ -79,36 +133,10 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.tf = 0;
   in.bwd_only = a.x == nullptr ? 1 : 0;
 
-  // ---- backward DMA: chunk g = q*64 + lane64 of the slot [C | c | F | f]
-  const char *Cb = reinterpret_cast<const char *>(a.C), *cb = reinterpret_cast<const char *>(a.c);
+  lqr_asm_backward_sources<NX, NU, G, HAS_F>(in, a.C, a.c, a.F, a.f, T, B, b0, lane64);
   const char *Fb = reinterpret_cast<const char *>(a.F);
   const char *fb = HAS_F ? reinterpret_cast<const char *>(a.f) : reinterpret_cast<const char *>(dmpc_zero_chunks);
   constexpr size_t per_f = HAS_F ? (size_t)NX * 4 : 0;  // bytes of f per trajectory and timestep (0: the zero chunks)
-  static_assert(nf <= 16, "dmpc_zero_chunks too small");
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    if (q >= G::NDB) {
-      in.ptr[q] = in.str1[q] = in.str[q] = 0;
-      continue;
-    }
-    // which array does chunk g of the slot [C | c | F | f | padding] belong to?  (selects, no branches: this
-    // set-up runs once per wave but sits on the critical path of the first DMA)
-    const int g = q * 64 + lane64;
-    const bool isC = g < nC, isc = !isC && g < nC + nc, isF = !isC && !isc && g < nC + nc + nF;
-    const bool isf = !isC && !isc && !isF && g < nC + nc + nF + nf;
-    const bool dyn = isF || isf;  // arrays without a slice T-1
-    const uint64_t base = isc ? reinterpret_cast<uint64_t>(cb) : isF ? reinterpret_cast<uint64_t>(Fb)
-                          : isf ? reinterpret_cast<uint64_t>(fb) : reinterpret_cast<uint64_t>(Cb);
-    const size_t per = isc ? (size_t)NS * 4 : isF ? (size_t)NX * NS * 4 : isf ? per_f : (size_t)NS * NS * 4;
-    const int g0 = isC ? 0 : isc ? nC : isF ? nC + nc : isf ? nC + nc + nF : g;  // padding lanes: chunk 0 of C again
-    const size_t off = (size_t)(g - g0) * 16;
-    const int t0 = dyn ? T - 2 : T - 1;
-    const uint64_t p = base + ((size_t)t0 * B + (size_t)b0) * per + off;
-    in.ptr[q] = p - (uint64_t)q * 1024u;  // the instruction offset q*1024 moves the global address as well
-    const uint64_t s = (uint64_t)0 - (uint64_t)(B * per);
-    in.str[q] = s;
-    in.str1[q] = dyn ? 0 : s;  // there is no F_{T-1}: the first group fetches F_{T-2} (unused), as does the second
-  }
   if constexpr (MASKED) {  // dword i < nu of the 4 * nu flag bytes of this wave and timestep; the other lanes repeat dword 0
     in.pm = reinterpret_cast<uint64_t>(a.mask) + ((size_t)(T - 1) * B + (size_t)b0) * NU + (size_t)(lane64 < NU ? lane64 : 0) * 4 -
             (uint64_t)G::PADM;  // the instruction offset that places the dwords in the slot padding moves the source too
@@ -126,15 +154,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.nz = (int)(gain_wave_bytes / 1024u);
   const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
   const bool col_aff = lane == AFF;
-  {  // lane j < ns: column j of the rows of [C] / [F] (stride ns floats); lane ns: c / f themselves (stride 1)
-    const unsigned q0 = ring + (col_aff ? (unsigned)(G::OFF_c + r * NS * 4) : (unsigned)(G::OFF_C + (r * NS * NS + lane_c) * 4));
-    const unsigned f0 = ring + (col_aff ? (unsigned)(G::OFF_f + r * NX * 4) : (unsigned)(G::OFF_F + (r * NX * NS + lane_c) * 4));
-    const unsigned st = col_aff ? 4u : (unsigned)(NS * 4);
-#pragma unroll
-    for (int i = 0; i < NS; ++i) in.aq[i] = q0 + (unsigned)i * st;
-#pragma unroll
-    for (int k = 0; k < NX; ++k) in.af[k] = f0 + (unsigned)k * st;
-  }
+  lqr_asm_row_addresses<NX, NU, G>(in, ring, r, lane);
   in.ak = gain_traj + (unsigned)((T - 1) * NU * KROW * 4) + (unsigned)lane * 4u;
   in.eaff = col_aff ? 1.f : 0.f;
   if constexpr (WRITE_K) {

@@ -8,6 +8,7 @@
 #include "api_util.hpp"
 #include "costate_args.hpp"
 #include "box_ddp_kernels.hpp"
+#include "mpc_asm_kernel.hpp"
 #include "mpc_dma_kernels.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_kernels.hpp"
@@ -87,6 +88,10 @@ static bool mpc_dma_disabled() {
   static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_DMA"); return e && e[0] == '1'; }();
   return off;
 }
+static bool mpc_asm_disabled() {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_ASM"); return e && e[0] == '1'; }();
+  return off;
+}
 template <class... P>
 static bool aligned16(const P *...p) {   // nullptr counts as aligned
   return ((reinterpret_cast<uintptr_t>(p) | ...) & 15u) == 0;
@@ -113,6 +118,27 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   // per-trajectory termination, whole wavefronts of four trajectories, 16-byte aligned runs: inputs through the LDS-DMA
   // ring of mpc_dma_kernels.hpp (DMPC_NO_MPC_DMA=1: the register-bank kernel, for A/B timing)
   const bool dma_ok = mpc_back_dma_ok(a);
+  // The sweep as one generated instruction stream with the box QP inside (mpc_asm_kernel.hpp): shapes the generator
+  // covers, c already re-centred, no bookkeeping riding along.  DMPC_NO_MPC_ASM=1: the HIP kernels (A/B timing).
+  if (dma_ok && a.states == nullptr && a.T >= 2 && !mpc_asm_disabled() && (sel == nullptr || sel_sync != nullptr)) {
+    const int n_sel = sel != nullptr ? select_parts(a.B) : 0;
+    const dim3 grid((a.B + 15) / 16 + n_sel), block(256);
+#define A(NX_, NU_)                                                                                                    \
+  if (nx == NX_ && nu == NU_) {                                                                                        \
+    constexpr size_t lds = mpc_asm_lds_bytes<NX_, NU_>();                                                              \
+    if (sel != nullptr && a.f != nullptr)                                                                              \
+      hipLaunchKernelGGL((mpc_backward_asm_select_kernel<NX_, NU_, true>), grid, block, lds, stream, a, *sel, n_sel, sel_sync); \
+    else if (sel != nullptr)                                                                                           \
+      hipLaunchKernelGGL((mpc_backward_asm_select_kernel<NX_, NU_, false>), grid, block, lds, stream, a, *sel, n_sel, sel_sync); \
+    else if (a.f != nullptr)                                                                                           \
+      hipLaunchKernelGGL((mpc_backward_asm_kernel<NX_, NU_, true>), grid, block, lds, stream, a);                      \
+    else                                                                                                               \
+      hipLaunchKernelGGL((mpc_backward_asm_kernel<NX_, NU_, false>), grid, block, lds, stream, a);                     \
+    return (int)hipGetLastError();                                                                                     \
+  }
+    A(8, 2) A(3, 1) A(4, 2) A(2, 2) A(1, 1) A(2, 1) A(3, 2)
+#undef A
+  }
 #define X(NX_, NU_, L_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                               \
     constexpr int GPB = 256 / L_;                                                                             \
@@ -140,7 +166,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
                        a);                                                                                    \
     return (int)hipGetLastError();                                                                            \
   }
-  if (sel != nullptr && !(dma_ok && nx == 3 && nu == 1 && sel_sync != nullptr)) return DMPC_E_BADARG;   // callers ask mpc_back_dma_ok first
+  if (sel != nullptr && !(dma_ok && sel_sync != nullptr)) return DMPC_E_BADARG;   // callers ask mpc_back_dma_ok first
   DMPC_MPC_SHAPES(X)
 #undef X
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)

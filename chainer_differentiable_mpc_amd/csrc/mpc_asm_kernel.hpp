@@ -1,0 +1,101 @@
+// mpc_asm_kernel.hpp - MPCstep.backward_rec (mpc/mpc_step.py:70-173) as ONE generated gfx950 instruction stream
+// (MpcAsm<nx, nu> of lqr_asm_gen.hpp, emitted by gen_lqr_asm.py with mpc=True): the Riccati sweep of the fused LQR
+// stream with the box QP of every timestep solved inside it (projected Newton, mpc/pnqp.py:37-201, per-trajectory
+// termination).  This file is the C++ side, as lqr_asm_kernel.hpp is for the LQR solve: LDS layout (one ring per
+// wavefront, nothing else - the gains go straight to HBM) and the per-lane operands.
+//
+// Against the HIP kernels (mpc_kernels.hpp / mpc_dma_kernels.hpp) the arithmetic is the same up to the last bit of a
+// reciprocal (the gain solve uses v_rcp_f32 as the LQR stream does; the QP's own quotients carry a Newton step as
+// pnqp_device.hpp's do), and nothing is left to the compiler between the first DMA and the last store.
+// Needs: B % 4 == 0, per-trajectory termination, c already re-centred (states == nullptr), 16-byte aligned C, c, F, f.
+#pragma once
+#include "box_ddp_kernels.hpp"
+#include "lqr_asm_kernel.hpp"
+#include "mpc_kernels.hpp"
+
+namespace dmpc {
+
+template <int NX, int NU>
+constexpr size_t mpc_asm_lds_bytes() {
+  return (size_t)4 * MpcAsm<NX, NU>::RING_BYTES;
+}
+
+template <int NX, int NU, bool HAS_F>
+__device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, const int block) {
+  using G = MpcAsm<NX, NU>;
+  static_assert(G::kAvailable, "no generated instruction stream for this shape");
+  constexpr int NS = NX + NU;
+  if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r = lane64 >> 4;  // trajectory within the wave
+  const int lane = lane64 & 15;
+  const int b0 = __builtin_amdgcn_readfirstlane((block * 4 + wave) * 4);  // first trajectory of this wave
+  if (b0 >= a.B) return;      // whole wavefront (B % 4 == 0); the stream has no workgroup barrier
+  const int b = b0 + r;
+
+  extern __shared__ float lds[];
+  const unsigned ring = lds_byte_address(lds) + (unsigned)wave * G::RING_BYTES;
+
+  LqrAsmIn<NX, NU> in{};      // the forward sweep's operands stay zero: the stream stops after the backward sweep
+  in.ring = __builtin_amdgcn_readfirstlane(ring);
+  in.T = T;
+  in.bwd_only = 1;
+  in.n_qp_iter = a.n_qp_iter;
+  lqr_asm_backward_sources<NX, NU, G, HAS_F>(in, a.C, a.c, a.F, a.f, T, B, b0, lane64);
+  {  // the slot padding takes [u | lower | upper] of the wave's four trajectories: dword l < 12 nu comes from lane l
+    const int l = lane64 < 12 * NU ? lane64 : 0;
+    const int arr = l / (4 * NU), j = l % (4 * NU);
+    const float *base = arr == 0 ? a.controls : (arr == 1 ? a.lower : a.upper);
+    in.pm = reinterpret_cast<uint64_t>(base + ((size_t)(T - 1) * B + (size_t)b0) * NU + j) - (uint64_t)G::PADM;
+    in.dm = (uint64_t)0 - (uint64_t)(B * NU * 4);
+    in.am = ring + (unsigned)(r * NU * 4);
+  }
+  G::issue_first(in);  // the first DMA groups leave now; the rest of the set-up overlaps their flight
+  lqr_asm_row_addresses<NX, NU, G>(in, ring, r, lane);
+  const bool col_aff = lane == NS;
+  in.eaff = col_aff ? 1.f : 0.f;
+  {
+    const size_t tb = (size_t)(T - 1) * B + (size_t)b;
+#pragma unroll
+    for (int m = 0; m < NU; ++m)
+      in.pk[m] = col_aff ? reinterpret_cast<uint64_t>(a.ks + tb * NU + m)
+                         : reinterpret_cast<uint64_t>(a.Ks + (tb * NU + m) * NX + (lane < NX ? lane : 0));
+    in.dk = (uint64_t)0 - (uint64_t)(col_aff ? B * NU * 4 : B * NU * NX * 4);
+  }
+  in.pxi = reinterpret_cast<uint64_t>(a.C);  // the stream loads x_init unconditionally: any readable word
+
+  float xvout, minpiv;
+  int nqp, qpinfo;
+  G::run(in, xvout, minpiv, nqp, qpinfo);
+
+  if (lane == 0) {
+    a.n_qp_total[b] = nqp;
+    if (a.info != nullptr) {
+      if (a.info_store) a.info[b] = qpinfo;
+      else if (qpinfo != 0) atomicOr(&a.info[b], qpinfo);
+    }
+  }
+}
+
+template <int NX, int NU, bool HAS_F>
+__global__ __launch_bounds__(256) void mpc_backward_asm_kernel(const MpcBackArgs a) {
+  mpc_backward_asm_body<NX, NU, HAS_F>(a, blockIdx.x);
+}
+
+// the sweep with the previous box-DDP iteration's bookkeeping in the launch's last n_sel workgroups (see
+// mpc_backward_rec_dma_select_kernel of mpc_dma_kernels.hpp)
+template <int NX, int NU, bool HAS_F>
+__global__ __launch_bounds__(256) void mpc_backward_asm_select_kernel(const MpcBackArgs a, const DdpSelectArgs s,
+                                                                      const int n_sel, unsigned *sel_sync) {
+  const int n_back = (int)gridDim.x - n_sel;
+  if ((int)blockIdx.x >= n_back) {
+    box_ddp_select_body<256, NX, NU>(s, (int)blockIdx.x - n_back, n_sel, sel_sync);
+    return;
+  }
+  mpc_backward_asm_body<NX, NU, HAS_F>(a, blockIdx.x);
+}
+
+}  // namespace dmpc
