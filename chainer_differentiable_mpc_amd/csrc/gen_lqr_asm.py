@@ -220,7 +220,7 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
+def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
     """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
     is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
     rollout needs no change); the value update keeps the unmasked blocks (:143-145).
@@ -230,11 +230,14 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
     wave-uniform loops as pnqp_solve_rows of pnqp_device.hpp); k_t is its solution, K_t the masked solve with 1e-11 on
     the diagonal (the QP's own last factorisation, :147-157), the value update keeps the unmasked blocks (:165-166).
     u, lower, upper of the wave's four trajectories arrive as 12 nu dwords in the slot padding (the flag DMA of the
-    masked variant, one float per lane)."""
+    masked variant, one float per lane).
+    expand (mpc only): need_expand of MPCstep.forward (mpc_step.py:305-317) inside the sweep - the slot padding also
+    takes x_t (4 nx more dwords) and every step starts with c_hat = C [x_t; u_t] + c in the affine column."""
     L = Layout(nx, nu)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
     assert not mpc or (masked and write_k and not stash)
+    assert not expand or (mpc and 12 * nu + 4 * nx <= 64)
     P = Prog()
     R = Regs(VBASE)
     # ---- operand names (C++ side: struct LqrAsmIn of lqr_asm_gen.hpp, filled by lqr_asm_kernel.hpp)
@@ -270,6 +273,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
     QU = R.take(nu) if mpc else None                          # qu in every lane
     NQP = R.take(1)[0] if mpc else None                       # sum over t of the QP passes run          (mpc_step.py:145)
     QINFO = R.take(1)[0] if mpc else None                     # 4 once a QP ran into the iteration cap
+    TAU = R.take(3) if expand else None                       # expand: lane j < ns of set s holds [x_t; u_t][j]
     Am = [R.take(nu) for _ in range(nu)] if masked else None   # masked Quu
     Rm = R.take(nu) if masked else None                        # masked right-hand side rows
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
@@ -377,6 +381,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
             for a_, regs in enumerate((UC[s], LB[s], UB[s])):     # [u | lower | upper], 4 nu floats each
                 for m in range(nu):
                     P.raw("ds_read_b32 %s, %%[am] offset:%d" % (regs[m], off + PADM + (a_ * 4 * nu + m) * 4))
+            if expand:
+                P.uses([TAU[s]])
+                P.raw("ds_read_b32 %s, %%[atau] offset:%d" % (TAU[s], off + PADM))
         elif masked:
             for m in range(nu):
                 P.raw("ds_read_u8 %s, %%[am] offset:%d" % (ACT[s][m], off + PADM + m))
@@ -634,6 +641,19 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
         V = Q[p]
         issue_group(ptr, s, L.SLOT_B, gap="s_waitcnt lgkmcnt(0)")   # the slot's last reads are in before it is refilled
         advance(ptr, strd, by_steps_left=DB if first else DB + 1)
+        if expand:
+            # c_hat = C tau + c: the products of a row of C with tau sit in lanes 0..ns-1, four row rotations sum them
+            # into every lane (group_sum of colwise.hpp, same order), the affine lane adds the sum to c
+            tmp = [tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2][:ns]
+            P.v("v_cndmask_b32_e64 %s, 0, %s, %s" % (TAU[s], TAU[s], S_SM), writes=(TAU[s],), reads=(TAU[s],))
+            for i in range(ns):
+                P.v("v_mul_f32_e32 %s, %s, %s" % (tmp[i], Q[s][i], TAU[s]), writes=(tmp[i],), reads=(Q[s][i], TAU[s]))
+            for rot in (8, 4, 2, 1):
+                for i in range(ns):
+                    P.valu("v_add_f32_dpp %s, %s, %s row_ror:%d row_mask:0xf bank_mask:0xf" % (tmp[i], tmp[i], tmp[i], rot),
+                           writes=(tmp[i],), reads=(tmp[i],), dpp=tmp[i])
+            for i in range(ns):
+                P.v("v_fmac_f32_e32 %s, %s, %%[eaff]" % (Q[s][i], tmp[i]), writes=(Q[s][i],), reads=(tmp[i], Q[s][i]))
         if not first and mfma:
             # Q~ += F~^T V^ F^ as (V^^T F^)^T F^ - both products have the A^T B shape that an outer-product MFMA
             # computes from column-per-lane registers (A operand = 4 lanes of a register = 4 rows of A^T):
@@ -1078,13 +1098,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False):
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)'), ("bwd_only", '"v"(in.bwd_only)')]
     if mpc:
         ins.append(("nqp_iter", '"s"(in.n_qp_iter)'))
+    if expand:
+        ins.append(("atau", '"v"(in.atau)'))
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
         ['"s%d"' % i for i in ([70] + list(range(72, 102 if mpc else 98)))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
     name = "LqrAsm<%d, %d, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked))
     if mpc:
-        name = "MpcAsm<%d, %d>" % (nx, nu)
+        name = "MpcAsm<%d, %d, %s>" % (nx, nu, tf(expand))
     o = []
     o.append("// (%d,%d) write_k=%d stash=%d masked=%d: %d instructions in prologue + 4 backward steps, %d in %d unrolled forward steps\n"
              % (nx, nu, write_k, stash, masked, n_bwd, n_fwd, n_fwd_steps))
@@ -1153,6 +1175,7 @@ struct LqrAsmIn {
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
   unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
   int n_qp_iter;                     // mpc (wave-uniform): iteration cap of the box QP
+  unsigned atau;                     // mpc, expand: LDS byte address (ring slot 0, without the padding offset) of [x_t; u_t][lane]
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
   uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
@@ -1172,8 +1195,9 @@ struct LqrAsm {
   static constexpr bool kAvailable = false;
 };
 
-// MPCstep.backward_rec: backward sweep with the box QP in the stream (gains to HBM, no rollout)
-template <int NX, int NU>
+// MPCstep.backward_rec: backward sweep with the box QP in the stream (gains to HBM, no rollout); EXPAND: with the
+// Taylor re-centring of c (need_expand) in the sweep
+template <int NX, int NU, bool EXPAND>
 struct MpcAsm {
   static constexpr bool kAvailable = false;
 };
@@ -1198,6 +1222,8 @@ def main():
                     out.append(gen_kernel(nx, nu, write_k, stash, masked=True))
                 if write_k and not stash and L0.SLOT_B - 16 * L0.nchunk_b >= 256:
                     out.append(gen_kernel(nx, nu, True, False, masked=True, mpc=True))
+                    if 12 * nu + 4 * nx <= 64:
+                        out.append(gen_kernel(nx, nu, True, False, masked=True, mpc=True, expand=True))
     out.append("}  // namespace dmpc\n")
     with open(OUT, "w") as fh:
         fh.write("".join(out))

@@ -120,24 +120,25 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   const bool dma_ok = mpc_back_dma_ok(a);
   // The sweep as one generated instruction stream with the box QP inside (mpc_asm_kernel.hpp): shapes the generator
   // covers, c already re-centred, no bookkeeping riding along.  DMPC_NO_MPC_ASM=1: the HIP kernels (A/B timing).
-  if (dma_ok && a.states == nullptr && a.T >= 2 && !mpc_asm_disabled() && (sel == nullptr || sel_sync != nullptr)) {
+  if (dma_ok && a.T >= 2 && !mpc_asm_disabled() && (sel == nullptr || sel_sync != nullptr) &&
+      (a.states == nullptr || a.f == nullptr)) {
     const int n_sel = sel != nullptr ? select_parts(a.B) : 0;
     const dim3 grid((a.B + 15) / 16 + n_sel), block(256);
-#define A(NX_, NU_)                                                                                                    \
-  if (nx == NX_ && nu == NU_) {                                                                                        \
-    constexpr size_t lds = mpc_asm_lds_bytes<NX_, NU_>();                                                              \
-    if (sel != nullptr && a.f != nullptr)                                                                              \
-      hipLaunchKernelGGL((mpc_backward_asm_select_kernel<NX_, NU_, true>), grid, block, lds, stream, a, *sel, n_sel, sel_sync); \
-    else if (sel != nullptr)                                                                                           \
-      hipLaunchKernelGGL((mpc_backward_asm_select_kernel<NX_, NU_, false>), grid, block, lds, stream, a, *sel, n_sel, sel_sync); \
-    else if (a.f != nullptr)                                                                                           \
-      hipLaunchKernelGGL((mpc_backward_asm_kernel<NX_, NU_, true>), grid, block, lds, stream, a);                      \
-    else                                                                                                               \
-      hipLaunchKernelGGL((mpc_backward_asm_kernel<NX_, NU_, false>), grid, block, lds, stream, a);                     \
-    return (int)hipGetLastError();                                                                                     \
+    const int variant = a.states != nullptr ? 2 : (a.f != nullptr ? 1 : 0);   // re-centring / with f_hat / plain
+#define L_(K_, ...)                                                                                            \
+  if (sel != nullptr) hipLaunchKernelGGL((mpc_backward_asm_select_kernel<__VA_ARGS__>), grid, block, K_, stream, a, *sel, n_sel, sel_sync); \
+  else hipLaunchKernelGGL((mpc_backward_asm_kernel<__VA_ARGS__>), grid, block, K_, stream, a);
+#define A(NX_, NU_)                                                                                            \
+  if (nx == NX_ && nu == NU_) {                                                                                \
+    constexpr size_t lds = mpc_asm_lds_bytes<NX_, NU_>();                                                      \
+    if (variant == 2) { L_(lds, NX_, NU_, false, true) }                                                       \
+    else if (variant == 1) { L_(lds, NX_, NU_, true, false) }                                                  \
+    else { L_(lds, NX_, NU_, false, false) }                                                                   \
+    return (int)hipGetLastError();                                                                             \
   }
     A(8, 2) A(3, 1) A(4, 2) A(2, 2) A(1, 1) A(2, 1) A(3, 2)
 #undef A
+#undef L_
   }
 #define X(NX_, NU_, L_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                               \

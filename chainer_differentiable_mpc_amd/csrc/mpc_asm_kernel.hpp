@@ -7,7 +7,8 @@
 // Against the HIP kernels (mpc_kernels.hpp / mpc_dma_kernels.hpp) the arithmetic is the same up to the last bit of a
 // reciprocal (the gain solve uses v_rcp_f32 as the LQR stream does; the QP's own quotients carry a Newton step as
 // pnqp_device.hpp's do), and nothing is left to the compiler between the first DMA and the last store.
-// Needs: B % 4 == 0, per-trajectory termination, c already re-centred (states == nullptr), 16-byte aligned C, c, F, f.
+// Needs: B % 4 == 0, per-trajectory termination, 16-byte aligned C, c, F, f (and 12 nu + 4 nx <= 64 for the
+// re-centring variant: its x_t share the slot padding's one dword DMA with u_t and the bounds).
 #pragma once
 #include "box_ddp_kernels.hpp"
 #include "lqr_asm_kernel.hpp"
@@ -17,12 +18,13 @@ namespace dmpc {
 
 template <int NX, int NU>
 constexpr size_t mpc_asm_lds_bytes() {
-  return (size_t)4 * MpcAsm<NX, NU>::RING_BYTES;
+  return (size_t)4 * MpcAsm<NX, NU, false>::RING_BYTES;
 }
 
-template <int NX, int NU, bool HAS_F>
+// EXPAND: a.states given - c is the ORIGINAL linear term and the sweep re-centres it (need_expand, mpc_step.py:305-317)
+template <int NX, int NU, bool HAS_F, bool EXPAND>
 __device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, const int block) {
-  using G = MpcAsm<NX, NU>;
+  using G = MpcAsm<NX, NU, EXPAND>;
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU;
   if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
@@ -45,13 +47,18 @@ __device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, cons
   in.bwd_only = 1;
   in.n_qp_iter = a.n_qp_iter;
   lqr_asm_backward_sources<NX, NU, G, HAS_F>(in, a.C, a.c, a.F, a.f, T, B, b0, lane64);
-  {  // the slot padding takes [u | lower | upper] of the wave's four trajectories: dword l < 12 nu comes from lane l
-    const int l = lane64 < 12 * NU ? lane64 : 0;
-    const int arr = l / (4 * NU), j = l % (4 * NU);
-    const float *base = arr == 0 ? a.controls : (arr == 1 ? a.lower : a.upper);
-    in.pm = reinterpret_cast<uint64_t>(base + ((size_t)(T - 1) * B + (size_t)b0) * NU + j) - (uint64_t)G::PADM;
-    in.dm = (uint64_t)0 - (uint64_t)(B * NU * 4);
+  {  // the slot padding takes [u | lower | upper (| x)] of the wave's four trajectories: dword l comes from lane l
+    constexpr int n_u = 12 * NU, n_all = n_u + (EXPAND ? 4 * NX : 0);
+    const int l = lane64 < n_all ? lane64 : 0;
+    const bool is_x = EXPAND && l >= n_u;
+    const int arr = l / (4 * NU), j = is_x ? l - n_u : l % (4 * NU);
+    const float *base = is_x ? a.states : (arr == 0 ? a.controls : (arr == 1 ? a.lower : a.upper));
+    const size_t per = is_x ? NX : NU;   // floats per trajectory and timestep
+    in.pm = reinterpret_cast<uint64_t>(base + ((size_t)(T - 1) * B + (size_t)b0) * per + j) - (uint64_t)G::PADM;
+    in.dm = (uint64_t)0 - (uint64_t)(B * per * 4);
     in.am = ring + (unsigned)(r * NU * 4);
+    if constexpr (EXPAND)   // lane j < nx: x_t[j], lane nx + m: u_t[m] (the other lanes are masked off in the stream)
+      in.atau = ring + (unsigned)((lane < NX ? n_u + r * NX + lane : (lane < NS ? r * NU + (lane - NX) : 0)) * 4);
   }
   G::issue_first(in);  // the first DMA groups leave now; the rest of the set-up overlaps their flight
   lqr_asm_row_addresses<NX, NU, G>(in, ring, r, lane);
@@ -80,14 +87,14 @@ __device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, cons
   }
 }
 
-template <int NX, int NU, bool HAS_F>
+template <int NX, int NU, bool HAS_F, bool EXPAND>
 __global__ __launch_bounds__(256) void mpc_backward_asm_kernel(const MpcBackArgs a) {
-  mpc_backward_asm_body<NX, NU, HAS_F>(a, blockIdx.x);
+  mpc_backward_asm_body<NX, NU, HAS_F, EXPAND>(a, blockIdx.x);
 }
 
 // the sweep with the previous box-DDP iteration's bookkeeping in the launch's last n_sel workgroups (see
 // mpc_backward_rec_dma_select_kernel of mpc_dma_kernels.hpp)
-template <int NX, int NU, bool HAS_F>
+template <int NX, int NU, bool HAS_F, bool EXPAND>
 __global__ __launch_bounds__(256) void mpc_backward_asm_select_kernel(const MpcBackArgs a, const DdpSelectArgs s,
                                                                       const int n_sel, unsigned *sel_sync) {
   const int n_back = (int)gridDim.x - n_sel;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void mpc_backward_asm_select_kernel(const MpcB
     box_ddp_select_body<256, NX, NU>(s, (int)blockIdx.x - n_back, n_sel, sel_sync);
     return;
   }
-  mpc_backward_asm_body<NX, NU, HAS_F>(a, blockIdx.x);
+  mpc_backward_asm_body<NX, NU, HAS_F, EXPAND>(a, blockIdx.x);
 }
 
 }  // namespace dmpc
