@@ -209,9 +209,19 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
                          a.traj_in_lds ? lds : 0, stream, a);
     return (int)hipGetLastError();
   }
+  // LinDx, whole wavefronts of four trajectories, 16-byte aligned runs: inputs through the LDS-DMA ring
+  const bool fwd_dma = a.dyn_kind == 0 && a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
+                       aligned16(a.C, a.c, a.F, a.f, a.Ks, a.ks, a.controls, a.lower, a.upper, a.states);
 #define X(NX_, NU_, L_)                                                                                      \
   if (nx == NX_ && nu == NU_) {                                                                              \
     constexpr int GPB = 256 / L_;                                                                            \
+    if constexpr (L_ == 16 && MpcFwdDmaLayout<NX_, NU_>::lds_bytes() <= 96 * 1024) {                          \
+      if (fwd_dma) {                                                                                         \
+        hipLaunchKernelGGL((mpc_forward_rec_kernel<NX_, NU_, L_, true>), dim3((a.B + GPB - 1) / GPB), dim3(256), \
+                           (MpcFwdDmaLayout<NX_, NU_>::lds_bytes()), stream, a);                             \
+        return (int)hipGetLastError();                                                                       \
+      }                                                                                                      \
+    }                                                                                                        \
     hipLaunchKernelGGL((mpc_forward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
                        a);                                                                                   \
     return (int)hipGetLastError();                                                                           \

@@ -343,12 +343,32 @@ struct MpcFwdArgs {
   const int32_t *info_in;                // [B] flags to merge into info (the backward sweep's, when it ran ahead of `done`)
 };
 
-template <int NX, int NU, int L>
+// chunks of one wave-step of the forward kernel's LDS-DMA ring (DMA variant):
+// [C | c | F | f | Ks | ks | u | lower | upper | x], four trajectories each
+template <int NX, int NU>
+struct MpcFwdDmaLayout {
+  static constexpr int NS = NX + NU;
+  static constexpr int CH_C = 0, CH_c = CH_C + NS * NS, CH_F = CH_c + NS, CH_f = CH_F + NX * NS, CH_K = CH_f + NX;
+  static constexpr int CH_k = CH_K + NU * NX, CH_u = CH_k + NU, CH_lo = CH_u + NU, CH_hi = CH_lo + NU, CH_x = CH_hi + NU;
+  static constexpr int CH_END = CH_x + NX;
+  static constexpr int kDma = (CH_END + 63) / 64;   // gather DMAs per step; padding lanes repeat chunk 0 of C
+  static constexpr int SLOT = kDma * 256;           // floats per wave and timestep
+  static constexpr int DB = kDma == 1 ? 8 : 4;      // ring depth
+  static constexpr size_t lds_bytes() { return (size_t)4 * DB * SLOT * 4; }
+};
+
+// DMA (L == 16, LinDx, B % 4 == 0, 16-byte aligned arrays): the inputs of a timestep come through an LDS ring filled by
+// per-lane gather LDS-DMA, DB - 1 steps ahead (the scheme of mpc_dma_kernels.hpp) instead of three compiler-managed
+// register banks.  Both variants run the line search as a WAVE-UNIFORM loop: a pass is executed by every lane while
+// any trajectory of the wavefront still searches, and the trajectories that are done neither store nor commit.
+template <int NX, int NU, int L, bool DMA = false>
 __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a) {
   constexpr int NS = NX + NU;
   static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
+  static_assert(!DMA || L == 16, "the ring is laid out for four trajectories per wavefront");
   constexpr int GPB = 256 / L;
   using G = Group<L>;
+  using Lay = MpcFwdDmaLayout<NX, NU>;
 
   if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
   const int lane = threadIdx.x % L;
@@ -374,8 +394,8 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   // with the cost.  A candidate that has collapsed onto the nominal trajectory gives d = 0, hence exactly 0.
   float old_cost = 0.f;
 
-  // Inputs of one timestep of a pass; the loads of step t+2 are issued before step t is computed (see the backward
-  // kernel above).  A pass that is no longer needed by this trajectory still runs masked while wave-mates search.
+  // Inputs of one timestep of a pass.  Register-bank variant: the loads of step t+2 are issued before step t is
+  // computed (see the backward kernel above).
   struct Slot {
     float xt, kv[NU], uc[NU], lb[NU], ub[NU];
     float Crow[NS + 1], ci, Frow[NS + 1], fi;  // (+1: the fused DPP blocks take rows in the [row | affine] shape)
@@ -405,6 +425,80 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       sl.fi = has_f ? a.f[tbF * NX + lane_x] : 0.f;
     }
   };
+  // ---- the ring (DMA only)
+  extern __shared__ float fwd_lds[];
+  constexpr int DB = Lay::DB;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r4 = lane64 >> 4;
+  float *ring = fwd_lds + wave * (DB * Lay::SLOT);
+  unsigned ring_addr = 0;
+  unsigned long long ptr0[Lay::kDma], ptr[Lay::kDma], str[Lay::kDma], strl[Lay::kDma];
+  if constexpr (DMA) {
+    const int b0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + wave) * 4);
+    if (b0 >= a.B) return;   // whole wavefront (B % 4 == 0); no workgroup barrier below
+    ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+#pragma unroll
+    for (int q = 0; q < Lay::kDma; ++q) {
+      const int g = q * 64 + lane64;
+      const char *base_p = (const char *)a.C;
+      size_t per = (size_t)NS * NS * 4;
+      int g0 = g;   // absent arrays and padding lanes: chunk 0 of C again
+      bool isF = false;
+      if (g < Lay::CH_c) { g0 = Lay::CH_C; }
+      else if (g < Lay::CH_F) { base_p = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::CH_c; }
+      else if (g < Lay::CH_f) { if (T > 1) { base_p = (const char *)a.F; per = (size_t)NX * NS * 4; g0 = Lay::CH_F; isF = true; } }
+      else if (g < Lay::CH_K) { if (has_f && T > 1) { base_p = (const char *)a.f; per = (size_t)NX * 4; g0 = Lay::CH_f; isF = true; } }
+      else if (g < Lay::CH_k) { base_p = (const char *)a.Ks; per = (size_t)NU * NX * 4; g0 = Lay::CH_K; }
+      else if (g < Lay::CH_u) { base_p = (const char *)a.ks; per = (size_t)NU * 4; g0 = Lay::CH_k; }
+      else if (g < Lay::CH_lo) { base_p = (const char *)a.controls; per = (size_t)NU * 4; g0 = Lay::CH_u; }
+      else if (g < Lay::CH_hi) { base_p = (const char *)a.lower; per = (size_t)NU * 4; g0 = Lay::CH_lo; }
+      else if (g < Lay::CH_x) { base_p = (const char *)a.upper; per = (size_t)NU * 4; g0 = Lay::CH_hi; }
+      else if (g < Lay::CH_END) { base_p = (const char *)a.states; per = (size_t)NX * 4; g0 = Lay::CH_x; }
+      ptr0[q] = (unsigned long long)base_p + (size_t)b0 * per + (size_t)(g - g0) * 16 - (unsigned long long)(q % 4) * 1024u;
+      str[q] = (unsigned long long)(B * per);
+      strl[q] = isF ? 0ull : str[q];   // there is no F_{T-1}: the step t = T-1 fetches F_{T-2} again (never consumed)
+    }
+  }
+  int ti = 0;  // timesteps the pointers may still advance
+  auto issue_next = [&](int slot) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_addr + (unsigned)slot * (Lay::SLOT * 4));
+    static_for<0, Lay::kDma>([&](auto q) {  // the instruction offset is 13 bits signed: M0 moves every 4 KB
+      if constexpr (q.value % 4 == 0) set_m0(dst + (unsigned)q.value * 1024u);
+      dma16_gather<(q.value % 4) * 1024>(ptr[q.value]);
+    });
+    if (ti > 0) {  // past the horizon the last blocks are fetched again (never consumed): the count per step stays exact
+      const bool last = ti == 1;
+#pragma unroll
+      for (int q = 0; q < Lay::kDma; ++q) ptr[q] += last ? strl[q] : str[q];
+      --ti;
+    }
+  };
+  // per-lane LDS indices (floats, relative to a slot)
+  const int i_x = Lay::CH_x * 4 + r4 * NX + lane_x;
+  const int i_k = col_aff ? Lay::CH_k * 4 + r4 * NU : Lay::CH_K * 4 + r4 * NU * NX + lane_x;
+  const int k_step = col_aff ? 1 : NX;
+  const int i_C = Lay::CH_C * 4 + (r4 * NS + lane_t) * NS, i_c = Lay::CH_c * 4 + r4 * NS + lane_t;
+  const int i_F = Lay::CH_F * 4 + (r4 * NX + lane_x) * NS, i_f = Lay::CH_f * 4 + r4 * NX + lane_x;
+  auto read_slot = [&](const float *slot, Slot &sl) {
+    sl.xt = slot[i_x];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) {
+      sl.kv[m] = slot[i_k + m * k_step];
+      sl.uc[m] = slot[Lay::CH_u * 4 + r4 * NU + m];
+      sl.lb[m] = slot[Lay::CH_lo * 4 + r4 * NU + m];
+      sl.ub[m] = slot[Lay::CH_hi * 4 + r4 * NU + m];
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      sl.Crow[j] = slot[i_C + j];
+      sl.Frow[j] = slot[i_F + j];
+    }
+    sl.Crow[NS] = 0.f;
+    sl.Frow[NS] = 0.f;
+    sl.ci = slot[i_c];
+    sl.fi = has_f ? slot[i_f] : 0.f;
+  };
   auto row_dot = [&](const Slot &sl, float v) {   // (C v)[lane]: broadcast-FMAs fused into one DPP instruction each
     float q = 0.f;
     Blk::dot_x(q, v, sl.Crow);
@@ -416,9 +510,11 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   float cost = 0.f;
   int n_pass = 0;
   bool worse = true;
-  while (worse && n_pass < a.ls_cap) {  // :196 - until this trajectory is not worse than before
-    float xh = is_x ? a.states[(size_t)b * NX + lane] : 0.f;  // new_x[0] = states[0]     :198
-    cost = 0.f;
+  bool searching = a.ls_cap > 0;   // this trajectory's search goes on                      :196
+  for (int pass_idx = 0; __any(searching); ++pass_idx) {
+    float xh = 0.f;                                            // new_x[0] = states[0]     :198
+    if constexpr (!DMA) xh = is_x ? a.states[(size_t)b * NX + lane] : 0.f;   // (DMA: from the ring's first slot, below)
+    float cost_p = 0.f, old_p = 0.f;
     float delta = 0.f;                  // current_cost - OLD_COST, summed per timestep
     auto step = [&](int t, const Slot &sl) {
       const size_t tb = (size_t)t * B + b;
@@ -444,17 +540,17 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       // per-lane partial sums over the timesteps; the lanes of the group are added up ONCE after the pass (only the
       // optional per-step output `objs` needs the sum of a single step)                          :246-251, util.py:162-198
       const float obj_l = is_tau ? tau * fmaf(0.5f, qi, sl.ci) : 0.f;
-      cost += obj_l;
+      cost_p += obj_l;
       delta += is_tau ? fmaf(dt_, fmaf(0.5f, qi, sl.ci), 0.5f * tau0 * qd) : 0.f;
-      if (n_pass == 0)     // cost of the iterate, from C tau = C tau' - C d                                 :191
-        old_cost += is_tau ? tau0 * fmaf(0.5f, qi - qd, sl.ci) : 0.f;
+      if (pass_idx == 0)   // cost of the iterate, from C tau = C tau' - C d                                 :191
+        old_p += is_tau ? tau0 * fmaf(0.5f, qi - qd, sl.ci) : 0.f;
       float obj = 0.f;
       if (a.objs != nullptr) obj = group_sum<L>(obj_l);
-      if (live) {  // outputs are overwritten by later passes; the last one is the accepted one
+      if (live && searching) {  // outputs are overwritten by later passes; the last one is the accepted one
         if (is_x) a.x[tb * NX + lane] = xh;
         else if (lane < NS) a.u[tb * NU + (lane - NX)] = tau;
         if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
-        if (a.u_first != nullptr && n_pass == 0 && lane >= NX && lane < NS) a.u_first[tb * NU + (lane - NX)] = tau;
+        if (a.u_first != nullptr && pass_idx == 0 && lane >= NX && lane < NS) a.u_first[tb * NU + (lane - NX)] = tau;
       }
       if (t < T - 1 && !lin) {  // built-in pendulum (cos th, sin th, dth), torque -> next   pendulum.py:84-98
         if constexpr (NX == 3 && NU == 1) {
@@ -472,27 +568,62 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
         xh = is_x ? acc : 0.f;
       }
     };
-    Slot sa, sb, sc;
-    load(0, sa);
-    load(1, sb);
-    for (int t = 0; t < T; t += 3) {
-      load(t + 2, sc);
-      step(t, sa);
-      if (t + 1 < T) {
-        load(t + 3, sa);
-        step(t + 1, sb);
+    if constexpr (DMA) {
+      // software pipeline of mpc_backward_rec_dma_body, forward in time; the stores of a pass only make the counted
+      // wait more conservative
+      Slot sa, sb;
+#pragma unroll
+      for (int q = 0; q < Lay::kDma; ++q) ptr[q] = ptr0[q];
+      ti = T - 1;
+      static_for<0, DB>([&](auto j) { issue_next(j.value); });
+      wait_vmcnt<(DB - 1) * Lay::kDma>();
+      read_slot(ring, sa);
+      xh = is_x ? sa.xt : 0.f;
+      for (int t0 = 0; t0 < T; t0 += DB) {
+        static_for<0, DB>([&](auto j) {
+          const int t = t0 + j.value;
+          if (t < T) {
+            constexpr int nslot = (j.value + 1) % DB;
+            issue_next(j.value);
+            wait_vmcnt<(DB - 1) * Lay::kDma>();
+            if constexpr (j.value % 2 == 0) {
+              read_slot(ring + nslot * Lay::SLOT, sb);
+              step(t, sa);
+            } else {
+              read_slot(ring + nslot * Lay::SLOT, sa);
+              step(t, sb);
+            }
+          }
+        });
       }
-      if (t + 2 < T) {
-        load(t + 4, sb);
-        step(t + 2, sc);
+      wait_vmcnt<0>();   // the ring is refilled from t = 0 by the next pass
+    } else {
+      Slot sa, sb, sc;
+      load(0, sa);
+      load(1, sb);
+      for (int t = 0; t < T; t += 3) {
+        load(t + 2, sc);
+        step(t, sa);
+        if (t + 1 < T) {
+          load(t + 3, sa);
+          step(t + 1, sb);
+        }
+        if (t + 2 < T) {
+          load(t + 4, sb);
+          step(t + 2, sc);
+        }
       }
     }
-    cost = group_sum<L>(cost);
+    cost_p = group_sum<L>(cost_p);
     delta = group_sum<L>(delta);
-    if (n_pass == 0) old_cost = group_sum<L>(old_cost);
-    ++n_pass;
-    worse = delta > 0.f;                 // :266  current_cost > OLD_COST
-    if (worse) alpha *= a.ls_decay;      // :268
+    if (pass_idx == 0) old_cost = group_sum<L>(old_p);
+    if (searching) {
+      cost = cost_p;
+      ++n_pass;
+      worse = delta > 0.f;                 // :266  current_cost > OLD_COST
+      if (worse) alpha *= a.ls_decay;      // :268
+      searching = worse && n_pass < a.ls_cap;
+    }
   }
   int info_bits = 0;
   if (worse) {                           // cap hit: the reference would still be looping; :274
@@ -508,6 +639,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
     if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
   }
 }
+
 
 // forward_rec for the pendulum with a SPECULATIVE line search: the step sizes the search of mpc_step.py:196-268 can
 // visit are known in advance (alpha_p = ls_decay^p), and on the swing-up problem it usually walks ten or more of
