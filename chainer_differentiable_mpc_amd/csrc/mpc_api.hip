@@ -477,7 +477,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   auto ip = [&](size_t off) { return reinterpret_cast<int32_t *>(base + off); };
   float *xs = fp(w.xs), *c_back = fp(w.c_back), *Ks = fp(w.Ks), *ks = fp(w.ks), *x_new = fp(w.x_new);
   float *u_buf[2] = {fp(w.u_a), fp(w.u_b)};
-  float *u1 = fp(w.u1), *costs = fp(w.costs), *old = fp(w.old), *alphas = fp(w.alphas);
+  float *u1 = fp(w.u1), *costs = fp(w.costs), *alphas = fp(w.alphas);
   const float *F_hat = dyn_kind == 0 ? F : fp(w.F);
   const float pg = dyn_kind == 1 ? dyn_params[0] : 0.f, pm = dyn_kind == 1 ? dyn_params[1] : 0.f,
               pl = dyn_kind == 1 ? dyn_params[2] : 0.f, pdt = dyn_kind == 1 ? dyn_params[3] : 0.f,
@@ -528,7 +528,8 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
                              reinterpret_cast<unsigned *>(base + w.sel_sync));
     if (rc != 0) return rc;
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs_it, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
-                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1, costs, old,
+                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1, costs,
+                  /*old_costs: nobody reads them here*/ nullptr,
                   alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done,
                   fuse_lin ? fp(w.F) : nullptr, fuse_lin ? fp(w.f) : nullptr, fuse_lin ? c_back : nullptr, 0,
                   fused_select && info != nullptr ? ip(w.info_back) : nullptr};

@@ -10,6 +10,7 @@
 //   taylor_c_kernel           the need_expand re-centring c_hat_t = C_t [x_t;u_t] + c_t, :305-317.
 //   active_mask_kernel        active = |u-lo| <= 1e-8 | |u-hi| <= 1e-8 (:363-364) and -[dl_dx;dl_du].
 #pragma once
+#include <type_traits>
 #include "colwise.hpp"
 #include "dma_gather.hpp"
 #include "dpp_blocks_gen.hpp"
@@ -777,15 +778,16 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
     return acc;
   };
   // one rollout with step size alpha; mode 0: cost only, 1: also the cost of the nominal trajectory and (candidate 0)
-  // the controls of the alpha = 1 pass, 2: write the trajectory.  `delta` = cost - OLD_COST summed per timestep.
+  // the controls of the alpha = 1 pass, 3: as 1 without the nominal cost, 2: write the trajectory.  `delta` = cost - OLD_COST summed per timestep.
   float delta = 0.f;
-  auto pass = [&](float alpha, int mode, float &cost, float &old_cost) {
+  auto pass = [&](auto mode_c, float alpha, float &cost, float &old_cost) {   // the mode is a compile-time constant:
+    constexpr int mode = decltype(mode_c)::value;                              // no mode tests inside the T steps
     float xh[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xh[i] = a.states[(size_t)b * NX + i];                       // :198
     cost = 0.f;
     delta = 0.f;
-    if (mode == 1) old_cost = 0.f;
+    if (mode == 1 || mode == 3) old_cost = 0.f;
     auto step = [&](int t, const Slot &sl) {
       const size_t tb = (size_t)t * B + b;
       float v = alpha * sl.kk;
@@ -804,8 +806,8 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
 #pragma unroll
         for (int i = 0; i < NS; ++i) traj[(t * NS + i) * 256 + threadIdx.x] = tau[i];
       }
-      if (mode == 1) {
-        old_cost += quad(sl, tau0);                                                          // :191
+      if (mode == 1) old_cost += quad(sl, tau0);                                             // :191
+      if (mode == 1 || mode == 3) {
         if (k == 0 && live && a.u_first != nullptr) a.u_first[tb] = v;                       // :260-263
       }
       if (mode == 2 && k == 0 && live) {
@@ -886,7 +888,9 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
       alpha = 1.f;
       for (int i = 0; i < p; ++i) alpha *= a.ls_decay;                                       // :268, p times
       float oc = 0.f;
-      pass(alpha, r == 0 ? 1 : 0, cost, oc);
+      if (r == 0 && a.old_costs != nullptr) pass(std::integral_constant<int, 1>{}, alpha, cost, oc);
+      else if (r == 0) pass(std::integral_constant<int, 3>{}, alpha, cost, oc);   // nobody asked for OLD_COST itself
+      else pass(std::integral_constant<int, 0>{}, alpha, cost, oc);
       if (r == 0) old_cost = oc;
     }
     const bool accept = searching && p < a.ls_cap && !(delta > 0.f);                         // :266  cost > OLD_COST
@@ -943,12 +947,12 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
     float dummy = 0.f, c2 = 0.f;
     float al = 1.f;
     for (int i = 0; i < a.ls_cap - 1; ++i) al *= a.ls_decay;
-    pass(al, 2, c2, dummy);
+    pass(std::integral_constant<int, 2>{}, al, c2, dummy);
   } else {
     n_pass = p_sel + 1;
     if (!keep_traj) {   // no LDS copy of the candidates: roll the accepted one out again and write it
       float dummy = 0.f, c2 = 0.f;
-      pass(alpha_sel, 2, c2, dummy);
+      pass(std::integral_constant<int, 2>{}, alpha_sel, c2, dummy);
     }
   }
   if (!is_finite(cost_sel)) info_bits |= 2;
