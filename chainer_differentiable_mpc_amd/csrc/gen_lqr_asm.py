@@ -544,7 +544,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
             box_qp(s, first)
             for m in range(nu):      # K_t: rows of clamped controls zero, the QP's last H_f (mpc_step.py:147-157)
                 P.v("v_cndmask_b32_e64 %s, %s, 0, %s" % (Rm[m], Qs[nx + m], S_ACT[m]), writes=(Rm[m],), reads=(Qs[nx + m],))
-            masked_hessian(QP_REG)
+            # Am still holds that H_f: the QP's last pass built it from the same clamped set (a lane that converged
+            # earlier rebuilt the same one from its frozen iterate)
             rhs = Rm
             Au = Am
         elif masked:
