@@ -57,6 +57,11 @@ X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by 
 MFMA_USE = int(os.environ.get("GEN_MFMA_USE", "5"))     # wait states kept before a non-accumulating use of an MFMA result
 MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
 X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
+# Stash variants of (8,2): the backward sweep unrolled over the horizon (NSTASH steps, one exit test each), so that the F
+# block of a step goes to its accumulation registers by reads emitted in place - the table of per-step stubs, called by
+# s_setpc_b64 and left by s_branch, cost ~65 of a step's ~880 cycles (32.9 -> 31.3 us at B=4096 T=50; the stream grows
+# to ~75 KB, and wavefronts of a CU run it close enough to lock step for the instruction cache).  GEN_UNROLL_BWD=0: the loop.
+X_UNROLL_BWD = os.environ.get("GEN_UNROLL_BWD", "1") == "1"
 USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
 
 
@@ -637,7 +642,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
                 for i in range(nx):
                     P.fmac_dpp(Qs[i], Kt[m], Rr[m], i)
 
-    def bstep(s, first, extra_outstanding=0):
+    def bstep(s, first, extra_outstanding=0, stub_n=None):
         p, n = (s + 2) % 3, (s + 1) % 3
         V = Q[p]
         issue_group(ptr, s, L.SLOT_B, gap="s_waitcnt lgkmcnt(0)")   # the slot's last reads are in before it is refilled
@@ -685,7 +690,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
                 P.fmac_dpp(W[i], V[i], "%[eaff]", aff)
         vmwait((DB - 1) * NDB_ALL + extra_outstanding)
         read_set(n, n)
-        if stash:
+        if stash and stub_n is not None:
+            # unrolled sweep: this step's stash registers are known here
+            for p_, (w, off) in enumerate(L.stash_pieces):
+                regs = stash_regs_of(p_, stub_n - 1)
+                if w == 2:
+                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], stub_n % 3, off, off + 1))
+                else:
+                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], stub_n % 3, off * 4))
+        elif stash:
             # F of the NEXT step goes from its ring slot into this step's stash registers: the register numbers
             # differ per step, so the two reads live in a table of stubs (one per step) that is called here
             lo = int(S_STUB[2:S_STUB.index(":")])
@@ -812,19 +825,27 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
     P.comment("---- t = T-1")
     stamp(1)
-    bstep(0, True, n_extra)
+    unroll_bwd = X_UNROLL_BWD and stash and (nx, nu) == (8, 2)
+    bstep(0, True, n_extra, stub_n=1 if unroll_bwd else None)
     if X_SKIP_BWD:
         P.raw("s_branch Lbwd_done_%=")
     in_loop[0] = True
-    P.label("Lbwd_%=")
-    for s in (1, 2, 0):
-        P.comment("---- backward step, register set %d" % s)
-        bstep(s, False)
-        P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
-        if s != 0:
+    if unroll_bwd:
+        for k in range(1, L.NSTASH):
+            P.comment("---- backward step %d, register set %d" % (k, k % 3))
+            bstep(k % 3, False, stub_n=k + 1)
+            P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
             P.raw("s_cbranch_scc1 Lbwd_done_%=")
-        else:
-            P.raw("s_cbranch_scc0 Lbwd_%=")
+    else:
+        P.label("Lbwd_%=")
+        for s in (1, 2, 0):
+            P.comment("---- backward step, register set %d" % s)
+            bstep(s, False)
+            P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
+            if s != 0:
+                P.raw("s_cbranch_scc1 Lbwd_done_%=")
+            else:
+                P.raw("s_cbranch_scc0 Lbwd_%=")
     P.label("Lbwd_done_%=")
     in_loop[0] = False
     n_bwd = P.n_instr
@@ -1035,7 +1056,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
         # ---- backward stubs: F block of ring slot (n % 3) -> stash slot n-1
         P.lines.append(".p2align 5")
         P.label("Lbstub_%=")
-        for n in range(1, L.NSTASH + 1):
+        for n in range(1, (0 if unroll_bwd else L.NSTASH) + 1):
             P.lines.append(".p2align 5")
             for p, (w, off) in enumerate(L.stash_pieces):
                 regs = stash_regs_of(p, n - 1)
