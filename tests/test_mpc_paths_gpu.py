@@ -45,6 +45,9 @@ CASES = [
     pytest.param(8, 9, 8, 2, 0.25, False, id="stream-with-f-8-2"),
     pytest.param(12, 8, 3, 1, 0.5, True, id="stream-recentring-3-1"),
     pytest.param(4, 6, 3, 2, 0.375, False, id="stream-with-f-3-2"),
+    pytest.param(4, 2, 3, 1, 0.5, True, id="stream-shortest-horizon-3-1"),
+    pytest.param(4, 3, 8, 2, 0.25, False, id="stream-three-steps-8-2"),
+    pytest.param(4, 4, 8, 2, 0.25, True, id="stream-four-steps-8-2"),
     pytest.param(8, 7, 6, 2, 0.25, True, id="dma-ring-6-2"),
     pytest.param(4, 6, 4, 4, 0.375, False, id="dma-ring-4-4"),
     pytest.param(8, 6, 8, 4, 0.25, True, id="dma-ring-8-4"),
