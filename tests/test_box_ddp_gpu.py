@@ -282,6 +282,24 @@ def test_device_loop_matches_host_loop_pendulum(max_iter):
     assert_close(dev_[2], host[2], 1e-5, "costs")
 
 
+@pytest.mark.parametrize("B", [6, 260, 2304], ids=["ragged-plain-chain", "two-bookkeeping-workgroups", "keep-kernel"])
+def test_device_loop_matches_host_loop_pendulum_other_batches(B):
+    """the chain's other shapes: a batch that is not a multiple of four (register-bank kernels, one bookkeeping launch
+    per iteration), one whose bookkeeping is shared by two workgroups with a partly filled second one, and one too
+    large for the bookkeeping workgroups to move the kept trajectories themselves (box_ddp_keep_kernel)"""
+    T = 20
+    dx, x0, Q, pv = pendulum_problem(B, T, seed=4)
+    kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter)
+    dev_, host = _run_both(
+        lambda dl: BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, max_iter=4, exit_unconverged=False, quiet=True,
+                          device_loop=dl, **kw),
+        lambda: (dev(x0), QuadCost(dev(Q), dev(pv)), dx))
+    assert dev_[3] == host[3] and dev_[4] == host[4], (dev_[3:], host[3:])
+    assert_close(dev_[1], host[1], 1e-5, "u")
+    assert_close(dev_[0], host[0], 1e-5, "x")
+    assert_close(dev_[2], host[2], 1e-5, "costs")
+
+
 @pytest.mark.parametrize("shape", [(16, 8, 3, 2, 0.3), (64, 12, 8, 2, 0.5), (5, 6, 4, 2, 10.0), (12, 6, 5, 3, 0.5)])
 def test_device_loop_matches_host_loop_lindx(shape):
     # the nominal rollout is a kernel here and torch ops there: rounding differs, the iteration amplifies it
