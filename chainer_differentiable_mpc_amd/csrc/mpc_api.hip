@@ -192,11 +192,21 @@ static bool spec_line_search_disabled() {  // DMPC_NO_SPEC_LS=1: sequential line
   return off;
 }
 
+static bool spec4_disabled() {  // DMPC_NO_SPEC4=1: the lane-per-candidate speculative search (A/B timing, longer horizons' path)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_SPEC4"); return e && e[0] == '1'; }();
+  return off;
+}
+
 static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t stream) {
   MpcFwdArgs a = a_in;
   if (a.dyn_kind == 1 && nx == 3 && nu == 1 && !spec_line_search_disabled()) {
     // the pendulum's line search usually walks ten or more step sizes: 16 candidates per trajectory at once; every
     // candidate keeps its trajectory in LDS (T * 4 KB per workgroup) when that fits
+    if (a.T <= kSpec4MaxT && !spec4_disabled()) {   // a wavefront per trajectory, all inputs and candidates in LDS
+      hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec4_kernel, dim3((a.B + 3) / 4), dim3(256),
+                         Spec4Layout::lds_bytes(a.T), stream, a);
+      return (int)hipGetLastError();
+    }
     const size_t lds = (size_t)a.T * 4 * 256 * sizeof(float);
     a.traj_in_lds = lds <= 96 * 1024 ? 1 : 0;
     const bool dma = a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&

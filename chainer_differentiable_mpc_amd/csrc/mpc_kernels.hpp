@@ -258,14 +258,17 @@ __device__ __forceinline__ PendulumModel pendulum_model(float g, float m, float 
 // reduction and its branches are a quarter of a rollout step's instructions.  Minimax kernels of the Cephes sinf / cosf
 // on [-pi/4, pi/4] (error below one ulp of the result); anything larger goes to the library.
 __device__ __forceinline__ void sincos_increment(float x, float &sn, float &cs) {
-  if (fabsf(x) <= 0.785398163f) {
-    const float z = x * x;
-    const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
-    const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-    sn = fmaf(x * z, ps, x);
-    cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
-  } else {
-    sincosf(x, &sn, &cs);
+  const float z = x * x;
+  const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  sn = fmaf(x * z, ps, x);
+  cs = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+  const bool big = !(fabsf(x) <= 0.785398163f);
+  if (__builtin_amdgcn_ballot_w64(big) != 0) {   // wave-uniform branch (almost never taken); per-lane result either way
+    float sl, cl;
+    sincosf(x, &sl, &cl);
+    sn = big ? sl : sn;
+    cs = big ? cl : cs;
   }
 }
 
@@ -969,6 +972,212 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
 template <bool DMA>
 __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec_kernel(const MpcFwdArgs a) {
   mpc_forward_rec_pendulum_spec_body<DMA>(a, blockIdx.x);
+}
+
+// The speculative search with a wavefront per trajectory: 16 candidates x 4 lanes.  The four lanes of a candidate split
+// what has four rows - the rows of C in C tau and C d, the elements of tau kept in LDS - and repeat the rest (control,
+// clamp, pendulum step): ~110 instructions per timestep instead of ~290 when one lane does it all, and with one
+// wavefront per SIMD (or fewer) a sweep's time is its instruction count.  All T timesteps of the trajectory's inputs
+// (30 floats each) are brought into LDS once by T dword gather DMAs - every round of 16 candidates and the copy-out of
+// the accepted one read them from there - and the candidates' trajectories stay in LDS until one is accepted, which
+// also serves the reference's "still looping at the cap" case.  Needs T <= kSpec4MaxT (LDS).
+constexpr int kSpec4MaxT = 32;
+struct Spec4Layout {  // floats of one timestep's inputs in LDS (one dword per DMA lane, 64 lanes)
+  static constexpr int C = 0, c = 16, K = 20, k = 23, u = 24, lo = 25, hi = 26, x = 27, END = 30, SLOT = 64;
+  static constexpr size_t lds_bytes(int T) { return (size_t)4 * 2 * T * SLOT * 4; }   // inputs + trajectories, 4 wavefronts
+};
+
+__global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(const MpcFwdArgs a) {
+  constexpr int NX = 3, NS = 4, NC = 16;
+  using Lay = Spec4Layout;
+  if (a.done != nullptr && *a.done != 0) return;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int cand = lane64 >> 2, sub = lane64 & 3;
+  const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+  if (b >= a.B) return;   // whole wavefront; no workgroup barrier below
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+  extern __shared__ float spec4_lds[];
+  float *in_ = spec4_lds + (size_t)wave * 2 * T * Lay::SLOT, *traj = in_ + (size_t)T * Lay::SLOT;
+
+  {  // every timestep's inputs -> LDS: lane g < 30 carries one float of [C | c | K | k | u | lower | upper | x]
+    const int g = lane64;
+    const float *base = a.C;
+    size_t per = 16;
+    int j = 0;   // lanes >= 30: C[0] again (never read)
+    if (g < Lay::c) { j = g; }
+    else if (g < Lay::K) { base = a.c; per = 4; j = g - Lay::c; }
+    else if (g < Lay::k) { base = a.Ks; per = 3; j = g - Lay::K; }
+    else if (g < Lay::u) { base = a.ks; per = 1; }
+    else if (g < Lay::lo) { base = a.controls; per = 1; }
+    else if (g < Lay::hi) { base = a.lower; per = 1; }
+    else if (g < Lay::x) { base = a.upper; per = 1; }
+    else if (g < Lay::END) { base = a.states; per = 3; j = g - Lay::x; }
+    unsigned long long ptr = reinterpret_cast<unsigned long long>(base + (size_t)b * per + j);
+    const unsigned long long str = (unsigned long long)(B * per * 4);
+    const unsigned in_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(in_));
+    for (int t = 0; t < T; ++t) {
+      set_m0(in_addr + (unsigned)t * (Lay::SLOT * 4));
+      asm volatile("global_load_lds_dword %0, off" ::"v"(ptr) : "memory");
+      ptr += str;
+    }
+    wait_vmcnt<0>();
+  }
+
+  const unsigned m0 = sub == 0 ? ~0u : 0u, m1 = sub == 1 ? ~0u : 0u, m2 = sub == 2 ? ~0u : 0u, m3 = sub == 3 ? ~0u : 0u;
+  auto pick4 = [&](float e0, float e1, float e2, float e3) {
+    const unsigned r = (__builtin_bit_cast(unsigned, e0) & m0) | (__builtin_bit_cast(unsigned, e1) & m1) |
+                       (__builtin_bit_cast(unsigned, e2) & m2) | (__builtin_bit_cast(unsigned, e3) & m3);
+    return __builtin_bit_cast(float, r);
+  };
+  // one rollout of this lane's candidate with step size alpha; WITH_OLD: also the cost of the nominal trajectory.
+  // Per-lane partial sums (this lane's row of C) - the four lanes of a candidate are added up after the pass.
+  auto pass = [&](auto with_old_c, float alpha, float &cost, float &delta, float &old_cost) {
+    constexpr bool WITH_OLD = decltype(with_old_c)::value;
+    float xh[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xh[i] = in_[Lay::x + i];                                    // :198
+    cost = 0.f;
+    delta = 0.f;
+    old_cost = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float *sl = in_ + t * Lay::SLOT;
+      const float4 Cr = *reinterpret_cast<const float4 *>(sl + Lay::C + sub * 4);   // row `sub` of C_t
+      const float cs = sl[Lay::c + sub];
+      const float4 Kk = *reinterpret_cast<const float4 *>(sl + Lay::K);             // K_t (3), k_t
+      const float4 ub4 = *reinterpret_cast<const float4 *>(sl + Lay::u);            // u_t, lower, upper, x_t[0]
+      const float2 x12 = *reinterpret_cast<const float2 *>(sl + Lay::x + 1);
+      const float uc = ub4.x, lb = ub4.y, ub = ub4.z;
+      const float xt[NX] = {ub4.w, x12.x, x12.y};
+      float v = alpha * Kk.w;
+      v = fmaf(Kk.z, xh[2] - xt[2], v);
+      v = fmaf(Kk.y, xh[1] - xt[1], v);
+      v = fmaf(Kk.x, xh[0] - xt[0], v);
+      v += uc;                                                                               // :209-219
+      v = fminf(fmaxf(v, lb), ub);                                                           // :221
+      v = (v - lb <= bound_tol(lb)) ? lb : v;
+      v = (ub - v <= bound_tol(ub)) ? ub : v;
+      const float tau[NS] = {xh[0], xh[1], xh[2], v};
+      const float d[NS] = {xh[0] - xt[0], xh[1] - xt[1], xh[2] - xt[2], v - uc};
+      float qi = 0.f, qd = 0.f;   // (C tau)[sub], (C d)[sub]
+      qi = fmaf(Cr.x, tau[0], qi); qi = fmaf(Cr.y, tau[1], qi); qi = fmaf(Cr.z, tau[2], qi); qi = fmaf(Cr.w, tau[3], qi);
+      qd = fmaf(Cr.x, d[0], qd); qd = fmaf(Cr.y, d[1], qd); qd = fmaf(Cr.z, d[2], qd); qd = fmaf(Cr.w, d[3], qd);
+      // element `sub` of tau / tau0 by bit masks (hipcc turns a chain of selects on `sub` into exec-mask branches)
+      const float tau_s = pick4(tau[0], tau[1], tau[2], tau[3]);
+      const float tau0_s = pick4(xt[0], xt[1], xt[2], uc);
+      const float d_s = tau_s - tau0_s;
+      const float lin = fmaf(0.5f, qi, cs);
+      cost = fmaf(tau_s, lin, cost);                                                         // util.py:162-198
+      // obj(tau) - obj(tau0) without cancellation (see mpc_forward_rec_kernel): 1/2 d'(C tau) + 1/2 tau0'(C d) + c'd
+      delta += fmaf(d_s, lin, 0.5f * tau0_s * qd);
+      if constexpr (WITH_OLD) old_cost = fmaf(tau0_s, fmaf(0.5f, qi - qd, cs), old_cost);    // :191, C tau0 = C tau - C d
+      traj[t * Lay::SLOT + lane64] = tau_s;
+      if (t < T - 1) {
+        float cn, sn, wn, nth;
+        pendulum_next(pm, xh[0], xh[1], xh[2], v, cn, sn, wn, nth);
+        xh[0] = cn;
+        xh[1] = sn;
+        xh[2] = wn;
+      }
+    }
+    // the four lanes of the candidate: rows of C
+    auto sum4 = [](float v_) {
+      v_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+      v_ += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v_), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+      return v_;
+    };
+    cost = sum4(cost);
+    delta = sum4(delta);
+    if constexpr (WITH_OLD) old_cost = sum4(old_cost);
+  };
+
+  const int rounds = (a.ls_cap + NC - 1) / NC;
+  float old_cost = 0.f, cost = 0.f, delta = 0.f, alpha = 1.f;
+  float alpha_sel = 1.f, cost_sel = 0.f;
+  int p_sel = -1, ks = 0;
+  for (int r = 0; r < rounds && p_sel < 0; ++r) {   // wave-uniform: the wavefront has ONE trajectory
+    const int p = r * NC + cand;
+    alpha = 1.f;
+    for (int i = 0; i < p; ++i) alpha *= a.ls_decay;                                         // :268, p times
+    float oc = 0.f;
+    if (r == 0 && a.old_costs != nullptr) {
+      pass(std::true_type{}, alpha, cost, delta, oc);
+      old_cost = oc;
+    } else {
+      pass(std::false_type{}, alpha, cost, delta, oc);
+    }
+    if (r == 0 && a.u_first != nullptr && cand == 0 && sub == 3) {                           // :260-263
+      for (int t = 0; t < T; ++t) a.u_first[(size_t)t * B + b] = traj[t * Lay::SLOT + 3];
+    }
+    const bool accept = p < a.ls_cap && !(delta > 0.f);                                      // :266  cost > OLD_COST
+    const unsigned long long mask = __ballot(accept);
+    if (mask != 0ull) {
+      const int first = __ffsll((long long)mask) - 1;   // first lane of the first accepted candidate
+      ks = first >> 2;
+      p_sel = r * NC + ks;
+      alpha_sel = __shfl(alpha, first);
+      cost_sel = __shfl(cost, first);
+    }
+  }
+  int info_bits = 0;
+  int n_pass;
+  if (p_sel < 0) {  // cap hit: the reference would still be looping; its last pass is the result        :274
+    ks = (a.ls_cap - 1) % NC;   // still in LDS: a candidate of the last round
+    alpha_sel = __shfl(alpha, ks * 4);
+    cost_sel = __shfl(cost, ks * 4);
+    alpha_sel = (alpha_sel * a.ls_decay) / a.ls_decay;
+    n_pass = a.ls_cap;
+    info_bits |= 8;
+  } else {
+    n_pass = p_sel + 1;
+  }
+  // the result's trajectory (a wavefront executes in lock step: the pass's LDS writes are complete), with the NEXT
+  // iteration's model when asked for; the lanes share the timesteps
+  for (int t = lane64; t < T; t += 64) {
+    const size_t tb = (size_t)t * B + b;
+    const float4 tau = *reinterpret_cast<const float4 *>(traj + t * Lay::SLOT + ks * 4);
+    a.x[tb * NX + 0] = tau.x;
+    a.x[tb * NX + 1] = tau.y;
+    a.x[tb * NX + 2] = tau.z;
+    a.u[tb] = tau.w;
+    if (a.c_next != nullptr || a.objs != nullptr) {
+      const float *sl = in_ + t * Lay::SLOT;
+      const float tv[NS] = {tau.x, tau.y, tau.z, tau.w};
+      float cn4[NS], obj = 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const float4 Cr = *reinterpret_cast<const float4 *>(sl + Lay::C + i * 4);
+        const float ci = sl[Lay::c + i];
+        float q = 0.f;
+        q = fmaf(Cr.x, tau.x, q); q = fmaf(Cr.y, tau.y, q); q = fmaf(Cr.z, tau.z, q); q = fmaf(Cr.w, tau.w, q);
+        obj = fmaf(tv[i], fmaf(0.5f, q, ci), obj);                                           // util.py:162-198
+        float acc = ci;                                                                      // mpc_step.py:305-317
+        acc = fmaf(Cr.x, tau.x, acc); acc = fmaf(Cr.y, tau.y, acc); acc = fmaf(Cr.z, tau.z, acc); acc = fmaf(Cr.w, tau.w, acc);
+        cn4[i] = acc;
+      }
+      if (a.objs != nullptr) a.objs[tb] = obj;
+      if (a.c_next != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) a.c_next[tb * NS + i] = cn4[i];
+      }
+    }
+    if (t < T - 1 && a.F_next != nullptr) {
+      const float4 nx4 = *reinterpret_cast<const float4 *>(traj + (t + 1) * Lay::SLOT + ks * 4);
+      pendulum_jacobian_store(pm, tau.x, tau.y, tau.z, tau.w, nx4.x, nx4.y, nx4.z, a.F_next + tb * 12,
+                              a.f_next != nullptr ? a.f_next + tb * 3 : nullptr);
+    }
+  }
+  if (!is_finite(cost_sel)) info_bits |= 2;
+  if (lane64 == 0) {
+    if (a.info_in != nullptr) info_bits |= a.info_in[b];
+    a.costs[b] = cost_sel;
+    if (a.old_costs != nullptr) a.old_costs[b] = old_cost;
+    a.alphas[b] = alpha_sel;
+    a.n_ls[b] = n_pass;
+    if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+  }
 }
 
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
