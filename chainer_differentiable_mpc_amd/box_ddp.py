@@ -132,7 +132,7 @@ class BoxDDP(torch.nn.Module):
         out = torch.empty((n_x + n_u + 3 * B,), dtype=torch.float32, device=d)
         bx, bu = out[:n_x].view(T, B, nx), out[n_x:n_x + n_u].view(T, B, nu)
         bc, bn, ln = out[n_x + n_u:].view(3, B).unbind(0)
-        ints = torch.zeros((B + 8,), dtype=torch.int32, device=d)
+        ints = torch.empty((B + 8,), dtype=torch.int32, device=d)   # flags and loop state: cleared by the chain's first launch
         info, state = ints[:B], ints[B:]
         need = lib.dmpc_box_ddp_workspace_bytes(T, B, nx, nu)
         ws = _workspace(need, d)

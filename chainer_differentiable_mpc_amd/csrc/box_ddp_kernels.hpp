@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mpc_kernels.hpp"
 
 namespace dmpc {
 
@@ -24,8 +25,9 @@ enum { kDdpDone = 0, kDdpIter = 1, kDdpStatus = 2, kDdpNotImproved = 3 };
 __global__ __launch_bounds__(64) void lin_rollout_kernel(int T, int B, int nx, int nu, const float *__restrict__ x_init,
                                                          const float *__restrict__ u, const float *__restrict__ F,
                                                          const float *__restrict__ f, float *__restrict__ x,
-                                                         const int32_t *__restrict__ done) {
+                                                         const int32_t *__restrict__ done, const ChainClear clear) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  clear.run(b);
   if (b >= B) return;
   if (done != nullptr && *done != 0) return;
   const int ns = nx + nu;

@@ -454,7 +454,7 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
                      const float *f, float *x_out, dmpc_stream_t stream_) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0 || !x_init || !u || !x_out || (T > 1 && !F)) return DMPC_E_BADARG;
   hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), T, B, nx,
-                     nu, x_init, u, F, f, x_out, nullptr);
+                     nu, x_init, u, F, f, x_out, nullptr, ChainClear{});
   return (int)hipGetLastError();
 }
 
@@ -493,8 +493,11 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
               pl = dyn_kind == 1 ? dyn_params[2] : 0.f, pdt = dyn_kind == 1 ? dyn_params[3] : 0.f,
               pmax = dyn_kind == 1 ? dyn_params[4] : 0.f;
   const size_t rows = (size_t)T * B;
-  hipError_t e = hipMemsetAsync(state, 0, 8 * sizeof(int32_t), stream);
-  if (e != hipSuccess) return (int)e;
+  // loop state, the bookkeeping workgroups' meeting words and the flags are cleared by the chain's first launch
+  ChainClear clear;
+  clear.p[0] = state; clear.n[0] = 8;
+  clear.p[1] = ip(w.sel_sync); clear.n[1] = 4;
+  clear.p[2] = info; clear.n[2] = info != nullptr ? B : 0;
   const int32_t *done = state + kDdpDone;
   // Pendulum: the trajectory the line search accepts IS the next iteration's nominal one, and the search writes its
   // linearisation and re-centred cost while it writes the trajectory - the rollout + linearisation kernel runs for
@@ -512,12 +515,13 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
     if (dyn_kind == 1) {
       if (it == 0 || !fuse_lin) {
-        PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs_it, fp(w.F), fp(w.f), done, C, c, c_back};
+        PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs_it, fp(w.F), fp(w.f), it == 0 ? nullptr : done, C, c,
+                        c_back, it == 0 ? clear : ChainClear{}};
         hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, pa);
       }
     } else {
       hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
-                         f, xs_it, done);
+                         f, xs_it, it == 0 ? nullptr : done, it == 0 ? clear : ChainClear{});
     }
     // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
     // pendulum: c_back was re-centred by the rollout kernel / the previous line search; LinDx: the backward sweep
@@ -529,10 +533,6 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     if (fused_select && info != nullptr) {   // the sweep may run ahead of `done`: its flags count only if the search follows
       ba.info = ip(w.info_back);
       ba.info_store = 1;
-    }
-    if (it == 0 && fused_select) {   // the words the bookkeeping workgroups meet at
-      e = hipMemsetAsync(base + w.sel_sync, 0, 4 * sizeof(unsigned), stream);
-      if (e != hipSuccess) return (int)e;
     }
     int rc = launch_mpc_back(nx, nu, ba, stream, fused_select && it > 0 ? &sa : nullptr,
                              reinterpret_cast<unsigned *>(base + w.sel_sync));

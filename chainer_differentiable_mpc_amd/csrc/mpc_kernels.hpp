@@ -1184,6 +1184,18 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(con
 // (env_dx/pendulum.py:84-98, simple model), F_t = d x_{t+1} / d [x_t; u_t], f_t = x_{t+1} - F_t [x_t; u_t] - what
 // BoxDDP obtains from get_traj (util.py:201-277) followed by linearize_dynamics (mpc/approximate.py:77-119, there
 // through chainer.grad).  The torque clamp has derivative 1 on the CLOSED interval [-max_torque, max_torque] (Chainer's F.clip backward, torch.clamp autograd), else 0: box-DDP's bounds equal the torque limit, so saturated controls sit exactly on it.
+// The first launch of a dmpc_box_ddp chain clears the words the chain accumulates into (a memset or fill launch of its
+// own costs 2-5 us of GPU time each for a few bytes): thread g of the grid zeroes word g of each range.
+struct ChainClear {
+  int32_t *p[3] = {nullptr, nullptr, nullptr};
+  int n[3] = {0, 0, 0};
+  __device__ __forceinline__ void run(int g) const {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (p[k] != nullptr && g < n[k]) p[k][g] = 0;
+  }
+};
+
 struct PendulumArgs {
   int T, B;
   const float *x_init, *u;   // [B,3], [T,B,1]
@@ -1194,9 +1206,11 @@ struct PendulumArgs {
   // c_back[t][b] = C[t][b] [x_t; u_t] + c[t][b]                                            mpc_step.py:305-317
   const float *C, *c;        // [T,B,4,4], [T,B,4]
   float *c_back;             // [T,B,4] or nullptr
+  ChainClear clear;          // first launch of a box-DDP chain: words to zero (loop state, meeting words, flags)
 };
 
 __device__ __forceinline__ void pendulum_rollout_linearize_body(const PendulumArgs &a, const int b) {
+  a.clear.run(b);
   if (b >= a.B) return;
   if (a.done != nullptr && *a.done != 0) return;
   const size_t B = (size_t)a.B;

@@ -192,7 +192,7 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
  *   [6] trajectories whose info carries DMPC_INFO_NONFINITE (0 without info), [7] du_norm_best > eps somewhere;
  *   scrambled_norm != 0 reproduces the reference's reshape in full_du_norm (mpc_step.py:261-263);
  *   batch_coupled != 0: batch-global PNQP termination inside every step (as dmpc_mpc_backward_rec);
- *   info [B] accumulates the MPC step flags of every iteration (caller zeroes it).                              */
+ *   info [B] (optional) is cleared by the call and receives the OR of the MPC step flags of every iteration.      */
 size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu);
 int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float *C, const float *c, const float *F,
                  const float *f, int dyn_kind, const float *dyn_params, const float *u_init, const float *u_lower,
