@@ -31,7 +31,8 @@ OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
          "-I" + os.path.join(ROOT, "include")] + os.environ.get("DMPC_EXTRA_FLAGS", "").split()   # experiment knobs
-GENERATED = {"lqr_asm_gen.hpp": "gen_lqr_asm.py", "dpp_blocks_gen.hpp": "gen_dpp_blocks.py"}
+GENERATED = {"lqr_asm_gen.hpp": "gen_lqr_asm.py", "dpp_blocks_gen.hpp": "gen_dpp_blocks.py",
+             "mpc_fwd_asm_gen.hpp": "gen_mpc_fwd_asm.py"}
 HASH_TU = "lu_api.hip"      # the translation unit that defines dmpc_source_hash()
 
 

@@ -10,6 +10,7 @@
 #include "box_ddp_kernels.hpp"
 #include "mpc_asm_kernel.hpp"
 #include "mpc_dma_kernels.hpp"
+#include "mpc_fwd_asm_kernel.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_kernels.hpp"
 
@@ -222,6 +223,17 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   // LinDx, whole wavefronts of four trajectories, 16-byte aligned runs: inputs through the LDS-DMA ring
   const bool fwd_dma = a.dyn_kind == 0 && a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
                        aligned16(a.C, a.c, a.F, a.f, a.Ks, a.ks, a.controls, a.lower, a.upper, a.states);
+  // the line search as one generated instruction stream (mpc_fwd_asm_kernel.hpp); DMPC_NO_MPC_ASM=1: the HIP kernels
+  if (fwd_dma && a.ls_cap > 0 && !mpc_asm_disabled()) {
+    const dim3 grid((a.B + 15) / 16), block(256);
+#define A(NX_, NU_)                                                                                          \
+  if (nx == NX_ && nu == NU_) {                                                                              \
+    hipLaunchKernelGGL((mpc_forward_asm_kernel<NX_, NU_>), grid, block, (mpc_fwd_asm_lds_bytes<NX_, NU_>()), stream, a); \
+    return (int)hipGetLastError();                                                                           \
+  }
+    A(8, 2) A(3, 1) A(4, 2) A(6, 2) A(2, 2) A(1, 1) A(2, 1) A(3, 2)
+#undef A
+  }
 #define X(NX_, NU_, L_)                                                                                      \
   if (nx == NX_ && nu == NU_) {                                                                              \
     constexpr int GPB = 256 / L_;                                                                            \
