@@ -32,6 +32,12 @@ from gen_lqr_asm import Prog, Regs, VBASE   # noqa: E402  (emitter with the haza
 OUT = os.path.join(HERE, "mpc_fwd_asm_gen.hpp")
 SHAPES = [(8, 2), (3, 1), (4, 2), (6, 2), (2, 2), (1, 1), (2, 1), (3, 2)]
 DB = 6        # ring depth == loop unroll (two alternating register sets)
+# timing experiments only (the results of such builds are wrong on purpose)
+X_NO_STORE = os.environ.get("GEN_FWD_NO_STORE") == "1"
+X_NO_DMA = os.environ.get("GEN_FWD_NO_DMA") == "1"
+X_NO_LDS = os.environ.get("GEN_FWD_NO_LDS") == "1"
+X_NO_COST = os.environ.get("GEN_FWD_NO_COST") == "1"
+X_NO_ADV = os.environ.get("GEN_FWD_NO_ADV") == "1"
 
 
 class FwdLayout:
@@ -80,7 +86,7 @@ def gen_fwd(nx, nu):
     assert last_vgpr <= 255
 
     S_N, S_TI, S_PASS, S_TMP = "s70", "s88", "s89", "s90"
-    S_CAP, S_WOBJ, S_UF = "s91", "s92", "s[94:95]"
+    S_CAP, S_WOBJ, S_UFW = "s91", "s92", "s93"
     S_XM, S_UM, S_SM, S_SRCH, S_ST, S_W, S_T0, S_ROW0 = ("s[72:73]", "s[74:75]", "s[76:77]", "s[78:79]", "s[80:81]",
                                                          "s[82:83]", "s[84:85]", "s[86:87]")
 
@@ -89,6 +95,7 @@ def gen_fwd(nx, nu):
         return m16 | (m16 << 16)
 
     uniq = [0]
+    in_body = [False]
 
     def issue_group(slot):
         if slot == 0:
@@ -98,13 +105,16 @@ def gen_fwd(nx, nu):
         P.raw("s_waitcnt lgkmcnt(0)")          # the wait state an LDS-DMA needs after the M0 write; the slot's reads are in
         for q in range(KD):
             off = (" offset:%d" % (q * 1024)) if q else ""
-            P.raw("global_load_lds_dwordx4 %s, off%s" % (v2(PTR[q]), off))
+            if not (X_NO_DMA and in_body[0]):
+                P.raw("global_load_lds_dwordx4 %s, off%s" % (v2(PTR[q]), off))
 
     slow = []   # (label, return label): the one advance of a pass that must leave the F / f lanes where they are
 
     def advance():
         """move the DMA pointers one timestep on while there is one: S_TI counts the advances left; the LAST one (to
         t = T-1) uses the strides that keep the F / f lanes on slice T-2 (there is no F_{T-1}) - out of line"""
+        if X_NO_ADV and in_body[0]:
+            return
         uniq[0] += 1
         n_ = uniq[0]
         P.raw("s_cmp_lt_i32 %s, 2" % S_TI)
@@ -126,6 +136,8 @@ def gen_fwd(nx, nu):
             P.raw("s_branch Ladv%d_%%=" % n_)
 
     def read_set(c, slot):
+        if X_NO_LDS and in_body[0]:
+            return
         S = sets[c]
         off = slot * L.SLOT_B
         if L.wide:
@@ -159,14 +171,19 @@ def gen_fwd(nx, nu):
         P.v("v_cmp_le_f32_e32 vcc, %s, %s" % (T1, T2), reads=(T1, T2))
         P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (U, U, bound), writes=(U,), reads=(U, bound))
 
-    def fstep(c, X, XN, j):
-        """one timestep from register set c: X holds [x_t | -] element per lane, XN receives [x_{t+1} | -]"""
+    def fstep(c, X, XN, j, objs, uf):
+        """one timestep from register set c: X holds [x_t | -] element per lane, XN receives [x_{t+1} | -].
+        objs / uf: this pass stores the per-step objective / the first pass's controls (known per pass: the body exists
+        once per combination, so that the counted wait below is exact - vmcnt counts the stores too, and a wait that
+        ignores them leaves the DMAs ~3 instead of DB - 1 steps of flight: the kernel then runs at the memory latency)"""
         S = sets[c]
         ROW, CROW, HAT = S["ROW"], S["CROW"], S["HAT"]
         o = 1 - c
         issue_group(j)                       # slot j went to registers one step ago: refill it, DB steps ahead
         advance()
-        P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * KD))
+        n_st = 1 + (1 if objs else 0) + (1 if uf else 0)
+        if not X_NO_DMA:
+            P.raw("s_waitcnt vmcnt(%d)" % min(63, (DB - 1) * (KD + n_st)))
         read_set(o, (j + 1) % DB)
         # controls: u = clamp(u^ + alpha k + K (x - x^))                                           mpc_step.py:209-221
         P.v("v_sub_f32_e32 %s, %s, %s" % (DX, X, HAT), writes=(DX,), reads=(X, HAT))
@@ -184,10 +201,14 @@ def gen_fwd(nx, nu):
         for m in range(nu):
             P.fmac_dpp(XN, TAU, ROW[nx + m], nx + m)                                                # u part
         # cost of the step and its difference to the iterate's                                      :246-251, util.py:162-198
+        if X_NO_COST:
+            ns_cost = 0
+        else:
+            ns_cost = ns
         P.v("v_sub_f32_e32 %s, %s, %s" % (D, TAU, HAT), writes=(D,), reads=(TAU, HAT))
         P.mul_dpp(Q1, TAU, CROW[0], 0)
         P.mul_dpp(QD, D, CROW[0], 0)
-        for jj in range(1, ns):          # two independent chains, interleaved
+        for jj in range(1, ns_cost):     # two independent chains, interleaved
             P.fmac_dpp(Q1, TAU, CROW[jj], jj)
             P.fmac_dpp(QD, D, CROW[jj], jj)
         P.v("v_fma_f32 %s, 0.5, %s, %s" % (LIN, Q1, S["CAFF"]), writes=(LIN,), reads=(Q1, S["CAFF"]))
@@ -201,30 +222,27 @@ def gen_fwd(nx, nu):
         P.v("v_fma_f32 %s, 0.5, %s, %s" % (T2, T2, S["CAFF"]), writes=(T2,), reads=(T2, S["CAFF"]))
         P.v("v_fmac_f32_e32 %s, %s, %s" % (OLDP, HAT, T2), writes=(OLDP,), reads=(HAT, T2, OLDP))
         # outputs of the trajectories that still search (the last pass that writes is the accepted one)
-        uniq[0] += 1
-        n_ = uniq[0]
-        P.raw("s_cmp_eq_u32 %s, 0" % S_WOBJ)
-        P.raw("s_cbranch_scc1 Lnoobj%d_%%=" % n_)
-        for rot in (8, 4, 2, 1):
-            P.valu("v_add_f32_dpp %s, %s, %s row_ror:%d row_mask:0xf bank_mask:0xf" % (OBJ, OBJ, OBJ, rot),
-                   writes=(OBJ,), reads=(OBJ,), dpp=OBJ)
-        P.raw("s_and_b64 exec, %s, %s" % (S_ROW0, S_SRCH))
-        P.raw("global_store_dword %s, %s, off" % (v2(POBJ), OBJ))
-        P.raw("s_mov_b64 exec, -1")
-        P.exec_written()
-        P.v("v_lshl_add_u64 %s, %s, 0, %%[dobj]" % (v2(POBJ), v2(POBJ)))
-        P.label("Lnoobj%d_%%=" % n_, reset=False)
+        if objs:
+            for rot in (8, 4, 2, 1):
+                P.valu("v_add_f32_dpp %s, %s, %s row_ror:%d row_mask:0xf bank_mask:0xf" % (OBJ, OBJ, OBJ, rot),
+                       writes=(OBJ,), reads=(OBJ,), dpp=OBJ)
+            P.raw("s_and_b64 exec, %s, %s" % (S_ROW0, S_SRCH))
+            if not X_NO_STORE:
+                P.raw("global_store_dword %s, %s, off" % (v2(POBJ), OBJ))
         P.raw("s_mov_b64 exec, %s" % S_ST)
-        P.raw("global_store_dword %s, %s, off" % (v2(PST), TAU))
-        P.raw("s_cmp_lg_u32 %s, 0" % S_PASS)
-        P.raw("s_cbranch_scc1 Lnouf%d_%%=" % n_)
-        P.raw("s_and_b64 exec, %s, %s" % (S_UM, S_UF))                                            # :260-263 (first pass)
-        P.raw("global_store_dword %s, %s, off" % (v2(PUF), TAU))
-        P.label("Lnouf%d_%%=" % n_, reset=False)
+        if not X_NO_STORE:
+            P.raw("global_store_dword %s, %s, off" % (v2(PST), TAU))
+        if uf:
+            P.raw("s_mov_b64 exec, %s" % S_UM)                                                     # :260-263 (first pass)
+            if not X_NO_STORE:
+                P.raw("global_store_dword %s, %s, off" % (v2(PUF), TAU))
         P.raw("s_mov_b64 exec, -1")
         P.exec_written()
+        if objs:
+            P.v("v_lshl_add_u64 %s, %s, 0, %%[dobj]" % (v2(POBJ), v2(POBJ)))
         P.v("v_lshl_add_u64 %s, %s, 0, %%[dst]" % (v2(PST), v2(PST)))
-        P.v("v_lshl_add_u64 %s, %s, 0, %%[dst]" % (v2(PUF), v2(PUF)))
+        if uf:
+            P.v("v_lshl_add_u64 %s, %s, 0, %%[dst]" % (v2(PUF), v2(PUF)))
 
     def row_sum(reg):
         for rot in (8, 4, 2, 1):
@@ -240,9 +258,8 @@ def gen_fwd(nx, nu):
     # (hipcc gives an inline-asm block only a handful of "s" operands: the rest come as VGPRs, same in every lane)
     P.raw("v_readfirstlane_b32 %s, %%[cap]" % S_CAP)
     P.raw("v_readfirstlane_b32 %s, %%[want_objs]" % S_WOBJ)
-    lo_uf = int(S_UF[2:S_UF.index(":")])
-    P.raw("v_readfirstlane_b32 s%d, %%[uf_mask]" % lo_uf)
-    P.raw("s_mov_b32 s%d, s%d" % (lo_uf + 1, lo_uf))
+    P.raw("v_readfirstlane_b32 %s, %%[uf_mask]" % S_UFW)
+    P.raw("s_and_b32 %s, %s, 1" % (S_UFW, S_UFW))
     P.v("v_mov_b32_e32 %s, 1.0" % ALPHA, writes=(ALPHA,))
     for r_ in (COST, OLD, NLS, WF):
         P.v("v_mov_b32_e32 %s, 0" % r_, writes=(r_,))
@@ -272,18 +289,42 @@ def gen_fwd(nx, nu):
     read_set(0, 0)
     P.raw("s_waitcnt lgkmcnt(0)")
     P.v("v_mov_b32_e32 %s, %s" % (XA, sets[0]["HAT"]), writes=(XA,), reads=(sets[0]["HAT"],))       # new_x[0] = states[0]   :198
-    P.label("Lstep_%=")
-    for j in range(DB):
-        c = j % 2
-        X, XN = (XA, XB) if c == 0 else (XB, XA)
-        P.comment("---- step, slot %d" % j)
-        fstep(c, X, XN, j)
-        P.raw("s_sub_i32 %s, %s, 1" % (S_N, S_N))
-        P.raw("s_cmp_lg_u32 %s, 0" % S_N)
-        if j < DB - 1:
-            P.raw("s_cbranch_scc0 Lpassend_%=")
-        else:
-            P.raw("s_cbranch_scc1 Lstep_%=")
+    # the body of the pass, once per combination of stores (see fstep)
+    P.raw("s_cmp_lg_u32 %s, 0" % S_PASS)
+    P.raw("s_cselect_b32 %s, 0, %s" % (S_TMP, S_UFW))          # u_first: first pass only, when wanted
+    P.raw("s_lshl_b32 s84, %s, 1" % S_WOBJ)                   # (s84: low half of the S_T0 pair, free here)
+    P.raw("s_or_b32 %s, %s, s84" % (S_TMP, S_TMP))
+    for idx in (1, 2, 3):
+        P.raw("s_cmp_eq_u32 %s, %d" % (S_TMP, idx))
+        P.raw("s_cbranch_scc1 Lbody%d_%%=" % idx)
+    for idx in (0, 1, 2, 3):
+        objs, uf = bool(idx & 2), bool(idx & 1)
+        P.label("Lbody%d_%%=" % idx)
+        # The counted wait of fstep assumes (DB - 1) steps' worth of stores behind the DMA group it waits for; the
+        # first steps of a pass have issued none yet, so that many stores are put into the queue here (x^_0 / u^_0 to
+        # the slots the first step overwrites, searching trajectories only): the count is then never too large.
+        n_st = 1 + (1 if objs else 0) + (1 if uf else 0)
+        P.raw("s_mov_b64 exec, %s" % S_ST)
+        for _ in range((DB - 1) * n_st):
+            P.raw("global_store_dword %s, %s, off" % (v2(PST), XA))
+        P.raw("s_mov_b64 exec, -1")
+        P.exec_written()
+        P.label("Lloop%d_%%=" % idx, reset=False)
+        in_body[0] = True
+        for j in range(DB):
+            c = j % 2
+            X, XN = (XA, XB) if c == 0 else (XB, XA)
+            P.comment("---- step, slot %d (objs %d, u_first %d)" % (j, objs, uf))
+            fstep(c, X, XN, j, objs, uf)
+            P.raw("s_sub_i32 %s, %s, 1" % (S_N, S_N))
+            P.raw("s_cmp_lg_u32 %s, 0" % S_N)
+            if j < DB - 1:
+                P.raw("s_cbranch_scc0 Lpassend_%=")
+            else:
+                P.raw("s_cbranch_scc1 Lloop%d_%%=" % idx)
+        in_body[0] = False
+        if idx < 3:
+            P.raw("s_branch Lpassend_%=")
     P.label("Lpassend_%=")
     P.raw("s_waitcnt vmcnt(0) lgkmcnt(0)")       # the ring is refilled from t = 0 by the next pass
     row_sum(COSTP)
