@@ -300,6 +300,45 @@ def test_device_loop_matches_host_loop_pendulum_other_batches(B):
     assert_close(dev_[2], host[2], 1e-5, "costs")
 
 
+def test_device_loop_matches_host_loop_pendulum_long_horizon():
+    """T = 40: past the horizon the wavefront-per-trajectory line search keeps in LDS - the lane-per-candidate kernel
+    with its LDS-DMA ring runs (both loops)"""
+    B, T = 32, 40
+    dx, x0, Q, pv = pendulum_problem(B, T, seed=6)
+    kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter)
+    dev_, host = _run_both(
+        lambda dl: BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, max_iter=3, exit_unconverged=False, quiet=True,
+                          device_loop=dl, **kw),
+        lambda: (dev(x0), QuadCost(dev(Q), dev(pv)), dx))
+    assert dev_[3] == host[3] and dev_[4] == host[4], (dev_[3:], host[3:])
+    assert_close(dev_[1], host[1], 1e-5, "u")
+    assert_close(dev_[0], host[0], 1e-5, "x")
+    assert_close(dev_[2], host[2], 1e-5, "costs")
+    # one iLQR step of that kernel pair against the oracle (from the zero-control iterate)
+    lo, hi = np.full((T, B, 1), dx.lower), np.full((T, B, 1), dx.upper)
+    uk = np.zeros((T, B, 1))
+    xk = obox.get_traj(T, uk, x0, obox.pendulum_step)
+    Fm, fm = obox.pendulum_linearize(xk, uk)
+    cost_o = ompc.QuadCost(Q, pv)
+    xo, uo, _, fo, Ko, ko = ompc.mpc_forward(Q, pv, Fm, fm, uk, xk, lo, hi, cost_o, obox.pendulum_step, dx.linesearch_decay,
+                                             dx.max_linesearch_iter, T, 3, 1, need_expand=True, batch_coupled=False)
+    with torch.no_grad():
+        ud = dev(uk)
+        xd, Fd, fd = dx.rollout_linearize(dev(x0), ud)
+        step = MPCstep(controls=ud, T=T, u_upper=dev(hi), u_lower=dev(lo), n_batch=B, n_state=3, n_ctrl=1,
+                       current_states=xd, true_cost=QuadCost(dev(Q), dev(pv)), true_dynamics=dx,
+                       ls_decay=dx.linesearch_decay, max_ls_iter=dx.max_linesearch_iter, need_expand=True)
+        xn, un = step.forward((xd[0], dev(Q), dev(pv), Fd, fd))
+    old = ompc.get_cost(T, uk, cost_o, xk)
+
+    def candidates(rows, alpha):
+        xc, uc, _ = ompc.ls_rollout(Ko[:, rows], ko[:, rows], uk[:, rows], xk[:, rows], lo[:, rows], hi[:, rows],
+                                    ompc.QuadCost(Q[:, rows], pv[:, rows]), obox.pendulum_step, np.full(len(rows), alpha), T)
+        return xc, uc
+
+    assert_step_close(npy(un), npy(xn), uo, xo, old, fo.costs, candidates, 2e-4, "step at T = 40")
+
+
 @pytest.mark.parametrize("shape", [(16, 8, 3, 2, 0.3), (64, 12, 8, 2, 0.5), (5, 6, 4, 2, 10.0), (12, 6, 5, 3, 0.5)])
 def test_device_loop_matches_host_loop_lindx(shape):
     # the nominal rollout is a kernel here and torch ops there: rounding differs, the iteration amplifies it
