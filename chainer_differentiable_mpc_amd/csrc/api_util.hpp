@@ -10,4 +10,12 @@ static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t
 
 static constexpr size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// What this library launched last (a hint, not a synchronisation: plain reads and writes).  The headline solve exists
+// in two forms, a three-step loop and a sweep unrolled over the horizon (75 KB of straight-line code, ~3 % faster when
+// its code is still on chip, 4-5 us slower when other kernels ran in between - scripts/unroll_ab.sh): the unrolled
+// form is taken when the previous launch was the same solve.
+enum { kLaunchOther = 0, kLaunchPlainSolve = 1 };
+inline int g_last_launch = kLaunchOther;
+static inline void note_other_launch() { g_last_launch = kLaunchOther; }
+
 }  // namespace dmpc

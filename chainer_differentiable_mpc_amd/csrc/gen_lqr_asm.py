@@ -57,11 +57,17 @@ X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by 
 MFMA_USE = int(os.environ.get("GEN_MFMA_USE", "5"))     # wait states kept before a non-accumulating use of an MFMA result
 MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
 X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
-# Stash variants of (8,2): the backward sweep unrolled over the horizon (NSTASH steps, one exit test each), so that the F
-# block of a step goes to its accumulation registers by reads emitted in place - the table of per-step stubs, called by
-# s_setpc_b64 and left by s_branch, cost ~65 of a step's ~880 cycles (32.9 -> 31.3 us at B=4096 T=50; the stream grows
-# to ~75 KB, and wavefronts of a CU run it close enough to lock step for the instruction cache).  GEN_UNROLL_BWD=0: the loop.
+# A second form of the headline stream ((8,2), stash, no gains out): the backward sweep unrolled over the horizon (NSTASH
+# steps, one exit test each), so that the F block of a step goes to its accumulation registers by reads emitted in place -
+# the table of per-step stubs, called by s_setpc_b64 and left by s_branch, costs ~65 of a step's ~880 cycles.  75 KB of
+# straight-line code: 1-3 % faster than the loop when launched back to back, 4-5 us SLOWER per solve when other kernels
+# run in between (DiffLqr's forward + backward loop; scripts/unroll_ab.sh) - the launcher picks (api_util.hpp).
+# GEN_UNROLL_BWD=0: do not generate it.
 X_UNROLL_BWD = os.environ.get("GEN_UNROLL_BWD", "1") == "1"
+# Experiment: the prologue of the unrolled stream touches the stream's own code with 20 loads (64 lanes x one 64-byte
+# line each, clamped to the stream's end) so that the lines are in L2 before the fetcher asks for them.
+X_CODE_PREFETCH = os.environ.get("GEN_CODE_PREFETCH", "0") == "1"   # measured: makes both cases worse (+1.5 us); off
+N_CODE_PREFETCH = 20
 USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
 
 
@@ -225,7 +231,7 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
+def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, unroll=False):
     """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
     is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
     rollout needs no change); the value update keeps the unmasked blocks (:143-145).
@@ -241,6 +247,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
     L = Layout(nx, nu)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
+    unroll_bwd = unroll
+    assert not unroll or (stash and not mpc)
     assert not mpc or (masked and write_k and not stash)
     assert not expand or (mpc and 12 * nu + 4 * nx <= 64)
     P = Prog()
@@ -279,6 +287,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
     NQP = R.take(1)[0] if mpc else None                       # sum over t of the QP passes run          (mpc_step.py:145)
     QINFO = R.take(1)[0] if mpc else None                     # 4 once a QP ran into the iteration cap
     TAU = R.take(3) if expand else None                       # expand: lane j < ns of set s holds [x_t; u_t][j]
+    PFD = R.take(1)[0] if unroll_bwd and X_CODE_PREFETCH else None   # destination of the code-prefetch loads (never read)
     Am = [R.take(nu) for _ in range(nu)] if masked else None   # masked Quu
     Rm = R.take(nu) if masked else None                        # masked right-hand side rows
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
@@ -797,6 +806,20 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
             P.raw("global_load_lds_dwordx4 %s, off" % fp[q])
     P.raw("global_load_dword %s, %%[pxi], off" % XV0)
     n_extra += 1
+    if PFD is not None:
+        P.raw("s_getpc_b64 " + S_JMP)            # (the forward sweep sets S_JMP up again for its own use)
+        P.label("Lpf_%=", reset=False)
+        P.v("v_mbcnt_lo_u32_b32 %s, -1, 0" % tP, writes=(tP,))
+        P.v("v_mbcnt_hi_u32_b32 %s, -1, %s" % (tP, tP), writes=(tP,), reads=(tP,))
+        P.v("v_lshlrev_b32_e32 %s, 6, %s" % (tP, tP), writes=(tP,), reads=(tP,))
+        for k in range(N_CODE_PREFETCH):
+            if k:
+                P.v("v_add_u32_e32 %s, 0x%x, %s" % (tPQ, k * 4096, tP), writes=(tPQ,), reads=(tP,))
+            else:
+                P.v("v_mov_b32_e32 %s, %s" % (tPQ, tP), writes=(tPQ,), reads=(tP,))
+            P.v("v_min_u32_e32 %s, Lcode_end_%%=-Lpf_%%=-4, %s" % (tPQ, tPQ), writes=(tPQ,), reads=(tPQ,))
+            P.raw("global_load_dword %s, %s, %s" % (PFD, tPQ, S_JMP))
+        n_extra += N_CODE_PREFETCH
     # zero this wave's gain rows while the first slots are in flight (columns nx..ns-1 and the pad of every row
     # are never written afterwards; the region is padded to whole 1 KB pieces by lqr_asm_kernel.hpp)
     if not mpc:
@@ -825,7 +848,6 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
     P.comment("---- t = T-1")
     stamp(1)
-    unroll_bwd = X_UNROLL_BWD and stash and (nx, nu) == (8, 2)
     bstep(0, True, n_extra, stub_n=1 if unroll_bwd else None)
     if X_SKIP_BWD:
         P.raw("s_branch Lbwd_done_%=")
@@ -1074,6 +1096,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
     stamp(3)
     for i in range(len(TS)):
         P.v("v_mov_b32_e32 %%[ts%d], %s" % (i, TS[i]))
+    if PFD is not None:
+        P.label("Lcode_end_%=", reset=False)
 
     # ---- operand lists
     outs = [("xvout", '"=&v"(xvout)'), ("minpiv", '"=&v"(minpiv)')]
@@ -1126,7 +1150,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False):
         ['"s%d"' % i for i in ([70] + list(range(72, 102 if mpc else 98)))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
-    name = "LqrAsm<%d, %d, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked))
+    name = "LqrAsm<%d, %d, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(unroll))
     if mpc:
         name = "MpcAsm<%d, %d, %s>" % (nx, nu, tf(expand))
     o = []
@@ -1212,7 +1236,8 @@ struct LqrAsmIn {
   unsigned ts[4];                    // GEN_TIMING builds only: s_memtime at the phase boundaries
 };
 
-template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false>
+// UNROLL: the backward sweep unrolled over the horizon (no per-step stash stubs), generated for the headline shape only
+template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false>
 struct LqrAsm {
   static constexpr bool kAvailable = false;
 };
@@ -1240,6 +1265,8 @@ def main():
                 if stash and not L0.stash_ok:
                     continue
                 out.append(gen_kernel(nx, nu, write_k, stash))
+                if X_UNROLL_BWD and stash and not write_k and (nx, nu) == (8, 2):
+                    out.append(gen_kernel(nx, nu, write_k, stash, unroll=True))
                 if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding
                     out.append(gen_kernel(nx, nu, write_k, stash, masked=True))
                 if write_k and not stash and L0.SLOT_B - 16 * L0.nchunk_b >= 256:

@@ -103,6 +103,7 @@ int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float 
                       const float *x, const float *u, const float *grad_x, const float *grad_u,
                       int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws,
                       size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !F || !x || !u || !grad_x || !grad_u || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(dC) || !aligned16(dF)) return DMPC_E_BADARG;

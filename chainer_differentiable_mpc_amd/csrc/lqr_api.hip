@@ -37,6 +37,11 @@ static bool wave_mfma_disabled() {  // DMPC_NO_WAVE_MFMA=1: large shapes on the 
   static const bool off = [] { const char *e = getenv("DMPC_NO_WAVE_MFMA"); return e && e[0] == '1'; }();
   return off;
 }
+static int g_before_this_solve = kLaunchOther;   // g_last_launch as dmpc_lqr_solve found it
+static bool unroll_disabled() {  // DMPC_NO_UNROLL=1: always the three-step loop form of the headline stream (A/B timing)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_UNROLL"); return e && e[0] == '1'; }();
+  return off;
+}
 static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
   static const bool off = [] { const char *e = getenv("DMPC_NO_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -124,6 +129,17 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
     else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, STASH>), g, block, shmem, stream, a);           \
     return (int)hipGetLastError();                                                                               \
   } while (0)
+      if constexpr (LqrAsm<NX, NU, false, true, false, true>::kAvailable) {
+        // the plain solve launched back to back: the sweep unrolled over the horizon (api_util.hpp: g_last_launch)
+        if (path == 4 && has_f && !write_k) {
+          const bool hot = g_before_this_solve == kLaunchPlainSolve && !unroll_disabled();
+          g_last_launch = kLaunchPlainSolve;
+          const size_t shmem = lqr_asm_lds_bytes<NX, NU, true>(a.T);
+          if (hot) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, true, false, true>), g, block, shmem, stream, a);
+          else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, true>), g, block, shmem, stream, a);
+          return (int)hipGetLastError();
+        }
+      }
       if constexpr (LqrAsm<NX, NU, false, true>::kAvailable) {
         if (path == 4) DMPC_ASM_LAUNCH(true);
       }
@@ -246,12 +262,15 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
     a.wsK = static_cast<float *>(ws);
     a.wsk = a.wsK + (size_t)T * B * nu * nx;
   }
+  g_before_this_solve = g_last_launch;
+  g_last_launch = kLaunchOther;          // (launch_lqr sets kLaunchPlainSolve when it takes the plain stash solve)
   return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
 }
 
 int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                             const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
                             int32_t *info, dmpc_stream_t stream) {
+  note_other_launch();
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !Ks_out || !ks_out || (T > 1 && !F)) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;
@@ -262,6 +281,7 @@ int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const 
 int dmpc_lqr_forward_sweep(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *F,
                            const float *f, const float *x_init, const uint8_t *u_zero_mask, float *x_out,
                            float *u_out, int32_t *info, dmpc_stream_t stream) {
+  note_other_launch();
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!Ks || !ks || !x_init || !x_out || !u_out || (T > 1 && !F)) return DMPC_E_BADARG;
   if (!aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;

@@ -97,9 +97,9 @@ __device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsi
 // MASKED: LQR_active (mpc/active_constrained_lqr.py) - a.mask [T,B,nu] uint8 marks the clamped controls; needs
 // B * nu to be a multiple of 4 (the flags of a wave's four trajectories are fetched as whole dwords).
 // a.x == nullptr: backward sweep only (LqrRecursion.backward(), gains to a.Ks / a.ks - WRITE_K).
-template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false>
+template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
-  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED>;
+  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, UNROLL>;
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU, AFF = NS, KROW = G::KROW;
   constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)

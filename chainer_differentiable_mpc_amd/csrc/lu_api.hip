@@ -138,6 +138,7 @@ const char *dmpc_source_hash(void) { return DMPC_SOURCE_HASH; }
 
 int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, int32_t *info,
                          dmpc_stream_t stream_) {
+  note_other_launch();
   if (B <= 0 || n <= 0 || !A || !LU || !piv) return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const dim3 block(256), grid((B + 255) / 256);
@@ -155,6 +156,7 @@ int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, 
 
 int dmpc_batch_lu_solve(int B, int n, int k, const float *LU, const int32_t *piv, const float *b, float *x,
                         dmpc_stream_t stream_) {
+  note_other_launch();
   if (B <= 0 || n <= 0 || k <= 0 || !LU || !piv || !b || !x) return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int total = B * k;

@@ -339,6 +339,7 @@ size_t dmpc_coupled_workspace_bytes(int T, int n_qp_iter_max) {
 int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
               const float *x_init, int n_iter, int batch_coupled, float *x, float *fac, int32_t *piv, float *index_f,
               int32_t *n_iter_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+  note_other_launch();
   if (B <= 0 || n <= 0 || n_iter <= 0 || !H || !q || !lower || !upper || !x || !fac || !index_f || !n_iter_out)
     return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -370,6 +371,7 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
                           const float *u_upper, int n_qp_iter_max, int batch_coupled, float *Ks_out, float *ks_out,
                           int32_t *n_qp_iter, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (!C_hat || !c_hat || !F_hat || !controls || !u_lower || !u_upper || !Ks_out || !ks_out || !n_qp_iter)
     return DMPC_E_BADARG;
@@ -386,6 +388,7 @@ int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const fl
                          int max_ls_iter, float *x_out, float *u_out, float *costs, float *old_costs,
                          float *alphas, float *objs, float *u_first, int32_t *n_ls_iter, int32_t *info,
                          dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!Ks || !ks || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true || !x_out ||
       !u_out || !costs || !alphas || !n_ls_iter)
@@ -402,6 +405,7 @@ int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks
                                   float max_torque, float ls_decay, int max_ls_iter, float *x_out, float *u_out,
                                   float *costs, float *old_costs, float *alphas, float *objs, float *u_first,
                                   int32_t *n_ls_iter, int32_t *info, dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0) return DMPC_E_BADARG;
   if (!Ks || !ks || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !x_out || !u_out || !costs ||
       !alphas || !n_ls_iter)
@@ -416,6 +420,7 @@ int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks
 int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const float *u, float g, float m, float l,
                                     float dt, float max_torque, float *x_out, float *F_out, float *f_out,
                                     dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 0 || B <= 0 || !x_init || !u || !x_out) return DMPC_E_BADARG;
   if (f_out != nullptr && F_out == nullptr) return DMPC_E_BADARG;
   PendulumArgs pa{T, B, x_init, u, g, m, l, dt, max_torque, x_out, F_out, f_out};
@@ -437,6 +442,7 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                           float *Ks_out, float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
                           float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
                           int32_t *info, dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (batch_coupled && n_qp_iter_max > kSyncQpIterMax) return DMPC_E_UNSUPPORTED;
   if (!C_hat || !c_hat || !F_hat || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true ||
@@ -464,6 +470,7 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
 
 int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const float *u, const float *F,
                      const float *f, float *x_out, dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0 || !x_init || !u || !x_out || (T > 1 && !F)) return DMPC_E_BADARG;
   hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), T, B, nx,
                      nu, x_init, u, F, f, x_out, nullptr, ChainClear{});
@@ -481,6 +488,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
                  float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, int batch_coupled,
                  float *x_best, float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last,
                  int32_t *state, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || max_iter <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (batch_coupled && n_qp_iter_max > kSyncQpIterMax) return DMPC_E_UNSUPPORTED;
   if (!x_init || !C || !c || !u_init || !u_lower || !u_upper || !x_best || !u_best || !costs_best || !du_norm_best ||
@@ -586,6 +594,7 @@ int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, con
                            const float *u_upper, const float *grad_x, const float *grad_u, float *d_x_init,
                            float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
                            dmpc_stream_t stream_) {
+  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C_hat || !c_hat || !F_hat || !x || !u || !u_lower || !u_upper || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(dC) || !aligned16(dF))
