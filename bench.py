@@ -82,11 +82,15 @@ def kernel_name(T, B, nx, nu):
     """the kernel dmpc_lqr_solve dispatches to at this size (what rocprofv3 --kernel-trace lists)"""
     from chainer_differentiable_mpc_amd import _lib
     path = _lib.load().dmpc_lqr_solve_path(T, B, nx, nu)
-    # template arguments as rocprofv3 prints them: <nx, nu, has_f, write_k, stash, masked>; the bench passes f, no gains
+    # template arguments as rocprofv3 prints them: <nx, nu, has_f, write_k, stash, masked, unroll>; the bench passes f, no
+    # gains.  Back-to-back solves of the headline shape take the stream's unrolled form (csrc/api_util.hpp).
+    import os
+    if path == 4 and (nx, nu) == (8, 2) and os.environ.get("DMPC_NO_UNROLL") != "1":
+        return "void dmpc::lqr_asm_kernel<8, 2, true, false, true, false, true>(dmpc::LqrArgs)"
     return {0: "dmpc::lqr_generic_kernel", 1: "void dmpc::lqr_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
             2: "void dmpc::lqr_dma_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
-            3: "void dmpc::lqr_asm_kernel<%d, %d, true, false, false, false>(dmpc::LqrArgs)" % (nx, nu),
-            4: "void dmpc::lqr_asm_kernel<%d, %d, true, false, true, false>(dmpc::LqrArgs)" % (nx, nu),
+            3: "void dmpc::lqr_asm_kernel<%d, %d, true, false, false, false, false>(dmpc::LqrArgs)" % (nx, nu),
+            4: "void dmpc::lqr_asm_kernel<%d, %d, true, false, true, false, false>(dmpc::LqrArgs)" % (nx, nu),
             5: "void dmpc::lqr_wave_mfma_backward<%d, %d, false, true>(dmpc::LqrArgs)" % (nx, nu)
             }.get(path, "?")
 
