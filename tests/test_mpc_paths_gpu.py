@@ -48,7 +48,17 @@ CASES = [
     pytest.param(4, 2, 3, 1, 0.5, True, id="stream-shortest-horizon-3-1"),
     pytest.param(4, 3, 8, 2, 0.25, False, id="stream-three-steps-8-2"),
     pytest.param(4, 4, 8, 2, 0.25, True, id="stream-four-steps-8-2"),
-    pytest.param(8, 7, 6, 2, 0.25, True, id="dma-ring-6-2"),
+    pytest.param(4, 7, 4, 2, 0.25, True, id="stream-recentring-4-2"),
+    pytest.param(8, 6, 4, 2, 0.25, False, id="stream-with-f-4-2"),
+    pytest.param(4, 6, 2, 2, 0.375, True, id="stream-recentring-2-2"),
+    pytest.param(4, 5, 2, 2, 0.375, False, id="stream-with-f-2-2"),
+    pytest.param(8, 6, 1, 1, 0.5, True, id="stream-recentring-1-1"),
+    pytest.param(4, 6, 1, 1, 0.5, False, id="stream-with-f-1-1"),
+    pytest.param(4, 7, 2, 1, 0.5, True, id="stream-recentring-2-1"),
+    pytest.param(4, 7, 2, 1, 0.5, False, id="stream-with-f-2-1"),
+    pytest.param(8, 5, 3, 2, 0.375, True, id="stream-recentring-3-2"),
+    pytest.param(8, 7, 6, 2, 0.25, True, id="dma-ring-sweep-stream-search-6-2"),
+    pytest.param(4, 6, 6, 2, 0.25, False, id="dma-ring-sweep-stream-search-with-f-6-2"),
     pytest.param(4, 6, 4, 4, 0.375, False, id="dma-ring-4-4"),
     pytest.param(8, 6, 8, 4, 0.25, True, id="dma-ring-8-4"),
     pytest.param(4, 5, 12, 3, 0.25, True, id="dma-ring-12-3"),
