@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DMPC_VERSION 200 /* 0.2.0: batch_coupled PNQP / MPC step */
+#define DMPC_VERSION 201 /* 0.2.1: dmpc_box_ddp clears info itself and reports its input checks in state[4:8] */
 
 #define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
 #define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */
