@@ -131,3 +131,95 @@ def test_the_kernel_families_agree_with_each_other(tmp_path, need_expand):
         assert int(o["nqp"]) == int(ref["nqp"]), (name, int(o["nqp"]), int(ref["nqp"]))
     np.testing.assert_array_equal(outs["dma"]["Ks"], ref["Ks"])          # the two HIP families: the same arithmetic
     np.testing.assert_array_equal(outs["dma"]["u"], ref["u"])
+
+
+_RUNNER_LS = r"""
+import sys, warnings
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost
+from tests.test_mpc_paths_gpu import problem, dev
+B, T, nx, nu, bound = 32, 9, 8, 2, 0.5
+p, lo, hi, u0, x0 = problem(B, T, nx, nu, bound, seed=9)
+rng = np.random.RandomState(3)
+# gains that are NOT descent directions for most trajectories: the search walks many step sizes (some to the cap)
+Ks = 0.6 * rng.standard_normal((T, B, nu, nx))
+ks = 0.8 * rng.standard_normal((T, B, nu))
+ks[:, ::4] = 0.0
+Ks[:, ::4] *= 0.02
+step = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(p["C"]), dev(p["c"])),
+               LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=True)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    x, u, fo = step.forward_rec(dev(Ks), dev(ks), step.true_cost, step.true_dynamics, 0.2, 5)
+np.savez(sys.argv[2], x=x.cpu().numpy(), u=u.cpu().numpy(), costs=fo.costs.cpu().numpy(), objs=fo.objs.cpu().numpy(),
+         alphas=step.alphas.cpu().numpy(), nls=step.n_ls_iter.cpu().numpy(), du=fo.full_du_norm.cpu().numpy())
+"""
+
+
+def test_long_line_searches_agree_between_the_families(tmp_path):
+    """forward_rec with gains that are not descent directions: most trajectories walk many step sizes, the wavefronts
+    of the stream run their pass loop with some rows finished and others still searching.  Stream against the
+    register-bank HIP kernel: the same pass counts and step sizes, trajectories to 2e-5, and the oracle on top."""
+    outs = {}
+    for name, env in (("stream", {}), ("banks", {"DMPC_NO_MPC_ASM": "1", "DMPC_NO_MPC_DMA": "1"})):
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _RUNNER_LS, ROOT, out], env=dict(os.environ, **env), cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    a, b = outs["stream"], outs["banks"]
+    assert int(b["nls"].max()) >= 8 and len(np.unique(b["nls"])) >= 3      # long and ragged searches
+    np.testing.assert_array_equal(a["nls"], b["nls"])
+    np.testing.assert_array_equal(a["alphas"], b["alphas"])
+    for key in ("x", "u", "costs", "objs", "du"):
+        assert_close(a[key], b[key], 2e-5, key)
+
+
+_RUNNER_QP = r"""
+import sys, warnings
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost
+from tests.test_mpc_paths_gpu import problem, dev
+B, T, nx, nu, bound = 64, 12, 8, 2, 0.05
+p, lo, hi, u0, x0 = problem(B, T, nx, nu, bound, seed=21)
+rng = np.random.RandomState(4)
+C = p["C"].copy()
+# strongly coupled controls and large linear terms: clamped sets change from step to step, the QP takes several
+# passes and its Armijo search more than one trial
+C[..., nx:, nx:] = np.array([[1.0, 0.97], [0.97, 1.0]]) * rng.uniform(0.3, 3.0, (T, B, 1, 1))
+c = p["c"] + 2.0 * rng.standard_normal(p["c"].shape)
+step = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(C), dev(c)),
+               LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=False)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    Ks, ks, bo = step.backward_rec(dev(C), dev(c), dev(p["F"]), dev(p["f"]))
+np.savez(sys.argv[2], Ks=Ks.cpu().numpy(), ks=ks.cpu().numpy(), nqp=step.n_qp_iter.cpu().numpy(), C=C, c=c)
+"""
+
+
+def test_hard_box_qps_agree_between_the_families_and_with_the_oracle(tmp_path):
+    """backward_rec on a problem whose box QPs take several passes (coupled controls, tight bounds, large linear terms):
+    the stream's in-line projected Newton against the HIP kernels' (same pass totals per trajectory, same clamped
+    sets) and against the numpy oracle"""
+    outs = {}
+    for name, env in (("stream", {}), ("banks", {"DMPC_NO_MPC_ASM": "1", "DMPC_NO_MPC_DMA": "1"})):
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _RUNNER_QP, ROOT, out], env=dict(os.environ, **env), cwd=ROOT,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    a, b = outs["stream"], outs["banks"]
+    T, B = a["ks"].shape[:2]
+    assert b["nqp"].mean() > 2.0 * T and b["nqp"].max() >= 2.4 * T      # more than two passes per QP on average
+    assert np.mean(a["nqp"] == b["nqp"]) > 0.95           # a pass more or less only where a test sits on its threshold
+    assert np.abs(a["nqp"].astype(int) - b["nqp"].astype(int)).max() <= 2
+    np.testing.assert_array_equal(a["Ks"] == 0, b["Ks"] == 0)
+    assert_close(a["ks"], b["ks"], 5e-5, "ks")
+    assert_close(a["Ks"], b["Ks"], 5e-5, "Ks")
+    p, lo, hi, u0, x0 = problem(B, T, 8, 2, 0.05, seed=21)
+    Ksr, ksr, bo, Ifree = ompc.mpc_backward_rec(a["C"], a["c"], p["F"], p["f"], u0, lo, hi, T, 8, 2, batch_coupled=False)
+    assert_close(a["ks"], ksr, TOL, "ks vs oracle")
+    assert_close(a["Ks"], Ksr, TOL, "Ks vs oracle")
+    assert np.all(a["Ks"][Ifree == 0] == 0) and (Ifree == 0).mean() > 0.2
