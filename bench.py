@@ -256,9 +256,17 @@ def secondary_metrics(device, d_headline):
         assert rc == 0, rc
 
     t = event_time(mpc_fwd, 30)
+    # algorithmic bytes per timestep: the sweep reads C, c, F, u, lower, upper, x (re-centring) and writes K, k; every
+    # line-search pass reads C, c, F, f, K, k, u, lower, upper, x and writes x, u (+ objs, u_first on the first pass)
+    ns = nx + nu
+    passes = float(nls.float().mean())
+    sweep_b = 4 * (ns * ns + ns + nx * ns + 3 * nu + nx) + 4 * (nu * nx + nu)
+    pass_b = 4 * (ns * ns + ns + nx * ns + nx + nu * nx + 4 * nu + nx) + 4 * ns
+    mpc_bytes = B * T * (sweep_b + passes * pass_b + 4 * (1 + nu))
     out["mpc_step_forward_cfg3"] = {"what": "MPCstep.forward (Taylor re-centring, backward_rec with one PNQP per timestep, "
                                             "line search) B=4096 T=50 (8,2), bounds +-0.5", "us": t * 1e6,
-                                    "timestep_solves_per_s": B * T / t}
+                                    "timestep_solves_per_s": B * T / t, "line_search_passes_mean": passes,
+                                    "algorithmic_bytes": int(mpc_bytes), "frac_hbm": mpc_bytes / t / 1e9 / HBM_PEAK_GBS}
     del ws, Ks, ks, xo, uo, u1, objs
     # (iv) config 2: pendulum box-DDP, B=128, T=20, 10 iLQR iterations; (v) config 4: imitation step at B=1024
     dx = PendulumDx()
