@@ -371,7 +371,8 @@ def gen_fwd(nx, nu):
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"s%d"' % i for i in ([70] + list(range(72, 96)))] + \
         ['"vcc"', '"scc"', '"memory"']
     o = []
-    o.append("// (%d,%d): %d instructions (%d per unrolled group of %d steps)\n" % (nx, nu, P.n_instr, 0, DB))
+    o.append("// (%d,%d): %d instructions: set-up, pass prologue and epilogue, four pass bodies of %d unrolled steps\n"
+             % (nx, nu, P.n_instr, DB))
     o.append("template <>\nstruct MpcFwdAsm<%d, %d> {\n" % (nx, nu))
     o.append("  static constexpr bool kAvailable = true;\n")
     o.append("  static constexpr int KD = %d, SLOT_B = %d, DEPTH = %d, RING_BYTES = %d, ZERO = %d;\n"

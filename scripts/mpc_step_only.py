@@ -2,7 +2,7 @@
 and for the generator's timing knobs (GEN_FWD_NO_* builds of mpc_fwd_asm_gen.hpp give wrong results on purpose)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost, synthetic, util
 dev = torch.device("cuda")
 B, T, nx, nu, bound = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (4096, 50, 8, 2) + (0,)
