@@ -193,6 +193,18 @@ static bool spec_line_search_disabled() {  // DMPC_NO_SPEC_LS=1: sequential line
   return off;
 }
 
+static bool spec4_disabled_early() {  // (DMPC_NO_SPEC4 also selects the lane-per-trajectory rollout)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_SPEC4"); return e && e[0] == '1'; }();
+  return off;
+}
+// rollout + linearisation of the built-in pendulum: four lanes per trajectory when the 16-byte row accesses are aligned
+static void launch_pendulum_rollout(const PendulumArgs &pa, hipStream_t stream) {
+  if (aligned16(pa.F, pa.C) && !spec4_disabled_early())
+    hipLaunchKernelGGL(pendulum_rollout_linearize4_kernel, dim3((4 * pa.B + 255) / 256), dim3(256), 0, stream, pa);
+  else
+    hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((pa.B + 63) / 64), dim3(64), 0, stream, pa);
+}
+
 static bool spec4_disabled() {  // DMPC_NO_SPEC4=1: the lane-per-candidate speculative search (A/B timing, longer horizons' path)
   static const bool off = [] { const char *e = getenv("DMPC_NO_SPEC4"); return e && e[0] == '1'; }();
   return off;
@@ -424,8 +436,7 @@ int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const flo
   if (T <= 0 || B <= 0 || !x_init || !u || !x_out) return DMPC_E_BADARG;
   if (f_out != nullptr && F_out == nullptr) return DMPC_E_BADARG;
   PendulumArgs pa{T, B, x_init, u, g, m, l, dt, max_torque, x_out, F_out, f_out};
-  hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0,
-                     static_cast<hipStream_t>(stream_), pa);
+  launch_pendulum_rollout(pa, static_cast<hipStream_t>(stream_));
   return (int)hipGetLastError();
 }
 
@@ -537,7 +548,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
       if (it == 0 || !fuse_lin) {
         PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs_it, fp(w.F), fp(w.f), it == 0 ? nullptr : done, C, c,
                         c_back, it == 0 ? clear : ChainClear{}};
-        hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, pa);
+        launch_pendulum_rollout(pa, stream);
       }
     } else {
       hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,

@@ -1277,6 +1277,76 @@ __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const Pe
   pendulum_rollout_linearize_body(a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// The same with four lanes per trajectory (needs 16-byte aligned F, C): the rollout is a chain of T dependent steps on
+// B / 64 wavefronts, so its time is the instructions of a step - the four lanes repeat the state update and split
+// what has rows: lane `sub` stores x_t[sub], row `sub` of F_t (one 16-byte store) with f_t[sub], and row `sub` of the
+// re-centred cost.  Same values as pendulum_jacobian_store.
+__global__ __launch_bounds__(256) void pendulum_rollout_linearize4_kernel(const PendulumArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  a.clear.run(g);
+  const int b = g >> 2, sub = g & 3;
+  if (b >= a.B) return;
+  if (a.done != nullptr && *a.done != 0) return;
+  const size_t B = (size_t)a.B;
+  float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
+  const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque);
+  const bool taylor = a.c_back != nullptr;
+  const unsigned m0 = sub == 0 ? ~0u : 0u, m1 = sub == 1 ? ~0u : 0u, m2 = sub == 2 ? ~0u : 0u, m3 = sub == 3 ? ~0u : 0u;
+  auto pick4 = [&](float e0, float e1, float e2, float e3) {   // element `sub` (bit masks: no exec-mask branches)
+    const unsigned r = (__builtin_bit_cast(unsigned, e0) & m0) | (__builtin_bit_cast(unsigned, e1) & m1) |
+                       (__builtin_bit_cast(unsigned, e2) & m2) | (__builtin_bit_cast(unsigned, e3) & m3);
+    return __builtin_bit_cast(float, r);
+  };
+  // the inputs of step t + 1 are fetched while step t computes
+  float u_nx = a.u[b], c_nx = 0.f;
+  float4 C_nx = {0.f, 0.f, 0.f, 0.f};
+  if (taylor) {
+    C_nx = *reinterpret_cast<const float4 *>(a.C + ((size_t)b * 4 + sub) * 4);
+    c_nx = a.c[(size_t)b * 4 + sub];
+  }
+  for (int t = 0; t < a.T; ++t) {
+    const size_t tb = (size_t)t * B + b;
+    const float ur = u_nx, cs = c_nx;
+    const float4 Cr = C_nx;
+    if (t + 1 < a.T) {
+      u_nx = a.u[tb + B];
+      if (taylor) {
+        C_nx = *reinterpret_cast<const float4 *>(a.C + ((tb + B) * 4 + sub) * 4);
+        c_nx = a.c[(tb + B) * 4 + sub];
+      }
+    }
+    if (sub < 3) a.x[tb * 3 + sub] = pick4(c, s, w, 0.f);
+    if (taylor) {
+      float acc = cs;
+      acc = fmaf(Cr.x, c, acc); acc = fmaf(Cr.y, s, acc); acc = fmaf(Cr.z, w, acc); acc = fmaf(Cr.w, ur, acc);
+      a.c_back[tb * 4 + sub] = acc;
+    }
+    if (t == a.T - 1) break;
+    float cn, sn, nw, nth;
+    pendulum_next(pm, c, s, w, ur, cn, sn, nw, nth);
+    if (a.F != nullptr && sub < 3) {
+      const float inside = (ur >= -pm.max_torque && ur <= pm.max_torque) ? 1.f : 0.f;
+      const float r2 = c * c + s * s;
+      const float dnw[4] = {0.f, pm.dt * pm.kg, 1.f, pm.dt * pm.ku * inside};
+      const float dnth[4] = {-s / r2 + pm.dt * dnw[0], c / r2 + pm.dt * dnw[1], pm.dt * dnw[2], pm.dt * dnw[3]};
+      const float xin[4] = {c, s, w, ur};
+      const float as = pick4(-sn, cn, 0.f, 0.f);
+      float row[4], fs = pick4(cn, sn, nw, 0.f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned pr = __builtin_bit_cast(unsigned, as * dnth[j]), pw = __builtin_bit_cast(unsigned, dnw[j]);
+        row[j] = __builtin_bit_cast(float, (m2 & pw) | (~m2 & pr));   // rows 0, 1: -sn / cn times dnth; row 2: dnw itself
+        fs = fmaf(-row[j], xin[j], fs);
+      }
+      *reinterpret_cast<float4 *>(a.F + tb * 12 + sub * 4) = float4{row[0], row[1], row[2], row[3]};
+      if (a.f != nullptr) a.f[tb * 3 + sub] = fs;
+    }
+    c = cn;
+    s = sn;
+    w = nw;
+  }
+}
+
 // c_back[t][b][i] = sum_j C[t][b][i][j] tau[t][b][j] + c[t][b][i]        (mpc_step.py:305-317), one lane per (t,b,i)
 __global__ __launch_bounds__(256) void taylor_c_kernel(size_t n_rows, int nx, int nu, const float *__restrict__ C,
                                                        const float *__restrict__ c, const float *__restrict__ states,
