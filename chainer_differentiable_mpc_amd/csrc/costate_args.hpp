@@ -10,12 +10,13 @@ struct CostateArgs {
   const float *C, *c, *F;
   const float *x, *u;    // tau   [T,B,nx], [T,B,nu]
   const float *dx, *du;  // dtau' [T,B,nx], [T,B,nu]  (solution of the second LQR solve)
-  const float *r;        // affine term of the d_lambda recursion, rows of length ns: [T,B,ns]; only [:nx] is read
+  const float *r;        // affine term of the d_lambda recursion, rows of length ns (or r_cols): [T,B,ns]; only [:nx] is read
   float r_sign;          // d_lambda_t = r_sign * r_t[:nx] + ...      (+1 DiffLqr :115,124; -1 MPCstep :417,420)
   float out_sign;        // +1 DiffLqr, -1 MPCstep
   int dC_mode;           // 0: 0.5*dtau(x)tau + tau(x)dtau (differentiable_lqr.py:128); 1: 0.5*(dtau(x)tau + tau(x)dtau)
   int df_shift;          // 0: df[t] = d_lambda[t] (differentiable_lqr.py:133); 1: df[t] = d_lambda[t+1]
   float *dx0, *dC, *dc, *dF, *df;  // outputs (dC, dF, df may be nullptr)
+  int r_cols = 0;        // row length of r; 0 = ns.  nx: r is the state part alone (DiffLqr: grad_x as it is)
 };
 
 // Shape dispatch (defined in kkt_api.hip).

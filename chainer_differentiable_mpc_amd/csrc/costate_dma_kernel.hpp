@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
   float *scrC = lds + 4 * (DB * Lay::SLOT) + wave * Lay::SCR, *scrF = scrC + 4 * NS * NS;
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
 
+  const int rc = a.r_cols ? a.r_cols : NS;   // row length of a.r
   const bool is_x = lane < NX;
   const bool is_tau = lane < NS;
   const int lane_x = is_x ? lane : NX - 1;  // clamped: rows/columns re-read by the idle lanes, never used
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
     bool isF = false;
     if (gg < Lay::CH_c) { base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = Lay::CH_C; }
     else if (gg < Lay::CH_r) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::CH_c; }
-    else if (gg < Lay::CH_F) { base = (const char *)a.r; per = (size_t)NS * 4; g0 = Lay::CH_r; }
+    else if (gg < Lay::CH_F) {   // r: rows of r_cols floats - the chunks past the wave's 4 rows repeat its chunk 0
+      base = (const char *)a.r; per = (size_t)rc * 4; g0 = gg - Lay::CH_r < rc ? Lay::CH_r : gg;
+    }
     else if (gg < Lay::CH_x) { base = (const char *)a.F; per = (size_t)NX * NS * 4; g0 = Lay::CH_F; isF = true; }
     else if (gg < Lay::CH_u) { base = (const char *)a.x; per = (size_t)NX * 4; g0 = Lay::CH_x; }
     else if (gg < Lay::CH_dx) { base = (const char *)a.u; per = (size_t)NU * 4; g0 = Lay::CH_u; }
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
   const int i_tau = lane_t < NX ? Lay::OFF_x + r * NX + lane_t : Lay::OFF_u + r * NU + (lane_t - NX);
   const int i_dtau = lane_t < NX ? Lay::OFF_dx + r * NX + lane_t : Lay::OFF_du + r * NU + (lane_t - NX);
   const int i_crow = Lay::OFF_C + (r * NS + lane_x) * NS;   // row lane_x of C_t
-  const int i_c = Lay::OFF_c + r * NS + lane_x, i_r = Lay::OFF_r + r * NS + lane_x;
+  const int i_c = Lay::OFF_c + r * NS + lane_x, i_r = Lay::OFF_r + r * rc + lane_x;
   const int i_fcol = Lay::OFF_F + r * NX * NS + lane_x;     // column lane_x of F_t[:, :NX]
   struct Slot {
     float tau, dtau, ci, ri;

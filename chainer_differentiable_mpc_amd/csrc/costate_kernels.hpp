@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
     s.dtau = *dp;
     load_contig<NS>(a.C + (tb * NS + lane_x) * NS, s.Crow);
     s.ci = a.c[tb * NS + lane_x];
-    s.ri = a.r[tb * NS + lane_x];
+    s.ri = a.r[tb * (a.r_cols ? a.r_cols : NS) + lane_x];
     const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);  // there is no F_{T-1}
     const float *Fp = a.F + ((size_t)tF * B + b) * NX * NS + lane_x;  // column lane_x of F_t[:, :NX]
 #pragma unroll
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void costate_generic_kernel(const CostateArgs a
     if (a.dc != nullptr)
       for (int j = lane; j < ns; j += 64) a.dc[tb * ns + j] = a.out_sign * dtau[j];
     for (int i = lane; i < nx; i += 64) {
-      float nl = a.c[tb * ns + i], ndl = a.r_sign * a.r[tb * ns + i];
+      float nl = a.c[tb * ns + i], ndl = a.r_sign * a.r[tb * (a.r_cols ? a.r_cols : ns) + i];
       const float *Cr = a.C + (tb * ns + i) * ns;
       for (int j = 0; j < ns; ++j) {
         nl = fmaf(Cr[j], tau[j], nl);

@@ -231,7 +231,7 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, unroll=False):
+def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, unroll=False, save=False, affine=False):
     """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
     is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
     rollout needs no change); the value update keeps the unmasked blocks (:143-145).
@@ -242,6 +242,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     the diagonal (the QP's own last factorisation, :147-157), the value update keeps the unmasked blocks (:165-166).
     u, lower, upper of the wave's four trajectories arrive as 12 nu dwords in the slot padding (the flag DMA of the
     masked variant, one float per lane).
+    save (write_k only): the training form of the solve - besides K_t, k_t it leaves Quu_t and Qxu_t of every step in HBM,
+    which is all DiffLqr.backward's second solve needs next to F (differentiable_lqr.py:95-134: same C, F, hence the
+    same gains; only the affine terms change - the `affine` form below).
+    affine (stash, no gains out): the re-solve of an LQR problem whose C and F have been solved before (the saving form
+    above) with another c, f = 0 - DiffLqr.backward's second solve (differentiable_lqr.py:108-114: c = [grad_x; grad_u],
+    x_init = 0).  The gains K_t and the blocks Quu_t, Qxu_t do not depend on c, so only the affine recursion is redone:
+    q = c_t + F_t^T v_{t+1}, k_t = -Quu_t^-1 qu, v_t = qx + Qxu_t k_t (lqr_recursion.py:92,119-120,152 with
+    qu + Quu k = 0), then the same rollout.  The slot's C region carries [K_t | Qxu_t | Quu_t] instead of C_t (36
+    chunks instead of 100 at (8,2); the other lanes of those groups fetch a resident zero chunk): 504 B per
+    timestep-solve instead of 832 B, and ~60 instructions per step instead of ~165.
     expand (mpc only): need_expand of MPCstep.forward (mpc_step.py:305-317) inside the sweep - the slot padding also
     takes x_t (4 nx more dwords) and every step starts with c_hat = C [x_t; u_t] + c in the affine column."""
     L = Layout(nx, nu)
@@ -251,6 +261,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     assert not unroll or (stash and not mpc)
     assert not mpc or (masked and write_k and not stash)
     assert not expand or (mpc and 12 * nu + 4 * nx <= 64)
+    assert not save or (write_k and not masked and not mpc and not unroll)
+    assert not affine or (stash and not write_k and not masked and not mpc and not unroll and not save and ns >= 4)
     P = Prog()
     R = Regs(VBASE)
     # ---- operand names (C++ side: struct LqrAsmIn of lqr_asm_gen.hpp, filled by lqr_asm_kernel.hpp)
@@ -265,13 +277,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     pk = ["%%[pk%d]" % m for m in range(nu)]
 
     # ---- fixed registers
-    mfma = USE_MFMA and ns <= 12 and nx % 4 == 0
+    mfma = USE_MFMA and ns <= 12 and nx % 4 == 0 and not affine
     NQ = 4 * ((ns + 3) // 4)            # MFMA accumulator tiles are 4 consecutive rows
-    Q = [R.take(NQ if mfma else ns, align=4) for _ in range(3)]
+    # affine: a set is [c | - | Qxu (nu) | Quu (nu*nu) | K rows (nu)] at (nu = 2: 0, 2, 4, 8; nu = 1: 0, 1, 2, 3)
+    AQX, AQU, AKR = (2, 4, 8) if nu == 2 else (1, 2, 3)
+    Q = [R.take(max(ns, AKR + nu) if affine else (NQ if mfma else ns), align=4) for _ in range(3)]
     F = [R.take(nx) for _ in range(3)]
     W = R.take(max(nx, 8 if mpc else 4), align=4)     # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V); mpc: the QP's temporaries
     G10 = R.take(1)[0]                  # MFMA path: row "1" of G^ = F^T v
-    A = [R.take(nu) for _ in range(nu)]
+    A = [R.take(nu, align=2 if save and nu == 2 and m_ == 0 else 1) for m_ in range(nu)]   # save: Quu leaves as one dwordx4
     Kt = R.take(nu)
     Rr = R.take(nu)
     tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = R.take(13)
@@ -313,6 +327,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     S_N, S_TF = "s70", "%[tf]"   # tf: time strides the DMA pointers may still take (an operand: it crosses the two asm blocks)
     S_KM, S_SM, S_UM, S_XM, S_HI = "s[72:73]", "s[74:75]", "s[76:77]", "s[88:89]", "s[90:91]"
     S_RET, S_STUB, S_JMP, S_TMP = "s[78:79]", "s[80:81]", "s[82:83]", "s84"
+    S_ROW0 = "s[98:99]"         # save: lane 0 of each 16-lane row
     S_AFF = "s[100:101]"        # mpc: the lanes `aff` (the stash pairs above are the QP's masks there - no stash in that mode)
 
     def mask64(lanes):
@@ -386,7 +401,17 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             return
         off = slot * L.SLOT_B
         P.uses(Q[s][:ns] + F[s])
-        for i in range(ns):
+        if affine:
+            P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][0], aq[0], off))                       # c_t, lane j = c[j]
+            if nu == 2:
+                P.raw("ds_read_b64 %s, %s offset:%d" % (vrange(Q[s][AQX:AQX + 2]), aq[1], off))  # Qxu row of lane i < nx
+                P.raw("ds_read_b128 %s, %s offset:%d" % (vrange(Q[s][AQU:AQU + 4]), aq[2], off)) # Quu, the same in every lane
+            else:
+                P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][AQX], aq[1], off))
+                P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][AQU], aq[2], off))
+            for m in range(nu):                                                                  # K rows, lane j < nx = K[m][j]
+                P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][AKR + m], aq[3], off + m * nx * 4))
+        for i in range(0 if affine else ns):
             P.raw("ds_read_b32 %s, %s offset:%d" % (Q[s][i], aq[i], off))
         for k in range(nx):
             P.raw("ds_read_b32 %s, %s offset:%d" % (F[s][k], af[k], off))
@@ -623,13 +648,55 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             P.uses(Kt)
             for m in range(nu):
                 P.raw("global_store_dword %s, %s, off" % (pk[m], Kt[m]))
+        if save:
+            # Qxu_t: rows i < nx of Q~ hold it in lanes nx..ns-1 (the value update below writes over them);
+            # Quu_t: every lane has it in A - lane 0 of each row stores the nu * nu floats
+            P.uses(Qs[:nx] + [r_ for row_ in A for r_ in row_])
+            P.raw("s_mov_b64 exec, " + S_UM)
+            for i in range(nx):
+                P.raw("global_store_dword %%[pqx], %s, off offset:%d" % (Qs[i], i * nu * 4))
+            P.raw("s_mov_b64 exec, " + S_ROW0)
+            if nu == 2:
+                quu = A[0] + A[1]
+                if int(quu[0][1:]) % 2 == 0:
+                    P.raw("global_store_dwordx4 %%[psq], %s, off" % vrange(quu))
+                else:                                   # register tuples start on even registers
+                    for j_, r_ in enumerate(quu):
+                        P.raw("global_store_dword %%[psq], %s, off offset:%d" % (r_, 4 * j_))
+            else:
+                P.raw("global_store_dword %%[psq], %s, off" % A[0][0])
         P.raw("s_mov_b64 exec, -1")
         P.exec_written()
         if write_k:
             for m in range(nu):
                 P.v("v_lshl_add_u64 %s, %s, 0, %%[dk]" % (pk[m], pk[m]))
+        if save:
+            P.v("v_lshl_add_u64 %[pqx], %[pqx], 0, %[dqx]")
+            P.v("v_lshl_add_u64 %[psq], %[psq], 0, %[dsq]")
         if not mpc:
             P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
+
+    def gains_affine(s):
+        """k_t = -Quu_t^-1 qu in every lane, v_t = qx + Qxu_t k_t in lanes < nx of VV, gain rows [K_t | 0 | k_t] to LDS"""
+        Qs = Q[s]
+        QUa, KK = W[0:nu], W[2:2 + nu]
+        Aa = [[Qs[AQU + m * nu + l] for l in range(nu)] for m in range(nu)]
+        for m in range(nu):
+            P.mov_dpp(QUa[m], Qs[0], nx + m)
+        neg_solve(Aa, QUa, KK)
+        P.v("v_fma_f32 %s, %s, %s, %s" % (G10, Qs[AQX], KK[0], Qs[0]), writes=(G10,), reads=(Qs[AQX], KK[0], Qs[0]))
+        for m in range(1, nu):
+            P.v("v_fmac_f32_e32 %s, %s, %s" % (G10, Qs[AQX + m], KK[m]), writes=(G10,), reads=(Qs[AQX + m], KK[m], G10))
+        for m in range(nu):
+            P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (Kt[m], Qs[AKR + m], KK[m], S_AFF), writes=(Kt[m],),
+                reads=(Qs[AKR + m], KK[m]))
+        P.raw("s_mov_b64 exec, " + S_KM)
+        for m in range(nu):
+            off = (" offset:%d" % (m * KROW * 4)) if m else ""
+            P.raw("ds_write_b32 %%[ak], %s%s" % (Kt[m], off))
+        P.raw("s_mov_b64 exec, -1")
+        P.exec_written()
+        P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
 
     def vupdate(s):
         """V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~) in place in Q[s][0..nx-1]   (lqr_recursion.py:151-152)"""
@@ -669,7 +736,13 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                            writes=(tmp[i],), reads=(tmp[i],), dpp=tmp[i])
             for i in range(ns):
                 P.v("v_fmac_f32_e32 %s, %s, %%[eaff]" % (Q[s][i], tmp[i]), writes=(Q[s][i],), reads=(tmp[i], Q[s][i]))
-        if not first and mfma:
+        if affine and not first:
+            # q = c_t + F_t^T v_{t+1}: lane j takes column j of F_t, v_{t+1}[k] broadcast from lane k    (:92)
+            for k in range(nx):
+                P.fmac_dpp(Q[s][0], G10, F[s][k], k)
+        elif affine:
+            pass
+        elif not first and mfma:
             # Q~ += F~^T V^ F^ as (V^^T F^)^T F^ - both products have the A^T B shape that an outer-product MFMA
             # computes from column-per-lane registers (A operand = 4 lanes of a register = 4 rows of A^T):
             #   G[b][j]  = sum_a V[a][b] F~[a][j]      rows b = x columns: tiles of 4, A = V[a] block b/4, B = F~[a]
@@ -697,7 +770,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                     P.fmac_dpp(W[i], V[i], F[s][k], k)
             for i in range(nx):
                 P.fmac_dpp(W[i], V[i], "%[eaff]", aff)
-        vmwait((DB - 1) * NDB_ALL + extra_outstanding)
+        # The stores of a step (gains, the saved blocks) are younger than its DMA group and retire in order with it
+        # (one counter, gfx9): between the group this step needs and now lie two younger groups AND the stores of the
+        # two steps since - allowing for them keeps two groups in flight (without, eleven stores per step would leave
+        # one).  Register set 1 also runs the second step of the sweep, where only one step's stores and the
+        # prologue's extra loads lie in between: the smaller of the two counts.
+        st_allow = 0
+        if not first and not mpc and n_step_stores:
+            st_allow = n_step_stores + (min(n_extra, n_step_stores) if s == 1 else n_step_stores)
+        vmwait((DB - 1) * NDB_ALL + extra_outstanding + st_allow)
         read_set(n, n)
         if stash and stub_n is not None:
             # unrolled sweep: this step's stash registers are known here
@@ -723,6 +804,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 P.raw("s_swappc_b64 %s, %s" % (S_RET, S_STUB))
             P.raw("s_add_u32 s%d, s%d, %d" % (lo, lo, BSTUB))
             P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+        if affine:
+            gains_affine(s)
+            return
         if not first and mfma:
             #   Q~[i][j] += sum_b G[b][i] F~[b][j] + g1[i] e_aff[j]    tiles of 4 rows i: A = G[b] block i/4, B = F~[b]
             for b_ in range(nx):
@@ -741,6 +825,12 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         gains(s, first)
         vupdate(s)
 
+    n_step_stores = 0      # global stores per backward step (not mpc)
+    if write_k:
+        n_step_stores += nu
+    if save:
+        n_step_stores += nx + (1 if nu == 1 or int(A[0][0][1:]) % 2 == 0 else nu * nu)
+    assert (DB - 1) * NDB_ALL + 2 * n_step_stores <= 63
     callsite = [0]
     bret = {}      # register set (or "first") -> return label number of its call site
     BSTUB = 32     # bytes per backward stub (two LDS reads + s_setpc_b64 = 20)
@@ -766,6 +856,14 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     for m in range(nu):
         P.v("v_mov_b32_e32 %s, 0" % Kt[m], writes=(Kt[m],))
     P.v("v_mov_b32_e32 %s, 0x7f7fffff" % MINPIV, writes=(MINPIV,))
+    if save:
+        lo_r0 = int(S_ROW0[2:S_ROW0.index(":")])
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_r0, mask64([0]) & 0xffffffff))
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_r0 + 1, mask64([0]) & 0xffffffff))
+    if affine:
+        lo_aff = int(S_AFF[2:S_AFF.index(":")])
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_aff, mask64([aff]) & 0xffffffff))
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_aff + 1, mask64([aff]) & 0xffffffff))
     if mpc:
         for r_ in XK + [NQP, QINFO]:
             P.v("v_mov_b32_e32 %s, 0" % r_, writes=(r_,))
@@ -1117,11 +1215,13 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             rw.append(("pk%d" % m, '"+v"(in.pk[%d])' % m))
     if masked:
         rw.append(("pm", '"+v"(in.pm)'))
+    if save:
+        rw += [("pqx", '"+v"(in.pqx)'), ("psq", '"+v"(in.psq)')]
     ins = []
     for q in range(L.ndma_b):
         ins.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
         ins.append(("str%d" % q, '"v"(in.str[%d])' % q))
-    for i in range(ns):
+    for i in range(4 if affine else ns):
         ins.append(("aq%d" % i, '"v"(in.aq[%d])' % i))
     for k in range(nx):
         ins.append(("af%d" % k, '"v"(in.af[%d])' % k))
@@ -1139,6 +1239,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         ins += [("drow", '"v"(in.drow)'), ("drow2", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'), ("daff2", '"v"(in.daff2)')]
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
+    if save:
+        ins += [("dqx", '"v"(in.dqx)'), ("dsq", '"v"(in.dsq)')]
     if masked:
         ins += [("dm", '"v"(in.dm)'), ("am", '"v"(in.am)')]
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)'), ("bwd_only", '"v"(in.bwd_only)')]
@@ -1147,10 +1249,10 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if expand:
         ins.append(("atau", '"v"(in.atau)'))
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
-        ['"s%d"' % i for i in ([70] + list(range(72, 102 if mpc else 98)))] + ['"vcc"', '"scc"', '"memory"']
+        ['"s%d"' % i for i in ([70] + list(range(72, 102 if (mpc or affine) else (100 if save else 98))))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
-    name = "LqrAsm<%d, %d, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(unroll))
+    name = "LqrAsm<%d, %d, %s, %s, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(unroll), tf(save), tf(affine))
     if mpc:
         name = "MpcAsm<%d, %d, %s>" % (nx, nu, tf(expand))
     o = []
@@ -1218,6 +1320,7 @@ struct LqrAsmIn {
   int bwd_only;                      // 1 = stop after the backward sweep (LqrRecursion.backward()); same in every lane
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
+  uint64_t pqx, dqx, psq, dsq;       // save: Qxu store pointer (lanes nx..ns-1: column m of row 0) / Quu (lane 0), time strides
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
   unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
   int n_qp_iter;                     // mpc (wave-uniform): iteration cap of the box QP
@@ -1237,7 +1340,9 @@ struct LqrAsmIn {
 };
 
 // UNROLL: the backward sweep unrolled over the horizon (no per-step stash stubs), generated for the headline shape only
-template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false>
+// SAVE (with WRITE_K): Quu_t and Qxu_t of every step go to HBM as well (DiffLqr's training form)
+// AFFINE (STASH, no gains out): the re-solve with saved K_t, Quu_t, Qxu_t and another c (DiffLqr.backward's second solve)
+template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false, bool AFFINE = false>
 struct LqrAsm {
   static constexpr bool kAvailable = false;
 };
@@ -1265,6 +1370,10 @@ def main():
                 if stash and not L0.stash_ok:
                     continue
                 out.append(gen_kernel(nx, nu, write_k, stash))
+                if write_k and nu in (1, 2):
+                    out.append(gen_kernel(nx, nu, write_k, stash, save=True))
+                if stash and not write_k and nx + nu >= 4:
+                    out.append(gen_kernel(nx, nu, write_k, stash, affine=True))
                 if X_UNROLL_BWD and stash and not write_k and (nx, nu) == (8, 2):
                     out.append(gen_kernel(nx, nu, write_k, stash, unroll=True))
                 if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding

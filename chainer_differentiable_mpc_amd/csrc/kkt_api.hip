@@ -99,11 +99,11 @@ size_t dmpc_lqr_kkt_workspace_bytes(int T, int B, int nx, int nu) {
   return kkt_layout(T, B, nx, nu).total;
 }
 
-int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
-                      const float *x, const float *u, const float *grad_x, const float *grad_u,
-                      int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws,
-                      size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
-  note_other_launch();
+// DiffLqr.backward.  Ks != nullptr: the gains of the forward solve are reused (dmpc_lqr_kkt_grad_saved).
+static int kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c, const float *F, const float *x,
+                    const float *u, const float *Ks, const float *Quu, const float *Qxu, const float *grad_x,
+                    const float *grad_u, int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df,
+                    void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !F || !x || !u || !grad_x || !grad_u || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(dC) || !aligned16(dF)) return DMPC_E_BADARG;
@@ -115,18 +115,53 @@ int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float 
   float *x0 = reinterpret_cast<float *>(base + w.x0);
   float *dx = reinterpret_cast<float *>(base + w.dx);
   float *du = reinterpret_cast<float *>(base + w.du);
-  const size_t rows = (size_t)T * B;
-  const int blocks = (int)((rows * (nx + nu) + 255) / 256 > 4096 ? 4096 : (rows * (nx + nu) + 255) / 256);
-  hipLaunchKernelGGL(concat_tau_kernel, dim3(blocks), dim3(256), 0, stream, rows, nx, nu, grad_x, grad_u, drl, x0,
-                     (size_t)B * nx);
-  // (1) second LQR solve: x_init = 0, c = drl, f = 0 (a NULL f is the same recursion, lqr_recursion.py:90-96)
-  int rc = dmpc_lqr_solve(T, B, nx, nu, C, drl, F, nullptr, x0, nullptr, nullptr, nullptr, dx, du, base + w.lqr,
-                          w.total - w.lqr, info, stream_);
+  // (1) second LQR solve: x_init = 0, c = [grad_x; grad_u], f = 0 (a NULL f is the same recursion, lqr_recursion.py:90-96).
+  // The generated streams take the two gradient arrays as they are (and x_init = 0 without a buffer of zeros) ...
+  const float *r = grad_x;
+  int r_cols = nx;
+  int rc = DMPC_E_UNSUPPORTED;
+  if (aligned16(grad_x) && aligned16(grad_u) && (Ks == nullptr || (aligned16(Ks) && aligned16(Quu) && aligned16(Qxu))))
+    rc = lqr_second_solve(T, B, nx, nu, C, grad_x, grad_u, F, Ks, Quu, Qxu, dx, du, info, stream);
+  if (rc == DMPC_E_UNSUPPORTED) {
+    if (Ks != nullptr) return rc;   // nothing has been launched: the caller goes on with dmpc_lqr_kkt_grad
+    // ... the other kernels a concatenated copy
+    const size_t rows = (size_t)T * B;
+    const int blocks = (int)((rows * (nx + nu) + 255) / 256 > 4096 ? 4096 : (rows * (nx + nu) + 255) / 256);
+    hipLaunchKernelGGL(concat_tau_kernel, dim3(blocks), dim3(256), 0, stream, rows, nx, nu, grad_x, grad_u, drl, x0,
+                       (size_t)B * nx);
+    rc = dmpc_lqr_solve(T, B, nx, nu, C, drl, F, nullptr, x0, nullptr, nullptr, nullptr, dx, du, base + w.lqr,
+                        w.total - w.lqr, info, stream_);
+    r = drl;
+    r_cols = 0;
+  }
   if (rc != 0) return rc;
   // (2) co-state sweeps and outer products
-  CostateArgs a{T, B, C, c, F, x, u, dx, du, drl, 1.0f, 1.0f, strict_math ? 1 : 0, strict_math ? 1 : 0,
+  CostateArgs a{T, B, C, c, F, x, u, dx, du, r, 1.0f, 1.0f, strict_math ? 1 : 0, strict_math ? 1 : 0,
                 d_x_init, dC, dc, dF, df};
+  a.r_cols = r_cols;
   return launch_costate(nx, nu, a, stream);
+}
+
+int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                      const float *x, const float *u, const float *grad_x, const float *grad_u,
+                      int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws,
+                      size_t ws_bytes, int32_t *info, dmpc_stream_t stream) {
+  note_other_launch();
+  return kkt_grad(T, B, nx, nu, C, c, F, x, u, nullptr, nullptr, nullptr, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF,
+                  df, ws, ws_bytes, info, stream);
+}
+
+// DiffLqr.backward with the gains of the forward solve (dmpc_lqr_solve_saving): the second solve shares C and F with it,
+// so K_t, Quu_t, Qxu_t are the same and only the affine recursion is redone (the `affine` stream of gen_lqr_asm.py).
+int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                            const float *x, const float *u, const float *Ks, const float *Quu, const float *Qxu,
+                            const float *grad_x, const float *grad_u, int strict_math, float *d_x_init, float *dC,
+                            float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
+                            dmpc_stream_t stream) {
+  note_other_launch();
+  if (!Ks || !Quu || !Qxu) return DMPC_E_BADARG;
+  return kkt_grad(T, B, nx, nu, C, c, F, x, u, Ks, Quu, Qxu, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF, df, ws,
+                  ws_bytes, info, stream);
 }
 
 }  // extern "C"

@@ -78,6 +78,26 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
 #define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
   hipLaunchKernelGGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
+  if (a.c_u != nullptr || (a.x_init == nullptr && a.x != nullptr)) {
+    // c in two arrays / x_init = 0: forms only the generated streams take (lqr_second_solve below)
+    bool ok = false;
+    if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable)
+      ok = mode == kSolve && !masked && a.Ks == nullptr && solve_path<NX, NU, L>(a.T, a.B) >= 3;
+    if (!ok) return DMPC_E_UNSUPPORTED;
+  }
+  if (a.Ks_in != nullptr) {
+    // the re-solve from saved gains (dmpc_lqr_saved_solve): the affine form of the generated stream, F in the stash
+    if constexpr (L == 16 && LqrAsm<NX, NU, false, true, false, false, false, true>::kAvailable) {
+      if (mode == kSolve && !masked && a.f == nullptr && a.Ks == nullptr && solve_path<NX, NU, L>(a.T, a.B) == 4) {
+        const int waves = (a.B + 3) / 4;
+        const size_t shmem = lqr_asm_lds_bytes<NX, NU, true>(a.T);
+        hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, true, false, false, false, true>), dim3((waves + 3) / 4),
+                           block, shmem, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
+    return DMPC_E_UNSUPPORTED;
+  }
   if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
     // fastest path: the whole solve as one generated instruction stream (lqr_asm_kernel.hpp); with the F stash
     // (no second read of F) when the horizon fits the stash registers
@@ -123,6 +143,14 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #define DMPC_ASM_LAUNCH(STASH)                                                                                   \
   do {                                                                                                           \
     const size_t shmem = lqr_asm_lds_bytes<NX, NU, STASH>(a.T);                                                  \
+    if constexpr (LqrAsm<NX, NU, true, STASH, false, false, true>::kAvailable) {                                 \
+      if (a.Quu_out != nullptr && write_k) { /* training form: Quu, Qxu saved too */                             \
+        if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, STASH, false, false, true>), g, block, shmem, stream, a); \
+        else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, STASH, false, false, true>), g, block, shmem, stream, a); \
+        return (int)hipGetLastError();                                                                           \
+      }                                                                                                          \
+    }                                                                                                            \
+    if (a.Quu_out != nullptr) return DMPC_E_UNSUPPORTED;                                                         \
     if (has_f && !write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, STASH>), g, block, shmem, stream, a); \
     else if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, STASH>), g, block, shmem, stream, a); \
     else if (!write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, STASH>), g, block, shmem, stream, a); \
@@ -218,8 +246,30 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
   if (nx == NX_ && nu == NU_) return launch_lqr<NX_, NU_, L_>(mode, a, stream);
   DMPC_LQR_SHAPES(X)
 #undef X
+  // (the generated streams' own argument forms - lqr_second_solve - stop here: nothing else reads them)
+  if (a.c_u != nullptr || a.Ks_in != nullptr || a.Quu_out != nullptr || (a.x_init == nullptr && a.x != nullptr))
+    return DMPC_E_UNSUPPORTED;
   if (lqr_family(nx, nu) == 3) return launch_lqr_generic(mode, nx, nu, a, stream);
   return DMPC_E_UNSUPPORTED;
+}
+
+// DiffLqr.backward's second solve (differentiable_lqr.py:108-114) without a concatenated copy of its inputs: c = [cx; cu]
+// as two arrays, x_init = 0, f = 0; with Ks != nullptr the re-solve from saved gains.  DMPC_E_UNSUPPORTED (nothing
+// launched) unless a generated stream serves the size.
+int lqr_second_solve(int T, int B, int nx, int nu, const float *C, const float *cx, const float *cu, const float *F,
+                     const float *Ks, const float *Quu, const float *Qxu, float *x_out, float *u_out, int32_t *info,
+                     hipStream_t stream) {
+  LqrArgs a{T, B, C, cx, F, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, x_out, u_out, info};
+  a.c_u = cu;
+  if (Ks != nullptr) {
+    if (B % 4 != 0) return DMPC_E_UNSUPPORTED;
+    a.Ks_in = Ks;
+    a.Quu_in = Quu;
+    a.Qxu_in = Qxu;
+  }
+  g_before_this_solve = kLaunchOther;
+  g_last_launch = kLaunchOther;
+  return dispatch_lqr(kSolve, nx, nu, a, stream);
 }
 
 }  // namespace dmpc
@@ -264,6 +314,36 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
   }
   g_before_this_solve = g_last_launch;
   g_last_launch = kLaunchOther;          // (launch_lqr sets kLaunchPlainSolve when it takes the plain stash solve)
+  return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
+}
+
+int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                          const float *f, const float *x_init, float *Ks_out, float *ks_out, float *Quu_out,
+                          float *Qxu_out, float *x_out, float *u_out, int32_t *info, dmpc_stream_t stream) {
+  note_other_launch();
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!C || !c || !F || !x_init || !x_out || !u_out || !Ks_out || !ks_out || !Quu_out || !Qxu_out) return DMPC_E_BADARG;
+  if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(Quu_out)) return DMPC_E_BADARG;
+  if (dmpc_lqr_solve_path(T, B, nx, nu) < 3 || B % 4 != 0) return DMPC_E_UNSUPPORTED;   // the generated streams only
+  LqrArgs a{T, B, C, c, F, f, x_init, nullptr, Ks_out, ks_out, nullptr, nullptr, x_out, u_out, info};
+  a.Quu_out = Quu_out;
+  a.Qxu_out = Qxu_out;
+  a.info_store = true;
+  return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
+}
+
+int dmpc_lqr_saved_solve(int T, int B, int nx, int nu, const float *c, const float *F, const float *Ks,
+                         const float *Quu, const float *Qxu, const float *x_init, float *x_out, float *u_out,
+                         int32_t *info, dmpc_stream_t stream) {
+  note_other_launch();
+  if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (!c || !F || !Ks || !Quu || !Qxu || !x_init || !x_out || !u_out) return DMPC_E_BADARG;
+  if (!aligned16(c) || !aligned16(F) || !aligned16(Ks) || !aligned16(Quu) || !aligned16(Qxu)) return DMPC_E_BADARG;
+  if (dmpc_lqr_solve_path(T, B, nx, nu) != 4 || B % 4 != 0) return DMPC_E_UNSUPPORTED;
+  LqrArgs a{T, B, nullptr, c, F, nullptr, x_init, nullptr, nullptr, nullptr, nullptr, nullptr, x_out, u_out, info};
+  a.Ks_in = Ks;
+  a.Quu_in = Quu;
+  a.Qxu_in = Qxu;
   return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
 }
 

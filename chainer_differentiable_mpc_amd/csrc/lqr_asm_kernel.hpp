@@ -44,7 +44,8 @@ constexpr size_t lqr_asm_lds_bytes(int T) {
 // (shared by the LQR kernels and the MPC backward kernel of mpc_asm_kernel.hpp).
 template <int NX, int NU, class G, bool HAS_F>
 __device__ __forceinline__ void lqr_asm_backward_sources(LqrAsmIn<NX, NU> &in, const float *C, const float *c, const float *F,
-                                                         const float *f, int T, size_t B, int b0, int lane64) {
+                                                         const float *f, int T, size_t B, int b0, int lane64,
+                                                         const float *c_u = nullptr) {
   constexpr int NS = NX + NU;
   constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
   const char *Cb = reinterpret_cast<const char *>(C), *cb = reinterpret_cast<const char *>(c);
@@ -64,10 +65,14 @@ __device__ __forceinline__ void lqr_asm_backward_sources(LqrAsmIn<NX, NU> &in, c
     const bool isC = g < nC, isc = !isC && g < nC + nc, isF = !isC && !isc && g < nC + nc + nF;
     const bool isf = !isC && !isc && !isF && g < nC + nc + nF + nf;
     const bool dyn = isF || isf;  // arrays without a slice T-1
-    const uint64_t base = isc ? reinterpret_cast<uint64_t>(cb) : isF ? reinterpret_cast<uint64_t>(Fb)
-                          : isf ? reinterpret_cast<uint64_t>(fb) : reinterpret_cast<uint64_t>(Cb);
-    const size_t per = isc ? (size_t)NS * 4 : isF ? (size_t)NX * NS * 4 : isf ? per_f : (size_t)NS * NS * 4;
-    const int g0 = isC ? 0 : isc ? nC : isF ? nC + nc : isf ? nC + nc + nF : g;  // padding lanes: chunk 0 of C again
+    // c in two arrays (c_u != nullptr): the c region is [c_x of the 4 trajectories (nx chunks) | c_u (nu chunks)]
+    const bool split = c_u != nullptr, iscu = isc && split && g >= nC + NX;
+    const uint64_t base = iscu ? reinterpret_cast<uint64_t>(c_u) : isc ? reinterpret_cast<uint64_t>(cb)
+                          : isF ? reinterpret_cast<uint64_t>(Fb) : isf ? reinterpret_cast<uint64_t>(fb)
+                          : reinterpret_cast<uint64_t>(Cb);
+    const size_t per = iscu ? (size_t)NU * 4 : isc ? (split ? (size_t)NX * 4 : (size_t)NS * 4) : isF ? (size_t)NX * NS * 4
+                       : isf ? per_f : (size_t)NS * NS * 4;
+    const int g0 = isC ? 0 : iscu ? nC + NX : isc ? nC : isF ? nC + nc : isf ? nC + nc + nF : g;  // padding lanes: chunk 0 of C again
     const size_t off = (size_t)(g - g0) * 16;
     const int t0 = dyn ? T - 2 : T - 1;
     const uint64_t p = base + ((size_t)t0 * B + (size_t)b0) * per + off;
@@ -78,10 +83,68 @@ __device__ __forceinline__ void lqr_asm_backward_sources(LqrAsmIn<NX, NU> &in, c
   }
 }
 
+// AFFINE: the slot's C region holds [K_t | Qxu_t | Quu_t] of the wave's four trajectories (nu nx + nx nu + nu nu chunks)
+// and nothing else - the remaining lanes of those groups fetch the resident zero chunk with a zero time stride.
+template <int NX, int NU, class G>
+__device__ __forceinline__ void lqr_asm_affine_sources(LqrAsmIn<NX, NU> &in, const float *Ks, const float *Qxu, const float *Quu,
+                                                       const float *c, const float *F, int T, size_t B, int b0, int lane64,
+                                                       const float *c_u = nullptr) {
+  constexpr int NS = NX + NU;
+  constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;
+  constexpr int nK = NU * NX, nQx = NX * NU, nQu = NU * NU;
+  static_assert(nK + nQx + nQu <= nC, "the saved blocks fit the C region");
+  const uint64_t zero = reinterpret_cast<uint64_t>(dmpc_zero_chunks);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q >= G::NDB) {
+      in.ptr[q] = in.str1[q] = in.str[q] = 0;
+      continue;
+    }
+    const int g = q * 64 + lane64;
+    const bool isK = g < nK, isQx = !isK && g < nK + nQx, isQu = !isK && !isQx && g < nK + nQx + nQu;
+    const bool isc = g >= nC && g < nC + nc, isF = g >= nC + nc && g < nC + nc + nF;
+    const bool split = c_u != nullptr, iscu = isc && split && g >= nC + NX;   // (as in lqr_asm_backward_sources)
+    const uint64_t base = isK ? reinterpret_cast<uint64_t>(Ks) : isQx ? reinterpret_cast<uint64_t>(Qxu)
+                          : isQu ? reinterpret_cast<uint64_t>(Quu) : iscu ? reinterpret_cast<uint64_t>(c_u)
+                          : isc ? reinterpret_cast<uint64_t>(c) : isF ? reinterpret_cast<uint64_t>(F) : zero;
+    const size_t per = isK ? (size_t)NU * NX * 4 : isQx ? (size_t)NX * NU * 4 : isQu ? (size_t)NU * NU * 4
+                       : iscu ? (size_t)NU * 4 : isc ? (split ? (size_t)NX * 4 : (size_t)NS * 4) : isF ? (size_t)NX * NS * 4 : 0;
+    const int g0 = isK ? 0 : isQx ? nK : isQu ? nK + nQx : iscu ? nC + NX : isc ? nC : isF ? nC + nc : g;   // zero lanes: chunk 0 of the zeros
+    const int t0 = isF ? T - 2 : T - 1;
+    const uint64_t p = base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(g - g0) * 16;
+    in.ptr[q] = p - (uint64_t)q * 1024u;
+    const uint64_t s = (uint64_t)0 - (uint64_t)(B * per);
+    in.str[q] = s;
+    in.str1[q] = isF ? 0 : s;
+  }
+}
+
+// ... and its LDS read addresses: aq[0] lane j = c[j]; aq[1] lane i < nx = row i of Qxu; aq[2] Quu (every lane of the row);
+// aq[3] lane j < nx = K[0][j] (row m at + m nx floats); af as in the full solve (f = 0: the zero chunks)
+template <int NX, int NU, class G>
+__device__ __forceinline__ void lqr_asm_affine_addresses(LqrAsmIn<NX, NU> &in, unsigned ring, int r, int lane, bool split_c = false) {
+  constexpr int NS = NX + NU;
+  static_assert(NS >= 4, "four address operands");
+  const int lane_c = lane < NS ? lane : NS - 1;
+  const int lane_x = lane < NX ? lane : NX - 1;
+  const bool col_aff = lane == NS;
+  in.aq[0] = ring + (unsigned)(G::OFF_c + (!split_c ? (r * NS + lane_c) * 4
+                                           : lane_c < NX ? (r * NX + lane_c) * 4 : NX * 16 + (r * NU + lane_c - NX) * 4));
+  in.aq[1] = ring + (unsigned)(G::OFF_C + NU * NX * 16 + (r * NX + lane_x) * NU * 4);
+  in.aq[2] = ring + (unsigned)(G::OFF_C + (NU * NX + NX * NU) * 16 + r * NU * NU * 4);
+  in.aq[3] = ring + (unsigned)(G::OFF_C + (r * NU * NX + lane_x) * 4);
+#pragma unroll
+  for (int i = 4; i < NS; ++i) in.aq[i] = 0;
+  const unsigned f0 = ring + (col_aff ? (unsigned)(G::OFF_f + r * NX * 4) : (unsigned)(G::OFF_F + (r * NX * NS + lane_c) * 4));
+  const unsigned st = col_aff ? 4u : (unsigned)(NS * 4);
+#pragma unroll
+  for (int k = 0; k < NX; ++k) in.af[k] = f0 + (unsigned)k * st;
+}
+
 // LDS read addresses (ring slot 0) of a lane's rows: lane j < ns walks column j of [C] / [F] (stride ns floats), lane ns
 // walks c / f themselves (stride 1)
 template <int NX, int NU, class G>
-__device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsigned ring, int r, int lane) {
+__device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsigned ring, int r, int lane, bool split_c = false) {
   constexpr int NS = NX + NU;
   const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
   const bool col_aff = lane == NS;
@@ -90,6 +153,11 @@ __device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsi
   const unsigned st = col_aff ? 4u : (unsigned)(NS * 4);
 #pragma unroll
   for (int i = 0; i < NS; ++i) in.aq[i] = q0 + (unsigned)i * st;
+  if (split_c && col_aff) {   // c region = [c_x of the 4 trajectories | c_u of the 4 trajectories]
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      in.aq[i] = ring + (unsigned)(G::OFF_c + (i < NX ? (r * NX + i) * 4 : NX * 16 + (r * NU + i - NX) * 4));
+  }
 #pragma unroll
   for (int k = 0; k < NX; ++k) in.af[k] = f0 + (unsigned)k * st;
 }
@@ -97,9 +165,12 @@ __device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsi
 // MASKED: LQR_active (mpc/active_constrained_lqr.py) - a.mask [T,B,nu] uint8 marks the clamped controls; needs
 // B * nu to be a multiple of 4 (the flags of a wave's four trajectories are fetched as whole dwords).
 // a.x == nullptr: backward sweep only (LqrRecursion.backward(), gains to a.Ks / a.ks - WRITE_K).
-template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false>
+// AFFINE: the re-solve from saved gains (a.Ks_in, a.Quu_in, a.Qxu_in; a.c the new affine term, no f, a.C not read).
+template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false,
+          bool AFFINE = false>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
-  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, UNROLL>;
+  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, UNROLL, SAVE, AFFINE>;
+  static_assert(!AFFINE || (!HAS_F && STASH), "the affine re-solve has no f and keeps F in the stash");
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU, AFF = NS, KROW = G::KROW;
   constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nf = NX;  // 16-byte chunks per wave-step (4 trajectories)
@@ -133,7 +204,8 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.tf = 0;
   in.bwd_only = a.x == nullptr ? 1 : 0;
 
-  lqr_asm_backward_sources<NX, NU, G, HAS_F>(in, a.C, a.c, a.F, a.f, T, B, b0, lane64);
+  if constexpr (AFFINE) lqr_asm_affine_sources<NX, NU, G>(in, a.Ks_in, a.Qxu_in, a.Quu_in, a.c, a.F, T, B, b0, lane64, a.c_u);
+  else lqr_asm_backward_sources<NX, NU, G, HAS_F>(in, a.C, a.c, a.F, a.f, T, B, b0, lane64, a.c_u);
   const char *Fb = reinterpret_cast<const char *>(a.F);
   const char *fb = HAS_F ? reinterpret_cast<const char *>(a.f) : reinterpret_cast<const char *>(dmpc_zero_chunks);
   constexpr size_t per_f = HAS_F ? (size_t)NX * 4 : 0;  // bytes of f per trajectory and timestep (0: the zero chunks)
@@ -154,7 +226,8 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.nz = (int)(gain_wave_bytes / 1024u);
   const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
   const bool col_aff = lane == AFF;
-  lqr_asm_row_addresses<NX, NU, G>(in, ring, r, lane);
+  if constexpr (AFFINE) lqr_asm_affine_addresses<NX, NU, G>(in, ring, r, lane, a.c_u != nullptr);
+  else lqr_asm_row_addresses<NX, NU, G>(in, ring, r, lane, a.c_u != nullptr);
   in.ak = gain_traj + (unsigned)((T - 1) * NU * KROW * 4) + (unsigned)lane * 4u;
   in.eaff = col_aff ? 1.f : 0.f;
   if constexpr (WRITE_K) {
@@ -168,6 +241,16 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
 #pragma unroll
     for (int m = 0; m < NU; ++m) in.pk[m] = 0;
     in.dk = 0;
+  }
+  if constexpr (SAVE) {   // Qxu: lane nx + m owns column m (row i by the instruction offset); Quu: lane 0 of the row
+    const size_t tb = (size_t)(T - 1) * B + (size_t)b;
+    const int m_ = lane >= NX && lane < NS ? lane - NX : 0;
+    in.pqx = reinterpret_cast<uint64_t>(a.Qxu_out + tb * NX * NU + m_);
+    in.dqx = (uint64_t)0 - (uint64_t)(B * NX * NU * 4);
+    in.psq = reinterpret_cast<uint64_t>(a.Quu_out + tb * NU * NU);
+    in.dsq = (uint64_t)0 - (uint64_t)(B * NU * NU * 4);
+  } else {
+    in.pqx = in.dqx = in.psq = in.dsq = 0;
   }
 
   // lane i < nx: row i of [F_t | f_t]; lane nx+m: gain row m; the other lanes shadow the last gain row
@@ -229,7 +312,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
                  : reinterpret_cast<uint64_t>(a.u + (size_t)b * NU + m_own);
   in.dst = row_x ? (uint64_t)(B * NX * 4) : (uint64_t)(B * NU * 4);
   in.pxi = a.x_init != nullptr ? reinterpret_cast<uint64_t>(a.x_init + (size_t)b * NX + (row_x ? lane : NX - 1))
-                               : reinterpret_cast<uint64_t>(a.C);  // backward only: any readable word
+                               : reinterpret_cast<uint64_t>(dmpc_zero_chunks);  // x_init = 0 (backward only: never used)
   in.px0 = reinterpret_cast<uint64_t>(a.x + (size_t)b * NX + (row_x ? lane : NX - 1));
 
   float xvout, minpiv;
@@ -250,7 +333,13 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     if (minpiv == 0.f) bits |= 1;                       // a zero pivot in some Quu (uniform over the row)
     if (lane < NS && !is_finite(xvout)) bits |= 2;      // NaN/Inf propagate to u_{T-1} through the recursion
     if (a.x == nullptr && !is_finite(minpiv)) bits |= 2;  // backward only: a NaN pivot is all there is to see
-    if (bits != 0) atomicOr(&a.info[b], bits);
+    if (a.info_store) {   // (uniform) one lane per trajectory writes the row's flags, zero included
+      const unsigned long long nonfinite = __ballot((bits & 2) != 0);
+      const int row_bits = (bits & 1) | ((((nonfinite >> (16 * r)) & 0xffffull) != 0) ? 2 : 0);
+      if (lane == 0) a.info[b] = row_bits;
+    } else if (bits != 0) {
+      atomicOr(&a.info[b], bits);
+    }
   }
 }
 

@@ -26,6 +26,17 @@ struct LqrArgs {
   float *wsK, *wsk;     // caller workspace used for the gains when they do not fit in LDS
   float *x, *u;
   int32_t *info;
+  // training form of the solve (generated stream only): Quu_t [T,B,nu,nu] and Qxu_t [T,B,nx,nu] next to Ks / ks, for
+  // DiffLqr.backward's second solve (dmpc_lqr_saved_solve); nullptr: not wanted
+  float *Quu_out = nullptr, *Qxu_out = nullptr;
+  // generated streams only: c given as two arrays, `c` = its state part [T,B,nx] and `c_u` its control part [T,B,nu]
+  // (DiffLqr.backward's second solve takes [grad_x; grad_u] as they are); there x_init == nullptr with x != nullptr
+  // means x_init = 0
+  const float *c_u = nullptr;
+  bool info_store = false;   // info[b] is written (0 included) instead of or-ed into: the caller need not clear it
+  // the re-solve with saved gains (lqr_asm_kernel<..., AFFINE>): K_t [T,B,nu,nx], Quu_t [T,B,nu,nu], Qxu_t [T,B,nx,nu] of
+  // an earlier solve of the same C, F; `c` is the new affine cost term, C is not read
+  const float *Ks_in = nullptr, *Quu_in = nullptr, *Qxu_in = nullptr;
 };
 
 enum LqrMode { kSolve = 0, kBackwardOnly = 1, kForwardOnly = 2 };

@@ -9,17 +9,22 @@ Reference quirks kept by default, switch off with `strict_math
   dC_t = 0.5*(d_tau (x) tau) + (tau (x) d_tau)      differentiable_lqr.py:128
   df   = d_lambda[0:T-1]                            differentiable_lqr.py:133
 """
+import os
+
 import numpy as np
 import torch
 
 from . import _lib
-from .lqr_recursion import _as_tensor, _device_of, _workspace, solve_device
+from .lqr_recursion import (_as_tensor, _device_of, _workspace, saving_solve_available, solve_device,
+                            solve_saving_device)
 from .util import expand_time_batch
 
 
 def kkt_grad_device(C, c, F, x, u, grad_x, grad_u, T, n_state, n_ctrl, strict_math=False, info=None,
-                    need_dC=True, need_dF=True, need_df=True):
-    """Raw KKT gradient on float32 device tensors -> (d_x_init, dC, dc, dF, df)."""
+                    need_dC=True, need_dF=True, need_df=True, saved=None):
+    """Raw KKT gradient on float32 device tensors -> (d_x_init, dC, dc, dF, df).
+    saved = (Ks, Quu, Qxu) of `solve_saving_device`: the second solve reuses the forward solve's gains
+    (`dmpc_lqr_kkt_grad_saved`) instead of repeating the Riccati sweep."""
     lib = _lib.load()
     _lib.require_gpu()
     dev = C.device
@@ -35,10 +40,19 @@ def kkt_grad_device(C, c, F, x, u, grad_x, grad_u, T, n_state, n_ctrl, strict_ma
     need = lib.dmpc_lqr_kkt_workspace_bytes(T, B, nx, nu)
     ws = _workspace(need, dev)
     with torch.cuda.device(dev):
-        rc = lib.dmpc_lqr_kkt_grad(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(x), _lib.ptr(u),
-                                   _lib.ptr(grad_x), _lib.ptr(grad_u), 1 if strict_math else 0, _lib.ptr(dx0),
-                                   _lib.ptr(dC), _lib.ptr(dc), _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need,
-                                   _lib.ptr(info), _lib.stream_ptr(dev))
+        rc = _lib.E_UNSUPPORTED
+        if saved is not None:
+            Ks, Quu, Qxu = saved
+            rc = lib.dmpc_lqr_kkt_grad_saved(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(x), _lib.ptr(u),
+                                             _lib.ptr(Ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(grad_x), _lib.ptr(grad_u),
+                                             1 if strict_math else 0, _lib.ptr(dx0), _lib.ptr(dC), _lib.ptr(dc),
+                                             _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need, _lib.ptr(info),
+                                             _lib.stream_ptr(dev))
+        if rc == _lib.E_UNSUPPORTED:      # (nothing was launched)
+            rc = lib.dmpc_lqr_kkt_grad(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(x), _lib.ptr(u),
+                                       _lib.ptr(grad_x), _lib.ptr(grad_u), 1 if strict_math else 0, _lib.ptr(dx0),
+                                       _lib.ptr(dC), _lib.ptr(dc), _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need,
+                                       _lib.ptr(info), _lib.stream_ptr(dev))
     _lib.check(rc, "dmpc_lqr_kkt_grad")
     return dx0, dC, dc, dF, df
 
@@ -78,13 +92,14 @@ class _DiffLqrFn(torch.autograd.Function):
 class DiffLqr:
     """Differentiable LQR (module 1 of Amos et al. 2018).  lqr/differentiable_lqr.py:21-142."""
 
-    def __init__(self, T, n_batch, n_state, n_ctrl, strict_math=False):
+    def __init__(self, T, n_batch, n_state, n_ctrl, strict_math=False, save_gains=True):
         self.T = int(T)
         self.n_batch = int(n_batch)
         self.n_state = int(n_state)
         self.n_ctrl = int(n_ctrl)
         self.n_sc = self.n_state + self.n_ctrl
         self.strict_math = bool(strict_math)
+        self.save_gains = bool(save_gains) and os.environ.get("DMPC_NO_SAVED_GAINS") != "1"
         self._retained = None
         self.info = None
 
@@ -108,9 +123,24 @@ class DiffLqr:
             assert list(f.shape) == [T - 1, B, nx], " f dim mismatch"
         dev = _device_of(C, c, F, x_init)
         d = [_lib.f32c(t.detach() if t is not None else None, dev) for t in (x_init, C, c, F, f)]
-        self.info = torch.zeros(B, dtype=torch.int32, device=dev)
-        x, u, _, _ = solve_device(d[1], d[2], d[3], d[4], d[0], None, T, nx, nu, info=self.info)
-        self._retained = dict(x_init=d[0], C=d[1], c=d[2], F=d[3], x=x, u=u, out_dtype=C.dtype, out_device=C.device)
+        saved = None
+        got = None
+        use_saving = self.save_gains and saving_solve_available(T, B, nx, nu)
+        # (the saving solve writes every trajectory's flags itself; the plain one ors into a cleared array)
+        self.info = (torch.empty if use_saving else torch.zeros)(B, dtype=torch.int32, device=dev)
+        if use_saving:
+            # training form: K_t, Quu_t, Qxu_t stay in HBM (36 % more bytes written by the forward solve) and the
+            # backward pass's second solve only redoes the affine recursion with them
+            got = solve_saving_device(d[1], d[2], d[3], d[4], d[0], T, nx, nu, info=self.info)
+        if got is not None:
+            x, u, Ks, _, Quu, Qxu = got
+            saved = (Ks, Quu, Qxu)
+        else:
+            if use_saving:
+                self.info.zero_()
+            x, u, _, _ = solve_device(d[1], d[2], d[3], d[4], d[0], None, T, nx, nu, info=self.info)
+        self._retained = dict(x_init=d[0], C=d[1], c=d[2], F=d[3], x=x, u=u, saved=saved, out_dtype=C.dtype,
+                              out_device=C.device)
         return x.to(device=C.device, dtype=C.dtype), u.to(device=C.device, dtype=C.dtype)
 
     # -- reference API ---------------------------------------------------------------------------
@@ -138,7 +168,7 @@ class DiffLqr:
         gu = _lib.f32c(_as_tensor(grad_u), dev) if grad_u is not None else torch.zeros((T, B, nu), device=dev)
         assert list(gx.shape) == [T, B, nx] and list(gu.shape) == [T, B, nu]
         out = kkt_grad_device(r["C"], r["c"], r["F"], r["x"], r["u"], gx, gu, T, nx, nu,
-                              strict_math=self.strict_math)
+                              strict_math=self.strict_math, saved=r.get("saved"))
         return tuple(g.to(device=r["out_device"], dtype=r["out_dtype"]) for g in out)
 
 

@@ -149,6 +149,53 @@ def _workspace(nbytes, device):
     return ws
 
 
+def saving_solve_available(T, B, n_state, n_ctrl):
+    """does `solve_saving_device` (and with it the saved-gains gradient) serve this size?"""
+    lib = _lib.load()
+    return B % 4 == 0 and n_ctrl <= 2 and lib.dmpc_lqr_solve_path(T, B, n_state, n_ctrl) == 4
+
+
+def solve_saving_device(C, c, F, f, x_init, T, n_state, n_ctrl, info=None):
+    """The training form of the fused solve (`dmpc_lqr_solve_saving`): (x, u, Ks, ks, Quu, Qxu), or None where the
+    generated stream does not serve the size (the caller then uses `solve_device`)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = C.device
+    B = C.shape[1]
+    nx, nu = n_state, n_ctrl
+    f32 = dict(dtype=torch.float32, device=dev)
+    x = torch.empty((T, B, nx), **f32)
+    u = torch.empty((T, B, nu), **f32)
+    Ks = torch.empty((T, B, nu, nx), **f32)
+    ks = torch.empty((T, B, nu), **f32)
+    Quu = torch.empty((T, B, nu, nu), **f32)
+    Qxu = torch.empty((T, B, nx, nu), **f32)
+    with torch.cuda.device(dev):
+        rc = lib.dmpc_lqr_solve_saving(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(x_init),
+                                       _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(x), _lib.ptr(u),
+                                       _lib.ptr(info), _lib.stream_ptr(dev))
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "dmpc_lqr_solve_saving")
+    return x, u, Ks, ks, Quu, Qxu
+
+
+def saved_solve_device(c, F, Ks, Quu, Qxu, x_init, T, n_state, n_ctrl, info=None):
+    """`dmpc_lqr_saved_solve`: the problem of an earlier saving solve with another c (f = 0) and x_init -> (x, u)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = c.device
+    B = c.shape[1]
+    x = torch.empty((T, B, n_state), dtype=torch.float32, device=dev)
+    u = torch.empty((T, B, n_ctrl), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.dmpc_lqr_saved_solve(T, B, n_state, n_ctrl, _lib.ptr(c), _lib.ptr(F), _lib.ptr(Ks), _lib.ptr(Quu),
+                                      _lib.ptr(Qxu), _lib.ptr(x_init), _lib.ptr(x), _lib.ptr(u), _lib.ptr(info),
+                                      _lib.stream_ptr(dev))
+    _lib.check(rc, "dmpc_lqr_saved_solve")
+    return x, u
+
+
 def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False, info=None, out=None):
     """Raw fused solve on float32 device tensors (no copies): the unit the benchmark times.
     Returns (x, u, Ks|None, ks|None)."""

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define DMPC_VERSION 201 /* 0.2.1: dmpc_box_ddp clears info itself and reports its input checks in state[4:8] */
+#define DMPC_VERSION 202 /* 0.2.1: dmpc_box_ddp clears info itself and reports its input checks in state[4:8] */
 
 #define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
 #define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */
@@ -71,6 +71,25 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
                    float *ks_out, float *x_out, float *u_out, void *ws, size_t ws_bytes, int32_t *info,
                    dmpc_stream_t stream);
 
+/* solve_recursion() in its training form: as dmpc_lqr_solve with gains, and the control blocks of every step's
+ * Q-function left in HBM as well - Quu_out [T,B,nu,nu] and Qxu_out [T,B,nx,nu] (lqr_recursion.py:112-120).  The
+ * gradient's second Riccati solve (DiffLqr.backward, lqr/differentiable_lqr.py:83-106) shares C and F with the
+ * forward solve, so it can reuse K_t, Quu_t, Qxu_t and only redo the affine terms: dmpc_lqr_saved_solve below.
+ * Served by the generated instruction streams only (dmpc_lqr_solve_path >= 3, B % 4 == 0, all pointers 16-byte
+ * aligned); DMPC_E_UNSUPPORTED otherwise - the caller then uses dmpc_lqr_solve and the full second solve.
+ * `info` [B], if given, is WRITTEN (0 = clean) rather than or-ed into: the caller need not clear it first. */
+int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                          const float *f, const float *x_init, float *Ks_out, float *ks_out, float *Quu_out,
+                          float *Qxu_out, float *x_out, float *u_out, int32_t *info, dmpc_stream_t stream);
+
+/* The re-solve: the LQR problem of an earlier dmpc_lqr_solve_saving (same C, F) with another affine cost term c
+ * [T,B,ns], f = 0 and another x_init.  K_t does not depend on c; k_t = -Quu_t^-1 (c_u + F_u^T v_{t+1}),
+ * v_t = q_x + Qxu_t k_t (lqr_recursion.py:92,119-120,152), then the rollout (:160-200).  C is not read.
+ * DMPC_E_UNSUPPORTED unless dmpc_lqr_solve_path == 4 (generated stream, F kept on chip) and B % 4 == 0. */
+int dmpc_lqr_saved_solve(int T, int B, int nx, int nu, const float *c, const float *F, const float *Ks,
+                         const float *Quu, const float *Qxu, const float *x_init, float *x_out, float *u_out,
+                         int32_t *info, dmpc_stream_t stream);
+
 /* backward(): gains only (lqr_recursion.py:69-158). */
 int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                             const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
@@ -92,6 +111,16 @@ int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float 
                       const float *x, const float *u, const float *grad_x, const float *grad_u,
                       int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df,
                       void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
+
+/* The same gradient when the forward solve was dmpc_lqr_solve_saving: the second Riccati solve of :108-114 shares C
+ * and F with it, so its gains are Ks and only the affine recursion is redone (dmpc_lqr_saved_solve); C is then read
+ * once (by the co-state sweep) instead of twice.  Same workspace; DMPC_E_UNSUPPORTED where dmpc_lqr_saved_solve is
+ * (nothing has been launched then: call dmpc_lqr_kkt_grad instead). */
+int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                            const float *x, const float *u, const float *Ks, const float *Quu, const float *Qxu,
+                            const float *grad_x, const float *grad_u, int strict_math, float *d_x_init, float *dC,
+                            float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
+                            dmpc_stream_t stream);
 
 /* ---- D. batched LU (util.py:462-482 torch.lu, util.py:505-528 torch.lu_solve in float32) */
 /* A [B,n,n] -> LU [B,n,n], piv [B,n] int32 1-based (LAPACK getrf). */

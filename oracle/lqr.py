@@ -11,8 +11,11 @@ import numpy as np
 from .linalg import bmv
 
 
-def lqr_backward(C, c, F, f, T, n_state, n_ctrl):
+def lqr_backward(C, c, F, f, T, n_state, n_ctrl, blocks=None):
     """Riccati value recursion -> gains.  lqr_recursion.py:69-158.
+
+    blocks: an optional dict that receives the control blocks of every step's Q-function, "Quu" [T,B,nu,nu] and
+    "Qxu" [T,B,nx,nu] (:100,102) - what the build's saving solve leaves in HBM next to the gains.
 
     Returns Ks [T,B,nu,nx], ks [T,B,nu] in forward time order (the reference returns
     Python lists of the same per-step arrays, :156-158).
@@ -51,6 +54,9 @@ def lqr_backward(C, c, F, f, T, n_state, n_ctrl):
         Kt_T = np.transpose(Kt, (0, 2, 1))
         Ks[t] = Kt
         ks[t] = kt
+        if blocks is not None:
+            blocks.setdefault("Quu", np.zeros((T, B, nu, nu), dtype=Ks.dtype))[t] = Qt_uu
+            blocks.setdefault("Qxu", np.zeros((T, B, nx, nu), dtype=Ks.dtype))[t] = Qt_xu
         # :151-152 - no symmetrisation, every term kept
         Vt = Qt_xx + np.matmul(Qt_xu, Kt) + np.matmul(Kt_T, Qt_ux) + np.matmul(np.matmul(Kt_T, Qt_uu), Kt)
         vt = qt_x + bmv(Qt_xu, kt) + bmv(Kt_T, qt_u) + bmv(np.matmul(Kt_T, Qt_uu), kt)

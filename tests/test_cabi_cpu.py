@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdmpc_hip.so lacks %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.dmpc_version() == 201
+    assert lib.dmpc_version() == 202
 
 
 def test_library_belongs_to_the_sources_in_the_tree():

@@ -1,0 +1,167 @@
+"""GPU parity: the training form of the fused solve (`dmpc_lqr_solve_saving`: gains and the control blocks Quu_t, Qxu_t
+of every step left in HBM), the re-solve that reuses them (`dmpc_lqr_saved_solve`) and DiffLqr.backward on top of it
+(`dmpc_lqr_kkt_grad_saved`; lqr/differentiable_lqr.py:108-114: the second solve has the forward solve's C and F).
+Rows A and B."""
+import numpy as np
+import pytest
+import torch
+
+from chainer_differentiable_mpc_amd import DiffLqr, _lib, synthetic
+from chainer_differentiable_mpc_amd.differentiable_lqr import kkt_grad_device
+from chainer_differentiable_mpc_amd.lqr_recursion import (saved_solve_device, saving_solve_available, solve_device,
+                                                          solve_saving_device)
+from oracle import kkt as okkt
+from oracle import lqr as olqr
+from tests.helpers import TOL_COSTATE, TOL_PRIMAL, assert_close, npy, to_dev
+
+pytestmark = pytest.mark.gpu
+
+# (B, T, nx, nu, with_f): every shape with an affine stream, short and stash-filling horizons, one wave and several
+CASES = [(4, 5, 8, 2, True), (12, 50, 8, 2, True), (8, 23, 8, 2, False), (260, 50, 8, 2, True), (8, 12, 4, 2, True),
+         (4, 30, 4, 2, False), (8, 9, 2, 2, True), (16, 40, 2, 2, False)]
+KEYS = ("d_x_init", "dC", "dc", "dF", "df")
+TOLS = dict(d_x_init=TOL_COSTATE, dC=TOL_PRIMAL, dc=TOL_PRIMAL, dF=TOL_COSTATE, df=TOL_COSTATE)
+
+
+def _problem(B, T, nx, nu, with_f, seed=3):
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=seed, with_f=with_f)
+    return p, to_dev(p)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_saving_solve_equals_the_plain_solve_and_leaves_the_q_blocks(case):
+    B, T, nx, nu, with_f = case
+    assert saving_solve_available(T, B, nx, nu)
+    p, d = _problem(B, T, nx, nu, with_f)
+    info = torch.full((B,), 77, dtype=torch.int32, device="cuda")     # written, not or-ed into (include/dmpc.h)
+    got = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu, info=info)
+    assert got is not None
+    x, u, Ks, ks, Quu, Qxu = got
+    assert int(info.abs().max()) == 0
+    x1, u1, Ks1, ks1 = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, want_gains=True)
+    torch.cuda.synchronize()
+    for a, b, what in ((x, x1, "x"), (u, u1, "u"), (Ks, Ks1, "Ks"), (ks, ks1, "ks")):
+        assert torch.equal(a, b), what + ": the saving stream is the plain stream plus stores"
+    blocks = {}
+    olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu, blocks=blocks)
+    assert_close(npy(Quu), blocks["Quu"], TOL_PRIMAL, "Quu")
+    assert_close(npy(Qxu), blocks["Qxu"], TOL_PRIMAL, "Qxu")
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_saved_solve_is_the_full_solve_with_the_new_affine_term(case):
+    B, T, nx, nu, with_f = case
+    p, d = _problem(B, T, nx, nu, with_f)
+    _, _, Ks, _, Quu, Qxu = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
+    rng = np.random.RandomState(17)
+    c2 = rng.randn(T, B, nx + nu).astype(np.float32).astype(np.float64)
+    x2 = rng.randn(B, nx).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(x2, p["C"], c2, p["F"], None, T, nx, nu)
+    info = torch.zeros(B, dtype=torch.int32, device="cuda")
+    x, u = saved_solve_device(torch.as_tensor(c2, dtype=torch.float32).cuda(), d["F"], Ks, Quu, Qxu,
+                              torch.as_tensor(x2, dtype=torch.float32).cuda(), T, nx, nu, info=info)
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
+    assert int(info.abs().max()) == 0
+    # ... and equals the device's own full solve of that problem to rounding
+    xf, uf, _, _ = solve_device(d["C"], torch.as_tensor(c2, dtype=torch.float32).cuda(), d["F"], None,
+                                torch.as_tensor(x2, dtype=torch.float32).cuda(), None, T, nx, nu)
+    assert_close(npy(x), npy(xf), 2e-5, "x vs full device solve")
+    assert_close(npy(u), npy(uf), 2e-5, "u vs full device solve")
+
+
+@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("case", CASES[:6], ids=[str(c) for c in CASES[:6]])
+def test_kkt_gradient_from_saved_gains_against_oracle(case, strict):
+    B, T, nx, nu, with_f = case
+    p, d = _problem(B, T, nx, nu, with_f, seed=5)
+    rng = np.random.RandomState(19)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu, strict_math=strict)
+    node = DiffLqr(T, B, nx, nu, strict_math=strict)
+    node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert node._retained["saved"] is not None, "the saving solve serves this size"
+    out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for got, want, key in zip(out, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)
+    # the same node without saved gains (the full second solve): same gradient to rounding
+    plain = DiffLqr(T, B, nx, nu, strict_math=strict, save_gains=False)
+    plain.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert plain._retained["saved"] is None
+    out2 = plain.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for a, b, key in zip(out, out2, KEYS):
+        assert_close(npy(a), npy(b), 1e-4, key + " saved vs full")
+
+
+def test_non_symmetric_cost_matrix():
+    """LqrNet_cost_dx learns a C that is not symmetric (differentiable_lqr.py:222-231): v_t = qx + Qxu k_t uses Qxu, not
+    the transpose of Qux - the saved block is the right one."""
+    B, T, nx, nu = 8, 20, 8, 2
+    p, _ = _problem(B, T, nx, nu, True, seed=7)
+    rng = np.random.RandomState(23)
+    p["C"] = p["C"] + 0.15 * rng.randn(*p["C"].shape).astype(np.float32).astype(np.float64)
+    d = to_dev(p)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu)
+    node = DiffLqr(T, B, nx, nu)
+    x, u = node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert node._retained["saved"] is not None
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for got, want, key in zip(out, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)
+
+
+def test_unsupported_sizes_fall_back_loudly_in_c_and_silently_in_python():
+    lib = _lib.load()
+    # (32,8) has no generated stream, (3,1) no F stash, B = 6 is not a whole number of wavefronts
+    for B, T, nx, nu in ((4, 6, 32, 8), (8, 10, 3, 1), (6, 10, 8, 2), (8, 80, 8, 2)):
+        assert not saving_solve_available(T, B, nx, nu)
+        p, d = _problem(B, T, nx, nu, True)
+        f32 = dict(dtype=torch.float32, device="cuda")
+        x, u = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32)
+        Ks, Quu, Qxu = torch.zeros((T, B, nu, nx), **f32), torch.zeros((T, B, nu, nu), **f32), torch.zeros((T, B, nx, nu), **f32)
+        rc = lib.dmpc_lqr_saved_solve(T, B, nx, nu, _lib.ptr(d["c"]), _lib.ptr(d["F"]), _lib.ptr(Ks), _lib.ptr(Quu),
+                                      _lib.ptr(Qxu), _lib.ptr(d["x_init"]), _lib.ptr(x), _lib.ptr(u), None, None)
+        assert rc == _lib.E_UNSUPPORTED
+        node = DiffLqr(T, B, nx, nu)
+        node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+        assert node._retained["saved"] is None
+        out = node.backward((0, 1, 2, 3, 4), (torch.ones((T, B, nx), **f32), torch.ones((T, B, nu), **f32)))
+        assert all(torch.isfinite(g).all() for g in out)
+
+
+def test_headline_size_sampled_against_oracle():
+    B, T, nx, nu = 4096, 50, 8, 2
+    p, d = _problem(B, T, nx, nu, True, seed=0)
+    node = DiffLqr(T, B, nx, nu)
+    node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert node._retained["saved"] is not None
+    gx = torch.ones((T, B, nx), dtype=torch.float32, device="cuda")
+    gu = torch.ones((T, B, nu), dtype=torch.float32, device="cuda")
+    out = node.backward((0, 1, 2, 3, 4), (gx, gu))
+    rows = np.array([0, 1, 2, 3, 777, 2048, 2049, 4093, 4094, 4095])
+    q = {k: (v[:, rows] if v.ndim > 2 or k in ("c",) else v[rows]) for k, v in p.items() if v is not None}
+    xr, ur = olqr.lqr_solve(q["x_init"], q["C"], q["c"], q["F"], q["f"], T, nx, nu)
+    ones_x, ones_u = np.ones((T, len(rows), nx)), np.ones((T, len(rows), nu))
+    ref = okkt.difflqr_backward(q["x_init"], q["C"], q["c"], q["F"], xr, ur, ones_x, ones_u, T, nx, nu)
+    for got, want, key in zip(out, ref, KEYS):
+        g = npy(got)
+        g = g[rows] if key == "d_x_init" else g[:, rows]
+        assert_close(g, want, TOLS[key], key)
+
+
+def test_saving_solve_flags_a_singular_quu_per_trajectory():
+    B, T, nx, nu = 8, 10, 8, 2
+    p, _ = _problem(B, T, nx, nu, True)
+    p["C"][T - 1, 5, nx:, :] = 0.0        # Quu_{T-1} = C_uu of trajectory 5: a zero pivot
+    p["C"][T - 1, 5, :, nx:] = 0.0
+    d = to_dev(p)
+    info = torch.full((B,), 77, dtype=torch.int32, device="cuda")
+    solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu, info=info)
+    got = npy(info)
+    assert got[5] != 0 and (np.delete(got, 5) == 0).all(), got
