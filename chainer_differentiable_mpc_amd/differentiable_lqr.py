@@ -4,6 +4,9 @@ torch.autograd.Function wrapper / torch.nn.Module.
 
 Forward = fused LQR solve kernel (`dmpc_lqr_solve`); backward = analytic KKT gradient
 (`dmpc_lqr_kkt_grad`: second LQR solve + co-state sweeps + outer products), both hand-written HIP.
+Where the generated stream serves the size the pair runs in its training form: the forward solve also leaves its
+gains and the control blocks of its Q-functions in HBM (`dmpc_lqr_solve_saving`) and the gradient's second solve -
+same C, same F - only redoes the affine recursion with them (`dmpc_lqr_kkt_grad_saved`).
 
 Reference quirks kept by default, switch off with `strict_math=True`:
   dC_t = 0.5*(d_tau (x) tau) + (tau (x) d_tau)      differentiable_lqr.py:128

@@ -33,3 +33,8 @@ pmc w328_mem wave_mfma "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE
 pmc w328_fetch wave_mfma "FETCH_SIZE" python3 $REPO/bench.py --workload cfg5-shard --steps 3 --warmup 1 --no-cpu-baseline
 pmc w328_write wave_mfma "WRITE_SIZE" python3 $REPO/bench.py --workload cfg5-shard --steps 3 --warmup 1 --no-cpu-baseline
 cd $REPO
+# DiffLqr forward + backward loop, with saved gains and with the full second solve
+cd /tmp
+stats difflqr_saved python3 $REPO/scripts/difflqr_loop.py
+stats difflqr_full python3 $REPO/scripts/difflqr_loop.py 0
+cd $REPO
