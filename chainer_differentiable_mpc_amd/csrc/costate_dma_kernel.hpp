@@ -27,8 +27,12 @@ __device__ __forceinline__ void store_chunks(const float *scr, float *dst, int l
 template <int NX, int NU, int DB>
 struct CostateDmaLayout {
   static constexpr int NS = NX + NU;
-  // 16-byte chunks of one wave-step (four trajectories): [C | c | r | F | x | u | dx | du]
-  static constexpr int nC = NS * NS, nc = NS, nF = NX * NS, nx_ = NX, nu_ = NU;
+  // 16-byte chunks of one wave-step (four trajectories): [C | c | r | F | x | u | dx | du].  Only the state rows of C
+  // enter the co-state recursions (differentiable_lqr.py:92,102,115,124: C[:nx, :]): where a trajectory's nx * ns
+  // floats are whole chunks, the control rows are not fetched (a fifth of C: 16 MB of 331 at the headline size)
+  static constexpr bool kStateRowsOnly = (NX * NS) % 4 == 0;
+  static constexpr int kCRows = kStateRowsOnly ? NX : NS;       // rows of C_t per trajectory in the slot
+  static constexpr int nC = kCRows * NS, nc = NS, nF = NX * NS, nx_ = NX, nu_ = NU;
   static constexpr int CH_C = 0, CH_c = CH_C + nC, CH_r = CH_c + nc, CH_F = CH_r + nc, CH_x = CH_F + nF;
   static constexpr int CH_u = CH_x + nx_, CH_dx = CH_u + nu_, CH_du = CH_dx + nx_, CH_END = CH_du + nu_;
   static constexpr int OFF_C = CH_C * 4, OFF_c = CH_c * 4, OFF_r = CH_r * 4, OFF_F = CH_F * 4, OFF_x = CH_x * 4;
@@ -86,7 +90,11 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
     size_t per;
     int g0;
     bool isF = false;
-    if (gg < Lay::CH_c) { base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = Lay::CH_C; }
+    size_t skip = 0;   // C, state rows only: trajectory k of the wave starts k * (ns - nx) * ns floats further on
+    if (gg < Lay::CH_c) {
+      base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = Lay::CH_C;
+      if constexpr (Lay::kStateRowsOnly) skip = (size_t)(gg / (NX * NS / 4)) * ((NS - NX) * NS * 4);
+    }
     else if (gg < Lay::CH_r) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::CH_c; }
     else if (gg < Lay::CH_F) {   // r: rows of r_cols floats - the chunks past the wave's 4 rows repeat its chunk 0
       base = (const char *)a.r; per = (size_t)rc * 4; g0 = gg - Lay::CH_r < rc ? Lay::CH_r : gg;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
     else if (gg < Lay::CH_du) { base = (const char *)a.dx; per = (size_t)NX * 4; g0 = Lay::CH_dx; }
     else { base = (const char *)a.du; per = (size_t)NU * 4; g0 = Lay::CH_du; }
     const int t0 = isF ? T - 2 : T - 1;
-    ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 - (unsigned long long)(q % 4) * 1024u;
+    ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 + skip - (unsigned long long)(q % 4) * 1024u;
     str[q] = 0ull - (unsigned long long)(B * per);
     str1[q] = isF ? 0ull : str[q];
   }
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
   // per-lane LDS indices (floats, relative to a slot), computed once
   const int i_tau = lane_t < NX ? Lay::OFF_x + r * NX + lane_t : Lay::OFF_u + r * NU + (lane_t - NX);
   const int i_dtau = lane_t < NX ? Lay::OFF_dx + r * NX + lane_t : Lay::OFF_du + r * NU + (lane_t - NX);
-  const int i_crow = Lay::OFF_C + (r * NS + lane_x) * NS;   // row lane_x of C_t
+  const int i_crow = Lay::OFF_C + (r * Lay::kCRows + lane_x) * NS;   // row lane_x of C_t
   const int i_c = Lay::OFF_c + r * NS + lane_x, i_r = Lay::OFF_r + r * rc + lane_x;
   const int i_fcol = Lay::OFF_F + r * NX * NS + lane_x;     // column lane_x of F_t[:, :NX]
   struct Slot {
