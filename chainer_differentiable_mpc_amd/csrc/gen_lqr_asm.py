@@ -290,6 +290,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     Rr = R.take(nu)
     tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = R.take(13)
     MINPIV = R.take(1)[0]
+    QB = R.take(1)[0] if affine else None   # affine: second accumulator of q = c + F^T v
     XV0 = R.take(1)[0]                  # x_init (lanes < nx), loaded by the stream itself
     ACT = [R.take(nu) for _ in range(3)] if masked and not mpc else None   # clamped-control flags of the slot in each register set
     EPS = R.take(1)[0] if masked and not mpc else None
@@ -676,14 +677,62 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         if not mpc:
             P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
 
-    def gains_affine(s):
-        """k_t = -Quu_t^-1 qu in every lane, v_t = qx + Qxu_t k_t in lanes < nx of VV, gain rows [K_t | 0 | k_t] to LDS"""
+    def gains_affine(s, first):
+        """One step of the affine recursion.  The step is a chain of dependent instructions on a wavefront that has its
+        SIMD to itself, so everything that does not depend on v_{t+1} - the factorisation of Quu_t (pivot choice, both
+        reciprocals) - is interleaved with the chain that does, q = c_t + F_t^T v_{t+1} (two accumulators):
+            q = c_t + F_t^T v_{t+1}   k_t = -Quu_t^-1 q_u (every lane)   v_t = q_x + Qxu_t k_t (lanes < nx of G10)
+        and the gain rows [K_t | 0 | k_t] go to LDS for the rollout."""
         Qs = Q[s]
         QUa, KK = W[0:nu], W[2:2 + nu]
         Aa = [[Qs[AQU + m * nu + l] for l in range(nu)] for m in range(nu)]
+        S_PIV = "s[86:87]"
+        fact, qch = [], []
+        if nu == 1:
+            fact.append(lambda: P.v("v_rcp_f32_e32 %s, %s" % (tRP, Aa[0][0]), writes=(tRP,), reads=(Aa[0][0],), trans=True))
+            fact.append(lambda: P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, Aa[0][0], tRP), writes=(tT,), reads=(Aa[0][0], tRP)))
+            fact.append(lambda: P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP)))
+        else:
+            a00, a01, a10, a11 = Aa[0][0], Aa[0][1], Aa[1][0], Aa[1][1]
+            fact.append(lambda: P.v("v_cmp_gt_f32_e64 %s, |%s|, |%s|" % (S_PIV, a10, a00), reads=(a10, a00)))
+            fact.append(lambda: P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (tP, a00, a10, S_PIV), writes=(tP,), reads=(a00, a10)))
+            fact.append(lambda: P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (tL0, a10, a00, S_PIV), writes=(tL0,), reads=(a00, a10)))
+            fact.append(lambda: P.v("v_rcp_f32_e32 %s, %s" % (tRP, tP), writes=(tRP,), reads=(tP,), trans=True))
+            fact.append(lambda: P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (tPQ, a01, a11, S_PIV), writes=(tPQ,), reads=(a01, a11)))
+            fact.append(lambda: P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (tM1, a11, a01, S_PIV), writes=(tM1,), reads=(a01, a11)))
+            fact.append(lambda: P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT, tP, tRP), writes=(tT,), reads=(tP, tRP)))
+            fact.append(lambda: P.v("v_fmac_f32_e32 %s, %s, %s" % (tRP, tT, tRP), writes=(tRP,), reads=(tT, tRP)))
+            fact.append(lambda: P.v("v_mul_f32_e32 %s, %s, %s" % (tLL, tL0, tRP), writes=(tLL,), reads=(tL0, tRP)))
+            fact.append(lambda: P.v("v_fma_f32 %s, -%s, %s, %s" % (tD2, tLL, tPQ, tM1), writes=(tD2,), reads=(tLL, tPQ, tM1)))
+            fact.append(lambda: P.v("v_rcp_f32_e32 %s, %s" % (tRD, tD2), writes=(tRD,), reads=(tD2,), trans=True))
+            fact.append(lambda: P.v("v_fma_f32 %s, -%s, %s, 1.0" % (tT2, tD2, tRD), writes=(tT2,), reads=(tD2, tRD)))
+            fact.append(lambda: P.v("v_fmac_f32_e32 %s, %s, %s" % (tRD, tT2, tRD), writes=(tRD,), reads=(tT2, tRD)))
+        if not first:       # q = c_t + F_t^T v_{t+1}: lane j takes column j of F_t, v_{t+1}[k] broadcast from lane k  (:92)
+            for k in range(nx):
+                if k == 1:
+                    qch.append(lambda k=k: P.mul_dpp(QB, G10, F[s][k], k))
+                elif k % 2 == 1:
+                    qch.append(lambda k=k: P.fmac_dpp(QB, G10, F[s][k], k))
+                else:
+                    qch.append(lambda k=k: P.fmac_dpp(Qs[0], G10, F[s][k], k))
+        while fact or qch:
+            if qch:
+                qch.pop(0)()
+            if fact:
+                fact.pop(0)()
+        if not first and nx > 1:
+            P.v("v_add_f32_e32 %s, %s, %s" % (Qs[0], QB, Qs[0]), writes=(Qs[0],), reads=(QB, Qs[0]))
         for m in range(nu):
             P.mov_dpp(QUa[m], Qs[0], nx + m)
-        neg_solve(Aa, QUa, KK)
+        if nu == 1:
+            P.v("v_mul_f32_e64 %s, %s, -%s" % (KK[0], QUa[0], tRP), writes=(KK[0],), reads=(QUa[0], tRP))
+        else:                # the back half of neg_solve (LAPACK getrs order)
+            P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (tRA, QUa[0], QUa[1], S_PIV), writes=(tRA,), reads=(QUa[0], QUa[1]))
+            P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (tRB, QUa[1], QUa[0], S_PIV), writes=(tRB,), reads=(QUa[0], QUa[1]))
+            P.v("v_fma_f32 %s, -%s, %s, %s" % (tY1, tLL, tRA, tRB), writes=(tY1,), reads=(tLL, tRA, tRB))
+            P.v("v_mul_f32_e64 %s, %s, -%s" % (KK[1], tY1, tRD), writes=(KK[1],), reads=(tY1, tRD))
+            P.v("v_fma_f32 %s, %s, %s, %s" % (tT2, tPQ, KK[1], tRA), writes=(tT2,), reads=(tPQ, KK[1], tRA))
+            P.v("v_mul_f32_e64 %s, %s, -%s" % (KK[0], tT2, tRP), writes=(KK[0],), reads=(tT2, tRP))
         P.v("v_fma_f32 %s, %s, %s, %s" % (G10, Qs[AQX], KK[0], Qs[0]), writes=(G10,), reads=(Qs[AQX], KK[0], Qs[0]))
         for m in range(1, nu):
             P.v("v_fmac_f32_e32 %s, %s, %s" % (G10, Qs[AQX + m], KK[m]), writes=(G10,), reads=(Qs[AQX + m], KK[m], G10))
@@ -736,12 +785,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                            writes=(tmp[i],), reads=(tmp[i],), dpp=tmp[i])
             for i in range(ns):
                 P.v("v_fmac_f32_e32 %s, %s, %%[eaff]" % (Q[s][i], tmp[i]), writes=(Q[s][i],), reads=(tmp[i], Q[s][i]))
-        if affine and not first:
-            # q = c_t + F_t^T v_{t+1}: lane j takes column j of F_t, v_{t+1}[k] broadcast from lane k    (:92)
-            for k in range(nx):
-                P.fmac_dpp(Q[s][0], G10, F[s][k], k)
-        elif affine:
-            pass
+        if affine:
+            pass    # (all of the step's arithmetic comes after the reads of the next step have been issued: gains_affine)
         elif not first and mfma:
             # Q~ += F~^T V^ F^ as (V^^T F^)^T F^ - both products have the A^T B shape that an outer-product MFMA
             # computes from column-per-lane registers (A operand = 4 lanes of a register = 4 rows of A^T):
@@ -805,7 +850,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             P.raw("s_add_u32 s%d, s%d, %d" % (lo, lo, BSTUB))
             P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
         if affine:
-            gains_affine(s)
+            gains_affine(s, first)
             return
         if not first and mfma:
             #   Q~[i][j] += sum_b G[b][i] F~[b][j] + g1[i] e_aff[j]    tiles of 4 rows i: A = G[b] block i/4, B = F~[b]
@@ -836,11 +881,11 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     BSTUB = 32     # bytes per backward stub (two LDS reads + s_setpc_b64 = 20)
     assert 8 * len(L.stash_pieces) + 4 <= BSTUB
 
-    TS = R.take(4) if X_TIMING else []
+    TS = R.take(4) if X_TIMING and not mpc else []     # (the mpc streams have no registers left for the stamps)
     last_vgpr = R.next - 1
 
     def stamp(i):
-        if X_TIMING:
+        if TS:
             P.raw("s_memtime s[86:87]")
             P.raw("s_waitcnt lgkmcnt(0)")
             P.v("v_mov_b32_e32 %s, s86" % TS[i], writes=(TS[i],))
@@ -1201,7 +1246,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     outs = [("xvout", '"=&v"(xvout)'), ("minpiv", '"=&v"(minpiv)')]
     if mpc:
         outs += [("nqp", '"=&v"(nqp)'), ("qpinfo", '"=&v"(qpinfo)')]
-    if X_TIMING:
+    if TS:
         outs += [("ts%d" % i, '"=&v"(in.ts[%d])' % i) for i in range(4)]
     rw = []
     for q in range(L.ndma_b):

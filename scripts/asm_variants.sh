@@ -15,5 +15,5 @@ wait
 for spec in "$@"; do
   name=${spec%%:*}
   echo "== $name (${spec#*:})"
-  DMPC_LIB=/tmp/var/lib_$name.so python ${SCRIPT:-scripts/phase_timing.py} $ARGS 2>&1 | grep -E "fused|rror|cycles"
+  DMPC_LIB=/tmp/var/lib_$name.so python ${SCRIPT:-scripts/phase_timing.py} $ARGS 2>&1 | grep -E "${PATTERN:-fused|rror|cycles}"
 done
