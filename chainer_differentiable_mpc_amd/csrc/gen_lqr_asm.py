@@ -288,7 +288,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     A = [R.take(nu, align=2 if save and nu == 2 and m_ == 0 else 1) for m_ in range(nu)]   # save: Quu leaves as one dwordx4
     Kt = R.take(nu)
     Rr = R.take(nu)
-    tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = R.take(13)
+    tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = TMP13 = R.take(13, align=2 if expand else 1)
     MINPIV = R.take(1)[0]
     QB = R.take(1)[0] if affine else None   # affine: second accumulator of q = c + F^T v
     XV0 = R.take(1)[0]                  # x_init (lanes < nx), loaded by the stream itself
@@ -427,6 +427,18 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         elif masked:
             for m in range(nu):
                 P.raw("ds_read_u8 %s, %%[am] offset:%d" % (ACT[s][m], off + PADM + m))
+
+    def read_ct(slot):
+        """expand: row min(lane, ns-1) of C_t of the slot into the temporaries (lane i: C[i][0..ns-1]) - the operand of the
+        re-centring C tau at the top of the step that consumes the slot; issued where the temporaries are idle (end of
+        the step before), waited for by that step's first s_waitcnt lgkmcnt(0)"""
+        off = slot * L.SLOT_B
+        if ns % 2 == 0:
+            for k in range(0, ns, 2):
+                P.raw("ds_read_b64 %s, %%[act] offset:%d" % (vrange(TMP13[k:k + 2]), off + k * 4))
+        else:
+            for k in range(ns):
+                P.raw("ds_read_b32 %s, %%[act] offset:%d" % (TMP13[k], off + k * 4))
 
     S_ACT = ["s[92:93]", "s[94:95]"]
     QP_REG = "0x2d2febff"       # 1e-11f  (pnqp.py:73)
@@ -773,18 +785,21 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         issue_group(ptr, s, L.SLOT_B, gap="s_waitcnt lgkmcnt(0)")   # the slot's last reads are in before it is refilled
         advance(ptr, strd, by_steps_left=DB if first else DB + 1)
         if expand:
-            # c_hat = C tau + c: the products of a row of C with tau sit in lanes 0..ns-1, four row rotations sum them
-            # into every lane (group_sum of colwise.hpp, same order), the affine lane adds the sum to c
-            tmp = [tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2][:ns]
-            P.v("v_cndmask_b32_e64 %s, 0, %s, %s" % (TAU[s], TAU[s], S_SM), writes=(TAU[s],), reads=(TAU[s],))
+            # c_hat = c + C tau: lane i holds row i of C_t (read_ct), tau_k comes from lane k of TAU by a DPP broadcast -
+            # two accumulators; then entry i of the sum goes to the affine lane of row i of Q~ (one DPP FMA against e_aff).
+            # (Until round 2's last day the rows of Q~ - columns per lane - were multiplied by tau and summed across the
+            # lanes by four rotations each: 61 instructions instead of 2 ns + 2 and ns / 2 LDS reads.)
+            assert ns + 2 <= len(TMP13)
+            ACCA, ACCB = TMP13[ns], TMP13[ns + 1]
+            P.mul_dpp(ACCA, TAU[s], TMP13[0], 0)
+            if ns > 1:
+                P.mul_dpp(ACCB, TAU[s], TMP13[1], 1)
+            for k in range(2, ns):
+                P.fmac_dpp(ACCA if k % 2 == 0 else ACCB, TAU[s], TMP13[k], k)
+            if ns > 1:
+                P.v("v_add_f32_e32 %s, %s, %s" % (ACCA, ACCB, ACCA), writes=(ACCA,), reads=(ACCA, ACCB))
             for i in range(ns):
-                P.v("v_mul_f32_e32 %s, %s, %s" % (tmp[i], Q[s][i], TAU[s]), writes=(tmp[i],), reads=(Q[s][i], TAU[s]))
-            for rot in (8, 4, 2, 1):
-                for i in range(ns):
-                    P.valu("v_add_f32_dpp %s, %s, %s row_ror:%d row_mask:0xf bank_mask:0xf" % (tmp[i], tmp[i], tmp[i], rot),
-                           writes=(tmp[i],), reads=(tmp[i],), dpp=tmp[i])
-            for i in range(ns):
-                P.v("v_fmac_f32_e32 %s, %s, %%[eaff]" % (Q[s][i], tmp[i]), writes=(Q[s][i],), reads=(tmp[i], Q[s][i]))
+                P.fmac_dpp(Q[s][i], ACCA, "%[eaff]", i)
         if affine:
             pass    # (all of the step's arithmetic comes after the reads of the next step have been issued: gains_affine)
         elif not first and mfma:
@@ -868,6 +883,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 for i in order:
                     P.fmac_dpp(Q[s][i], F[s][k], W[k], i)
         gains(s, first)
+        if expand:
+            read_ct(n)       # (the last step reads a slot nobody consumes)
         vupdate(s)
 
     n_step_stores = 0      # global stores per backward step (not mpc)
@@ -988,6 +1005,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         P.raw("s_cbranch_scc1 Lwarm_%=")
     P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * NDB_ALL + n_extra))
     read_set(0, 0)
+    if expand:
+        read_ct(0)
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
     P.comment("---- t = T-1")
     stamp(1)
@@ -1292,7 +1311,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if mpc:
         ins.append(("nqp_iter", '"s"(in.n_qp_iter)'))
     if expand:
-        ins.append(("atau", '"v"(in.atau)'))
+        ins += [("atau", '"v"(in.atau)'), ("act", '"v"(in.act)')]
     clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
         ['"s%d"' % i for i in ([70] + list(range(72, 102 if (mpc or affine) else (100 if save else 98))))] + ['"vcc"', '"scc"', '"memory"']
 
@@ -1369,6 +1388,7 @@ struct LqrAsmIn {
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
   unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
   int n_qp_iter;                     // mpc (wave-uniform): iteration cap of the box QP
+  unsigned act;                      // mpc, expand: LDS byte address (ring slot 0) of row min(lane, ns-1) of this trajectory's C_t
   unsigned atau;                     // mpc, expand: LDS byte address (ring slot 0, without the padding offset) of [x_t; u_t][lane]
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride

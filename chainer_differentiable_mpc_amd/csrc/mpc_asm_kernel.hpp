@@ -57,8 +57,10 @@ __device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, cons
     in.pm = reinterpret_cast<uint64_t>(base + ((size_t)(T - 1) * B + (size_t)b0) * per + j) - (uint64_t)G::PADM;
     in.dm = (uint64_t)0 - (uint64_t)(B * per * 4);
     in.am = ring + (unsigned)(r * NU * 4);
-    if constexpr (EXPAND)   // lane j < nx: x_t[j], lane nx + m: u_t[m] (the other lanes are masked off in the stream)
+    if constexpr (EXPAND) {  // lane j < nx: x_t[j], lane nx + m: u_t[m] (the stream broadcasts from lanes < ns only)
       in.atau = ring + (unsigned)((lane < NX ? n_u + r * NX + lane : (lane < NS ? r * NU + (lane - NX) : 0)) * 4);
+      in.act = ring + (unsigned)(G::OFF_C + (r * NS + (lane < NS ? lane : NS - 1)) * NS * 4);   // row `lane` of C_t
+    }
   }
   G::issue_first(in);  // the first DMA groups leave now; the rest of the set-up overlaps their flight
   lqr_asm_row_addresses<NX, NU, G>(in, ring, r, lane);
