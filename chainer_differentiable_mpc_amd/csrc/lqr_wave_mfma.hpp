@@ -10,7 +10,8 @@
 //   reference's own association  Q~ = C~ + (F^T V) F~  (lqr_recursion.py:89,96) both products have that shape:
 //       G  = V^^T F~        rows b = columns of [V|v] (tile TA, row 0 is the homogeneous row g1 = v^T F~)
 //       Q~ += G^T F~ + g1 (x) e_aff
-//   and so has Qxu K~ of the value update once Qxu is held as a row matrix XU = (F~^T G)[u rows] (same pass).
+//   and so has Qxu K~ of the value update once Qxu is held as a row matrix XU (lane i = Q[i][nx+m]): the control lanes
+//   write their columns of the finished x rows to LDS and lane i reads row i back (1 KB per wavefront).
 //
 // fp32 MFMA runs on the same FMA lanes as the VALU (their times add up, profiles/r01/microbench_mfma16_shadow.txt),
 // so a timestep costs (MFMAs x 8 + other instructions x 4) cycles plus whatever latency is exposed.  Round 2 removes
@@ -178,7 +179,6 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
   const bool k_lane = lane < NX || col_aff;
   const float eaff = col_aff ? 1.f : 0.f;
   const int voff_col = lane < NS ? lane * 4 : kOutOfRange;                  // column `lane` of a row of C / F
-  const int voff_xu = lane < NX ? lane * NS * 4 + NX * 4 : kOutOfRange;     // row `lane` of C, control columns
   float *Ks = a.Ks != nullptr ? a.Ks : a.wsK;
   float *ks = a.Ks != nullptr ? a.ks : a.wsk;
   int info_bits = 0;
@@ -186,7 +186,6 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
   struct Bank {
     f4v Q4[TS];    // rows of [C_t | c_t], column-per-lane
     float Fc[NX];  // rows of [F_t | f_t]
-    f4v XU4[TU];   // XU[m] = column nx+m of C_t's x rows as a ROW (lane i = C[i][nx+m])
     unsigned act;  // MASKED: bit m = control m is clamped at this step
   };
 
@@ -198,9 +197,6 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
     const size_t tb = (size_t)t * B + b;
     const __amdgpu_buffer_rsrc_t rc = wave_rsrc(a.C + tb * NS * NS, NS * NS * 4);
     static_for<0, NS>([&](auto i) { k.Q4[i.value / 4][i.value % 4] = wave_load<i.value * NS * 4>(rc, voff_col); });
-    static_for<0, TU>([&](auto q) {
-      k.XU4[q.value] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rc, voff_xu + 16 * q.value, 0, 0));
-    });
     if (col_aff) {   // the affine column: c_t is a contiguous run, fetched by lane ns alone
       const f4v *cp = reinterpret_cast<const f4v *>(a.c + tb * NS);
 #pragma unroll
@@ -228,6 +224,8 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
     }
   };
 
+  __shared__ float xu_all[4][NX * NU];   // per wavefront: Qxu of the current step, [i][m]
+  float *xu_lds = xu_all[threadIdx.x >> 6];
   f4v V4[TX];  // rows of [V | v]
 #pragma unroll
   for (int I = 0; I < TX; ++I) V4[I] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -255,12 +253,11 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
       DMPC_STAMP(2);
       if constexpr (DMPC_WAVE_PREFETCH) fetch_dyn(t - 1, next);
       DMPC_STAMP(1);
-      // ---- Q~ += G^T F~ + g1 (x) e_aff ;  XU += (F~^T G)[u rows]
+      // ---- Q~ += G^T F~ + g1 (x) e_aff
       static_for<0, NX>([&](auto b_) {
         const float gb = G4[b_.value / 4][b_.value % 4];
         const float fb = k.Fc[b_.value];
         static_for<0, TS>([&](auto I) { Q4[I.value] = mfma_bcast<I.value>(gb, fb, Q4[I.value]); });
-        static_for<0, TU>([&](auto q) { k.XU4[q.value] = mfma_bcast<TX + q.value>(fb, gb, k.XU4[q.value]); });
       });
       {
         const float g1 = G4[TX][0];
@@ -268,6 +265,12 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
       }
     }
     DMPC_STAMP(3);
+    // ---- Qxu as a row matrix for the value update (XU[m]: lane i = Q[i][nx+m]): the control lanes write their column
+    // of the finished x rows to LDS, lane i reads row i back after the gain solve - a transpose through 1 KB of LDS per
+    // wavefront instead of 64 more MFMAs per step accumulating (F~^T G)[u rows] (round 2, first version)
+    if (t > 0 && lane >= NX && lane < NS) {
+      static_for<0, NX>([&](auto i) { xu_lds[i.value * NU + (lane - NX)] = Q4[i.value / 4][i.value % 4]; });
+    }
     // ---- gains (:112-120): Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie.  Row m is one register
     // across the lanes; the multiplier of row i at pivot k is ONE lane of it (lane nx+k).
     float Kr[NU];
@@ -338,8 +341,10 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma
       // ---- value update (:151-152): V~ = Q~x. + Qxu K~ (+ K~^T (Q~u. + Quu K~) when the gains are masked)
 #pragma unroll
       for (int I = 0; I < TX; ++I) V4[I] = Q4[I];
+      f4v XU4[TU];
+      static_for<0, TU>([&](auto q) { XU4[q.value] = reinterpret_cast<const f4v *>(xu_lds + (lane < NX ? lane : 0) * NU)[q.value]; });
       static_for<0, NU>([&](auto m) {  // Qxu K~ = XU^T K~, the A^T B shape
-        const float xm = k.XU4[m.value / 4][m.value % 4];
+        const float xm = XU4[m.value / 4][m.value % 4];
         static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(xm, Kt[m.value], V4[I.value]); });
       });
       if constexpr (MASKED) {
