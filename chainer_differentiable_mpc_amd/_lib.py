@@ -91,14 +91,38 @@ def require_gpu():
 
 
 def ptr(t):
-    """device pointer of a tensor (None -> NULL)"""
+    """device pointer of a tensor (None -> NULL); a plain int - ctypes converts it for a c_void_p parameter"""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream_ptr(device=None):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's current HIP stream on `device` as the C-ABI's dmpc_stream_t"""
+    if _raw_stream is not None and device is not None and device.index is not None:
+        return _raw_stream(device.index)     # (the public accessor builds a Stream object: ~4 us per call)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def guard(device):
+    """`with guard(dev):` - make `dev` the current device for the launches inside; free when it already is"""
+    if device.index is None or torch.cuda.current_device() == device.index:
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 _ERR = {E_BADARG: "bad argument (NULL pointer, non-positive size or a base pointer that is not 16-byte aligned)",

@@ -92,7 +92,7 @@ class BoxDDP(torch.nn.Module):
             B, nx, nu = x_init.shape[0], x_init.shape[1], u.shape[2]
             x0, ud, F, f = _lib.f32c(x_init, d), _lib.f32c(u, d), _lib.f32c(dyn.F, d), _lib.f32c(dyn.f, d)
             x = torch.empty((T, B, nx), dtype=torch.float32, device=d)
-            with torch.cuda.device(d):
+            with _lib.guard(d):
                 rc = lib.dmpc_lin_rollout(T, B, nx, nu, _lib.ptr(x0), _lib.ptr(ud), _lib.ptr(F), _lib.ptr(f),
                                           _lib.ptr(x), _lib.stream_ptr(d))
             _lib.check(rc, "dmpc_lin_rollout")
@@ -136,7 +136,7 @@ class BoxDDP(torch.nn.Module):
         info, state = ints[:B], ints[B:]
         need = lib.dmpc_box_ddp_workspace_bytes(T, B, nx, nu)
         ws = _workspace(need, d)
-        with torch.cuda.device(d):
+        with _lib.guard(d):
             rc = lib.dmpc_box_ddp(T, B, nx, nu, _lib.ptr(x0), _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), kind,
                                   None if params is None else ctypes.cast(params, ctypes.c_void_p), _lib.ptr(u0),
                                   _lib.ptr(lo_), _lib.ptr(hi_), float(self.eps), int(self.not_improved_lim),

@@ -42,7 +42,7 @@ def kkt_grad_device(C, c, F, x, u, grad_x, grad_u, T, n_state, n_ctrl, strict_ma
     df = torch.empty((T - 1, B, nx), **f32) if need_df else None
     need = lib.dmpc_lqr_kkt_workspace_bytes(T, B, nx, nu)
     ws = _workspace(need, dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         rc = _lib.E_UNSUPPORTED
         if saved is not None:
             Ks, Quu, Qxu = saved

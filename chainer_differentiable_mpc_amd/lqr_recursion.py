@@ -96,7 +96,7 @@ class LqrRecursion:
         Ks = torch.empty((T, B, nu, nx), dtype=torch.float32, device=self._dev)
         ks = torch.empty((T, B, nu), dtype=torch.float32, device=self._dev)
         info = self._new_info()
-        with torch.cuda.device(self._dev):
+        with _lib.guard(self._dev):
             _lib.check(lib.dmpc_lqr_backward_sweep(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F),
                                                    _lib.ptr(f), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks),
                                                    _lib.ptr(info), _lib.stream_ptr(self._dev)),
@@ -118,7 +118,7 @@ class LqrRecursion:
         x = torch.empty((T, B, nx), dtype=torch.float32, device=self._dev)
         u = torch.empty((T, B, nu), dtype=torch.float32, device=self._dev)
         info = self._new_info()
-        with torch.cuda.device(self._dev):
+        with _lib.guard(self._dev):
             _lib.check(lib.dmpc_lqr_forward_sweep(T, B, nx, nu, _lib.ptr(Kd), _lib.ptr(kd), _lib.ptr(F),
                                                   _lib.ptr(f), _lib.ptr(x0), _lib.ptr(mask), _lib.ptr(x),
                                                   _lib.ptr(u), _lib.ptr(info), _lib.stream_ptr(self._dev)),
@@ -170,7 +170,7 @@ def solve_saving_device(C, c, F, f, x_init, T, n_state, n_ctrl, info=None):
     ks = torch.empty((T, B, nu), **f32)
     Quu = torch.empty((T, B, nu, nu), **f32)
     Qxu = torch.empty((T, B, nx, nu), **f32)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         rc = lib.dmpc_lqr_solve_saving(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(x_init),
                                        _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(x), _lib.ptr(u),
                                        _lib.ptr(info), _lib.stream_ptr(dev))
@@ -188,7 +188,7 @@ def saved_solve_device(c, F, Ks, Quu, Qxu, x_init, T, n_state, n_ctrl, info=None
     B = c.shape[1]
     x = torch.empty((T, B, n_state), dtype=torch.float32, device=dev)
     u = torch.empty((T, B, n_ctrl), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         rc = lib.dmpc_lqr_saved_solve(T, B, n_state, n_ctrl, _lib.ptr(c), _lib.ptr(F), _lib.ptr(Ks), _lib.ptr(Quu),
                                       _lib.ptr(Qxu), _lib.ptr(x_init), _lib.ptr(x), _lib.ptr(u), _lib.ptr(info),
                                       _lib.stream_ptr(dev))
@@ -221,7 +221,7 @@ def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False,
     if not want_gains and (per_traj_lds * 16 > 60 * 1024 or lib.dmpc_lqr_kernel_family(nx, nu) != 1):
         ws = _workspace(need, dev)
         ws_bytes = need
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         rc = lib.dmpc_lqr_solve(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f),
                                 _lib.ptr(x_init), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(x),
                                 _lib.ptr(u), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(dev))

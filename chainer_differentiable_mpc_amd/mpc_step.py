@@ -144,7 +144,7 @@ class MPCstep:
         if self.batch_coupled:
             need = lib.dmpc_coupled_workspace_bytes(T, self.n_qp_iter_max)
             ws = _workspace(need, d)
-        with torch.cuda.device(d):
+        with _lib.guard(d):
             rc = lib.dmpc_mpc_backward_rec(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f),
                                            _lib.ptr(self._u), _lib.ptr(self._lo), _lib.ptr(self._hi),
                                            self.n_qp_iter_max, 1 if self.batch_coupled else 0, _lib.ptr(Ks),
@@ -178,7 +178,7 @@ class MPCstep:
             objs = torch.empty((T, B), **f32)
             nls = torch.empty((B,), dtype=torch.int32, device=d)
             info = torch.zeros(B, dtype=torch.int32, device=d)
-            with torch.cuda.device(d):
+            with _lib.guard(d):
                 rc = lib.dmpc_mpc_forward_rec(T, B, nx, nu, _lib.ptr(Kd), _lib.ptr(kd), _lib.ptr(self._u),
                                               _lib.ptr(self._xs), _lib.ptr(self._lo), _lib.ptr(self._hi),
                                               _lib.ptr(Ct), _lib.ptr(ct), _lib.ptr(Ft), _lib.ptr(ft),
@@ -198,7 +198,7 @@ class MPCstep:
             objs = torch.empty((T, B), **f32)
             nls = torch.empty((B,), dtype=torch.int32, device=d)
             info = torch.zeros(B, dtype=torch.int32, device=d)
-            with torch.cuda.device(d):
+            with _lib.guard(d):
                 rc = lib.dmpc_mpc_forward_rec_pendulum(
                     T, B, _lib.ptr(Kd), _lib.ptr(kd), _lib.ptr(self._u), _lib.ptr(self._xs), _lib.ptr(self._lo),
                     _lib.ptr(self._hi), _lib.ptr(Ct), _lib.ptr(ct), g_, m_, l_, float(true_dynamics.dt),
@@ -315,7 +315,7 @@ class MPCstep:
             info = torch.zeros(B, dtype=torch.int32, device=d)
             need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
             ws = _workspace(need, d)
-            with torch.cuda.device(d):
+            with _lib.guard(d):
                 rc = lib.dmpc_mpc_step_forward(
                     T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(self._u),
                     _lib.ptr(self._xs), _lib.ptr(self._lo), _lib.ptr(self._hi), _lib.ptr(Ct), _lib.ptr(ct),
@@ -380,7 +380,7 @@ class MPCstep:
         info = torch.zeros(B, dtype=torch.int32, device=d)
         need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
         ws = _workspace(need, d)
-        with torch.cuda.device(d):
+        with _lib.guard(d):
             rc = lib.dmpc_mpc_step_backward(T, B, nx, nu, _lib.ptr(r["C"]), _lib.ptr(r["c"]), _lib.ptr(r["F"]),
                                             _lib.ptr(r["x"]), _lib.ptr(r["u"]), _lib.ptr(self._lo), _lib.ptr(self._hi),
                                             _lib.ptr(gx), _lib.ptr(gu), _lib.ptr(dx0), _lib.ptr(dC), _lib.ptr(dc),

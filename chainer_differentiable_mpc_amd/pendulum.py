@@ -104,7 +104,7 @@ class PendulumDx(torch.nn.Module):
         F = torch.empty((max(T - 1, 0), B, 3, 4), dtype=torch.float32, device=d) if want_model else None
         f = torch.empty((max(T - 1, 0), B, 3), dtype=torch.float32, device=d) if want_model else None
         g_, m_, l_ = self.host_params()
-        with torch.cuda.device(d):
+        with _lib.guard(d):
             rc = lib.dmpc_pendulum_rollout_linearize(T, B, _lib.ptr(x0), _lib.ptr(ud), g_, m_, l_, float(self.dt),
                                                      float(self.max_torque), _lib.ptr(x), _lib.ptr(F), _lib.ptr(f),
                                                      _lib.stream_ptr(d))

@@ -42,7 +42,7 @@ def pnqp_device(H, q, lower, upper, x_init, n_iter, info=None, batch_coupled=Fal
     if batch_coupled:
         need = lib.dmpc_coupled_workspace_bytes(1, int(n_iter))
         ws = _workspace(need, dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         rc = lib.dmpc_pnqp(B, n, _lib.ptr(H), _lib.ptr(q), _lib.ptr(lower), _lib.ptr(upper), _lib.ptr(x_init),
                            int(n_iter), 1 if batch_coupled else 0, _lib.ptr(x), _lib.ptr(fac), _lib.ptr(piv),
                            _lib.ptr(idx_f), _lib.ptr(iters), _lib.ptr(ws), need, _lib.ptr(info), _lib.stream_ptr(dev))

@@ -91,7 +91,7 @@ def batch_lu_factor(A):
     B, n, _ = a.shape
     LU = torch.empty_like(a)
     piv = torch.empty((B, n), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         _lib.check(lib.dmpc_batch_lu_factor(B, n, _lib.ptr(a), _lib.ptr(LU), _lib.ptr(piv), None,
                                             _lib.stream_ptr(dev)), "dmpc_batch_lu_factor")
     return LU.to(A.device), piv.to(A.device)
@@ -109,7 +109,7 @@ def batch_lu_solve(lu_and_piv, b):
     rhs = _lib.f32c(b.unsqueeze(2) if vec else b, dev)
     B, n, k = rhs.shape
     x = torch.empty_like(rhs)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         _lib.check(lib.dmpc_batch_lu_solve(B, n, k, _lib.ptr(lu), _lib.ptr(pv), _lib.ptr(rhs), _lib.ptr(x),
                                            _lib.stream_ptr(dev)), "dmpc_batch_lu_solve")
     x = x.squeeze(2) if vec else x
