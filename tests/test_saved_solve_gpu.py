@@ -165,3 +165,26 @@ def test_saving_solve_flags_a_singular_quu_per_trajectory():
     solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu, info=info)
     got = npy(info)
     assert got[5] != 0 and (np.delete(got, 5) == 0).all(), got
+
+
+@pytest.mark.parametrize("T", [2, 3, 51, 52, 53])
+def test_horizon_boundaries_of_the_stash(T):
+    """the affine stream keeps F in the accumulation registers: T = 2 (one F block), the last horizons that fit and the
+    first that does not (the plain pair takes over there) give the same gradient as the full second solve"""
+    B, nx, nu = 8, 8, 2
+    p, d = _problem(B, T, nx, nu, True, seed=31 + T)
+    rng = np.random.RandomState(T)
+    gx = torch.as_tensor(rng.randn(T, B, nx), dtype=torch.float32).cuda()
+    gu = torch.as_tensor(rng.randn(T, B, nu), dtype=torch.float32).cuda()
+    a, b = DiffLqr(T, B, nx, nu), DiffLqr(T, B, nx, nu, save_gains=False)
+    a.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    b.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert (a._retained["saved"] is not None) == saving_solve_available(T, B, nx, nu)
+    oa, ob = a.backward((0, 1, 2, 3, 4), (gx, gu)), b.backward((0, 1, 2, 3, 4), (gx, gu))
+    for ga, gb, key in zip(oa, ob, KEYS):
+        assert_close(npy(ga), npy(gb), 1e-4, key)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, npy(gx).astype(np.float64),
+                                npy(gu).astype(np.float64), T, nx, nu)
+    for got, want, key in zip(oa, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)
