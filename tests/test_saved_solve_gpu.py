@@ -188,3 +188,23 @@ def test_horizon_boundaries_of_the_stash(T):
                                 npy(gu).astype(np.float64), T, nx, nu)
     for got, want, key in zip(oa, ref, KEYS):
         assert_close(npy(got), want, TOLS[key], key)
+
+
+@pytest.mark.parametrize("use_saved", [True, False])
+@pytest.mark.parametrize("skip", [("dC",), ("dF",), ("df",), ("dC", "dF", "df")])
+def test_outputs_that_are_not_asked_for_leave_the_others_unchanged(skip, use_saved):
+    """include/dmpc.h: any of dC / dF / df may be NULL - the remaining outputs are the same numbers"""
+    B, T, nx, nu = 8, 12, 8, 2
+    _, d = _problem(B, T, nx, nu, True, seed=9)
+    x, u, Ks, _, Quu, Qxu = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
+    saved = (Ks, Quu, Qxu) if use_saved else None
+    gx, gu = torch.ones_like(x), 0.5 * torch.ones_like(u)
+    full = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu, saved=saved)
+    part = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu, saved=saved, need_dC="dC" not in skip,
+                           need_dF="dF" not in skip, need_df="df" not in skip)
+    torch.cuda.synchronize()
+    for a, b, key in zip(full, part, KEYS):
+        if key in skip:
+            assert b is None
+        else:
+            assert torch.equal(a, b), key
