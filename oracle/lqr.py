@@ -15,7 +15,8 @@ def lqr_backward(C, c, F, f, T, n_state, n_ctrl, blocks=None):
     """Riccati value recursion -> gains.  lqr_recursion.py:69-158.
 
     blocks: an optional dict that receives the control blocks of every step's Q-function, "Quu" [T,B,nu,nu] and
-    "Qxu" [T,B,nx,nu] (:100,102) - what the build's saving solve leaves in HBM next to the gains.
+    "Qxu" [T,B,nx,nu] (:100,102) - what the build's saving solve leaves in HBM next to the gains - and the value
+    function "V" [T,B,nx,nx], "v" [T,B,nx] of every step (:151-152).
 
     Returns Ks [T,B,nu,nx], ks [T,B,nu] in forward time order (the reference returns
     Python lists of the same per-step arrays, :156-158).
@@ -60,6 +61,9 @@ def lqr_backward(C, c, F, f, T, n_state, n_ctrl, blocks=None):
         # :151-152 - no symmetrisation, every term kept
         Vt = Qt_xx + np.matmul(Qt_xu, Kt) + np.matmul(Kt_T, Qt_ux) + np.matmul(np.matmul(Kt_T, Qt_uu), Kt)
         vt = qt_x + bmv(Qt_xu, kt) + bmv(Kt_T, qt_u) + bmv(np.matmul(Kt_T, Qt_uu), kt)
+        if blocks is not None:
+            blocks.setdefault("V", np.zeros((T, B, nx, nx), dtype=Ks.dtype))[t] = Vt
+            blocks.setdefault("v", np.zeros((T, B, nx), dtype=Ks.dtype))[t] = vt
     return Ks, ks
 
 

@@ -1,0 +1,62 @@
+"""CPU: the identity the build's saved-gains path rests on, checked on the oracle alone.  For an LQR problem (C, F) solved
+once, a second problem with the same C and F, another affine cost term and f = 0 (DiffLqr.backward's second solve,
+lqr/differentiable_lqr.py:108-114) has the same gains K_t, and its k_t, v_t follow from the first solve's control blocks:
+    q = c_t + F_t^T v_{t+1},   k_t = -Quu_t^-1 q_u,   v_t = q_x + Qxu_t k_t      (lqr_recursion.py:92,119-120,152)
+- for a non-symmetric C too (Qxu, not the transpose of Qux)."""
+import numpy as np
+import pytest
+
+from chainer_differentiable_mpc_amd import synthetic
+from oracle import lqr as olqr
+
+
+def affine_resolve(c2, F, Ks, Quu, Qxu, x_init, T, nx, nu):
+    B = c2.shape[1]
+    ks = np.zeros((T, B, nu))
+    v = None
+    for t in range(T - 1, -1, -1):
+        q = c2[t] if t == T - 1 else c2[t] + np.einsum("bij,bi->bj", F[t], v)
+        ks[t] = -np.linalg.solve(Quu[t], q[:, nx:, None])[..., 0]
+        v = q[:, :nx] + np.einsum("bim,bm->bi", Qxu[t], ks[t])
+    return olqr.lqr_forward(Ks, ks, x_init, F, None, T, nx, nu)
+
+
+@pytest.mark.parametrize("shape", [(3, 6, 8, 2), (2, 9, 4, 2), (4, 5, 3, 1), (2, 4, 5, 3)])
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_second_solve_from_the_first_solves_blocks(shape, symmetric):
+    B, T, nx, nu = shape
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=4, with_f=True)
+    rng = np.random.RandomState(6)
+    C = p["C"] if symmetric else p["C"] + 0.2 * rng.randn(*p["C"].shape)
+    blocks = {}
+    Ks, _ = olqr.lqr_backward(C, p["c"], p["F"], p["f"], T, nx, nu, blocks=blocks)
+    c2 = rng.randn(T, B, nx + nu)
+    x2 = rng.randn(B, nx)
+    Ks2, _ = olqr.lqr_backward(C, c2, p["F"], None, T, nx, nu)
+    np.testing.assert_allclose(Ks2, Ks, rtol=0, atol=1e-12)                 # the gains do not depend on c (or f)
+    xr, ur = olqr.lqr_solve(x2, C, c2, p["F"], None, T, nx, nu)
+    x, u = affine_resolve(c2, p["F"], Ks, blocks["Quu"], blocks["Qxu"], x2, T, nx, nu)
+    np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(u, ur, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("symmetric", [True, False])
+def test_costate_is_the_value_gradient_along_the_solution(symmetric):
+    """DESIGN.md section 8 (a backward pass that never reads C): the reference's solve is block elimination of its KKT
+    system, so the co-state of DiffLqr.backward (differentiable_lqr.py:87-104: lambda_t = C_t[:nx] tau_t + c_t[:nx] +
+    F_t[:, :nx]^T lambda_{t+1}) equals V_t x_t + v_t along the solution - also for a C that is not symmetric."""
+    B, T, nx, nu = 3, 7, 6, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=8, with_f=True)
+    rng = np.random.RandomState(9)
+    C = p["C"] if symmetric else p["C"] + 0.2 * rng.randn(*p["C"].shape)
+    blocks = {}
+    Ks, ks = olqr.lqr_backward(C, p["c"], p["F"], p["f"], T, nx, nu, blocks=blocks)
+    x, u = olqr.lqr_forward(Ks, ks, p["x_init"], p["F"], p["f"], T, nx, nu)
+    tau = np.concatenate([x, u], axis=2)
+    lam = None
+    for t in range(T - 1, -1, -1):
+        lt = np.einsum("bij,bj->bi", C[t][:, :nx, :], tau[t]) + p["c"][t][:, :nx]
+        if t < T - 1:
+            lt = lt + np.einsum("bij,bi->bj", p["F"][t][:, :, :nx], lam)
+        lam = lt
+        np.testing.assert_allclose(lam, np.einsum("bij,bj->bi", blocks["V"][t], x[t]) + blocks["v"][t], rtol=1e-8, atol=1e-8)
