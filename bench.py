@@ -6,7 +6,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one fused `solve_recursion` (backward Riccati sweep + forward rollout, x and u
-materialised in HBM) over one batch of synthetic trajectories already resident in HBM.  With N
+materialised in HBM) over one batch of synthetic trajectories resident in HBM (not in the Infinity
+Cache: consecutive steps solve different input sets).  With N
 GPUs every rank solves its own shard of B trajectories (independent units, no data-path
 collective; `--gather` adds the RCCL all-gather of (x*, u*) to the timed region), so scaling is
 weak and `value` = N*B*T*K / max-over-ranks time.  Rank 0 prints ONE JSON line.
@@ -14,13 +15,16 @@ weak and `value` = N*B*T*K / max-over-ranks time.  Rank 0 prints ONE JSON line.
 Extra objects in that line:
   roofline     dominant kernel vs the HBM roof: algorithmic bytes per launch (832 B per
                timestep-solve) / average launch duration measured with HIP events on
-               the launch stream over the timed region; peak 8 TB/s (MI355X_MICROARCH.md).
+               the launch stream over the timed region; peak 8 TB/s (MI355X_MICROARCH.md).  The timed
+               loop rotates over input sets (more than twice the 256 MiB Infinity Cache in total), so
+               every step streams its inputs from HBM; `frac_same_inputs` is the launch re-solving one set
+               (what rounds 1-2 reported), `box_copy_gbs` a plain copy on the same box, `kernel` the name
+               the library reports for the last launch (dmpc_last_kernel_name).
   cpu_baseline the numpy float64 oracle (a port of the reference's algorithm; the reference's
                Python cannot travel) timed on this host's cores on a bounded sample: one thread, and
                (`cpu_baseline_mp`) the batch sharded over the host cores this process may use.
   secondary    (N = 1, headline workload) the other numbers of SURVEY.md 8d, each timed with HIP events in this
-               run: the headline solve with inputs streamed from HBM (three input sets in rotation, > the 256 MiB
-               Infinity Cache), DiffLqr forward + KKT backward at config 3, one shard of config 5 ((32,8), B=8192),
+               run: DiffLqr forward + KKT backward at config 3, one shard of config 5 ((32,8), B=8192),
                the MPC step at config 3, config 2's box-DDP solve, config 4's imitation step.
 
 Other invocations (the same JSON contract):
@@ -47,6 +51,7 @@ from chainer_differentiable_mpc_amd.lqr_recursion import solve_device  # noqa: E
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak (MI355X_MICROARCH.md)
 PARITY_TOL = 1e-4
+INFINITY_CACHE_BYTES = 256 * 2 ** 20
 
 WORKLOADS = {
     # name: (B per GPU, T, nx, nu)
@@ -78,114 +83,24 @@ def make_inputs(B, T, nx, nu, seed, device):
     return None, dict(C=C, c=c, F=F, f=f, x_init=x_init)
 
 
-def kernel_name(T, B, nx, nu):
-    """the kernel dmpc_lqr_solve dispatches to at this size (what rocprofv3 --kernel-trace lists)"""
+def kernel_name():
+    """the kernel the last library call of this thread launched, as rocprofv3 --kernel-trace lists it: asked of the
+    library (dmpc_last_kernel_name -> hipKernelNameRefByPtr + demangling), not kept by hand"""
     from chainer_differentiable_mpc_amd import _lib
-    path = _lib.load().dmpc_lqr_solve_path(T, B, nx, nu)
-    # template arguments as rocprofv3 prints them: <nx, nu, has_f, write_k, stash, masked, unroll>; the bench passes f, no
-    # gains.  Back-to-back solves of the headline shape take the stream's unrolled form (csrc/api_util.hpp).
-    import os
-    if path == 4 and (nx, nu) == (8, 2) and os.environ.get("DMPC_NO_UNROLL") != "1":
-        return "void dmpc::lqr_asm_kernel<8, 2, true, false, true, false, true>(dmpc::LqrArgs)"
-    return {0: "dmpc::lqr_generic_kernel", 1: "void dmpc::lqr_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
-            2: "void dmpc::lqr_dma_kernel<%d, %d, ...>(dmpc::LqrArgs)" % (nx, nu),
-            3: "void dmpc::lqr_asm_kernel<%d, %d, true, false, false, false, false>(dmpc::LqrArgs)" % (nx, nu),
-            4: "void dmpc::lqr_asm_kernel<%d, %d, true, false, true, false, false>(dmpc::LqrArgs)" % (nx, nu),
-            5: "void dmpc::lqr_wave_mfma_backward<%d, %d, false, true>(dmpc::LqrArgs)" % (nx, nu)
-            }.get(path, "?")
+    return _lib.last_kernel_name()
 
 
-def cpu_baseline(p, T, nx, nu, budget_s=12.0):
-    """the oracle (kind "port") on this host, float64, one thread; bounded sample"""
-    from oracle import lqr as olqr
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:  # pragma: no cover
-        import contextlib
-        ctx = contextlib.nullcontext()
-    B = p["C"].shape[1]
-    times = []
-    with ctx:
-        t_all = time.perf_counter()
-        while True:
-            t0 = time.perf_counter()
-            xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
-            times.append(time.perf_counter() - t0)
-            if len(times) >= 3 and time.perf_counter() - t_all > budget_s:
-                break
-            if len(times) >= 25:
-                break
-    med = statistics.median(times)
-    return dict(value=B * T / med, unit="timestep-solves/s", cores=1, kind="port",
-                sample="numpy float64 oracle (oracle/lqr.py, restates lqr/lqr_recursion.py), full workload "
-                       "B=%d T=%d, median of %d runs, %d host cores present, BLAS limited to 1 thread"
-                       % (B, T, len(times), os.cpu_count() or 0)), xr, ur
-
-
-_MP_PROBLEM = None
-
-
-def _mp_solve_shard(job):
-    """worker: the oracle on one contiguous batch shard of the fork-inherited problem"""
-    from oracle import lqr as olqr
-    b0, b1, T, nx, nu = job
-    p = _MP_PROBLEM
-    try:
-        from threadpoolctl import threadpool_limits
-        ctx = threadpool_limits(limits=1)
-    except Exception:  # pragma: no cover
-        import contextlib
-        ctx = contextlib.nullcontext()
-    with ctx:
-        x, u = olqr.lqr_solve(p["x_init"][b0:b1], p["C"][:, b0:b1], p["c"][:, b0:b1], p["F"][:, b0:b1],
-                              p["f"][:, b0:b1], T, nx, nu)
-    return float(x.sum() + u.sum())
-
-
-def cpu_baseline_multiprocess(p, T, nx, nu, procs, reps=3):
-    """the same oracle with the batch sharded over `procs` worker processes (fork; started BEFORE this process touches
-    the GPU).  Wall time of one whole-batch solve = the slowest shard; median of `reps`."""
-    import multiprocessing as mp
-    from chainer_differentiable_mpc_amd.dist import shard_bounds
-    global _MP_PROBLEM
-    _MP_PROBLEM = p
-    B = p["C"].shape[1]
-    jobs = [shard_bounds(B, r, procs) + (T, nx, nu) for r in range(procs)]
-    times = []
-    with mp.get_context("fork").Pool(procs) as pool:
-        pool.map(_mp_solve_shard, jobs)          # warm-up: page in numpy in every worker
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            pool.map(_mp_solve_shard, jobs, chunksize=1)
-            times.append(time.perf_counter() - t0)
-    _MP_PROBLEM = None
-    med = statistics.median(times)
-    return dict(value=B * T / med, unit="timestep-solves/s", cores=procs, kind="port",
-                sample="numpy float64 oracle, full workload B=%d T=%d sharded over %d worker processes (one BLAS "
-                       "thread each), median of %d runs; %d host cores present, %d usable by this process"
-                       % (B, T, procs, reps, os.cpu_count() or 0, usable_cores()))
-
-
-def usable_cores():
-    try:
-        return len(os.sched_getaffinity(0))
-    except Exception:  # pragma: no cover
-        return os.cpu_count() or 1
-
-
-def event_time(fn, reps, warm=3):
-    """average duration of fn() in seconds: HIP events on the current stream around `reps` back-to-back calls"""
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / reps
+def hbm_copy_calibration(device, gib=1.0, reps=5):
+    """what THIS box's memory system sustains on the plainest streaming pattern: a device-to-device copy of `gib` GiB
+    (read + write, far beyond the Infinity Cache), GB/s of traffic, median of `reps` - MI355X_MICROARCH.md quotes
+    6.29 TB/s for it; boxes of this pool differ (clocks under load), and the HBM-streamed numbers move with it"""
+    n = int(gib * 2 ** 30) // 4
+    a = torch.empty(n, dtype=torch.float32, device=device).normal_()
+    b = torch.empty_like(a)
+    ts = [event_time(lambda: b.copy_(a), 4, warm=1) for _ in range(reps)]
+    del a, b
+    torch.cuda.empty_cache()
+    return 2 * n * 4 / statistics.median(ts) / 1e9
 
 
 def secondary_metrics(device, d_headline):
@@ -200,20 +115,6 @@ def secondary_metrics(device, d_headline):
     kts = synthetic.kkt_algorithmic_bytes_per_timestep(nx, nu)
     x = torch.empty((T, B, nx), dtype=torch.float32, device=device)
     u = torch.empty((T, B, nu), dtype=torch.float32, device=device)
-    # (i) headline solve, inputs streamed from HBM: three input sets in rotation (3 x 161 MB > 256 MiB Infinity Cache)
-    sets = [d_headline] + [make_inputs(B, T, nx, nu, 100 + s, device)[1] for s in range(2)]
-    k = [0]
-
-    def rot():
-        d = sets[k[0] % 3]
-        k[0] += 1
-        solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u))
-
-    t = event_time(rot, 150, warm=9)
-    out["headline_hbm_streamed"] = {
-        "what": "headline solve, three input sets in rotation (483 MB > Infinity Cache): every launch streams from HBM",
-        "us_per_solve": t * 1e6, "timestep_solves_per_s": B * T / t, "frac_hbm_streamed": bts * B * T / t / 1e9 / HBM_PEAK_GBS}
-    del sets[1:]
     # (ii) DiffLqr forward + backward at config 3: fused solve, then the KKT gradient (second solve + co-state sweeps)
     d = d_headline
     gx, gu = torch.ones_like(x), torch.ones_like(u)
@@ -321,7 +222,7 @@ def secondary_cfg5(device):
     return {"what": "one 8192-trajectory shard of config 5 (B=65536 over 8 GPUs), T=50, (32,8), fused solve",
             "ms_per_solve": t * 1e3, "timestep_solves_per_s": B * T / t, "algorithmic_bytes": bts * B * T,
             "frac_hbm": bts * B * T / t / 1e9 / HBM_PEAK_GBS,
-            "frac_mfma_f32": flops * B * T / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernel": kernel_name(T, B, nx, nu)}
+            "frac_mfma_f32": flops * B * T / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernel": kernel_name()}
 
 
 def main():
@@ -336,6 +237,8 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the sharded CPU baseline "
                     "(default: the cores this process may use, at most 16 - a one-GPU box's CPU share)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--allow-secondary-failure", action="store_true",
+                    help="exit 0 even when a secondary measurement raised (its error string is in the JSON line either way)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -369,6 +272,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     p, d = make_inputs(B, T, nx, nu, seed=rank, device=device)
+    # "Inputs resident in HBM when the timed region starts" - in HBM, not in the 256 MiB Infinity Cache: where one input
+    # set would fit the cache, the timed loop rotates over enough sets (more than twice the cache, at most 8) that every
+    # step streams its inputs from HBM.  Set 0 (seed = rank) is the one the CPU oracle solves.
+    set_bytes = sum(v.numel() * v.element_size() for v in d.values())
+    n_sets = 1 if set_bytes >= 2 * INFINITY_CACHE_BYTES else min(8, -(-2 * INFINITY_CACHE_BYTES // set_bytes))
+    sets = [d] + [make_inputs(B, T, nx, nu, seed=1000 + 16 * rank + k, device=device)[1] for k in range(1, n_sets)]
     x = torch.empty((T, B, nx), dtype=torch.float32, device=device)
     u = torch.empty((T, B, nu), dtype=torch.float32, device=device)
     gx = gu = None
@@ -376,8 +285,12 @@ def main():
         gx = torch.empty((world,) + tuple(x.shape), dtype=torch.float32, device=device)
         gu = torch.empty((world,) + tuple(u.shape), dtype=torch.float32, device=device)
 
+    k_step = [0]
+
     def step():
-        solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u))
+        e = sets[k_step[0] % n_sets]
+        k_step[0] += 1
+        solve_device(e["C"], e["c"], e["F"], e["f"], e["x_init"], None, T, nx, nu, out=(x, u))
         if gx is not None:
             dist.all_gather_into_tensor(gx, x)
             dist.all_gather_into_tensor(gu, u)
@@ -407,6 +320,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kern_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
+    kern_name = kernel_name() if gx is None else None      # (with --gather the last launch is RCCL's, not ours)
+    # for the parity check: the solution of set 0, whatever set the last timed step solved
+    solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u))
+    x_host, u_host = x.cpu().numpy(), u.cpu().numpy()
+    # context for the number above (N = 1): the same launch re-solving ONE input set (what rounds 1-2 timed: a set that
+    # fits the Infinity Cache), and what this box's memory system sustains on a plain copy
+    t_same = copy_gbs = None
+    if rank == 0 and world == 1:
+        del sets[1:]
+        torch.cuda.empty_cache()
+        if n_sets > 1:
+            t_same = event_time(lambda: solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu,
+                                                     out=(x, u)), 100, warm=30)
+        copy_gbs = hbm_copy_calibration(device)
 
     if rank == 0:
         bytes_per_ts = synthetic.lqr_algorithmic_bytes_per_timestep(nx, nu)
@@ -431,22 +358,38 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: synthetic random LQR, B=%d per GPU, T=%d, n_x=%d, n_u=%d, fused "
-                                   "solve_recursion (Riccati backward + rollout), inputs resident in HBM"
+                                   "solve_recursion (Riccati backward + rollout), inputs resident in HBM (streamed: "
+                                   "input sets in rotation)"
                                    % (args.workload, B, T, nx, nu),
                        "global_batch": world * B, "parallelism": "batch-shard x%d%s" % (
                            world, " + all-gather(x,u)" if gx is not None else ", no collective")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kernel_name(T, B, nx, nu),
+                         "kernel": kern_name,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3},
         }
-        parity_ok = True
+        out["roofline"].update({
+            "input_sets_in_rotation": n_sets,
+            "inputs": "%d input sets of %.0f MB in rotation (%.0f MB against the 256 MiB Infinity Cache): every step "
+                      "streams its inputs from HBM" % (n_sets, set_bytes / 1e6, n_sets * set_bytes / 1e6) if n_sets > 1
+                      else "one input set of %.0f MB (beyond the 256 MiB Infinity Cache by itself)" % (set_bytes / 1e6)})
+        if t_same is not None:
+            out["roofline"].update({"frac_same_inputs": alg_bytes / t_same / 1e9 / HBM_PEAK_GBS, "kernel_ms_same_inputs": t_same * 1e3,
+                                    "same_inputs_what": "the launch re-solving ONE input set 100 times (rounds 1-2 timed "
+                                                        "this; the set fits the Infinity Cache, but the solve's nt loads "
+                                                        "do not allocate there)"})
+        if copy_gbs is not None:
+            out["roofline"].update({"box_copy_gbs": copy_gbs,
+                                    "box_copy_what": "device-to-device copy of 1 GiB on this box (read + write traffic, GB/s): "
+                                                     "what its memory system sustains on the plainest streaming pattern "
+                                                     "(MI355X_MICROARCH.md: 6290); boxes of the pool differ"})
+        parity_ok, secondary_failed = True, False
         if cb is not None:
             out["cpu_baseline"] = cb
             if cb_mp is not None:
                 out["cpu_baseline_mp"] = cb_mp
-            xe = float(np.max(np.abs(x.cpu().numpy() - xr) / np.maximum(1.0, np.abs(xr))))
-            ue = float(np.max(np.abs(u.cpu().numpy() - ur) / np.maximum(1.0, np.abs(ur))))
+            xe = float(np.max(np.abs(x_host - xr) / np.maximum(1.0, np.abs(xr))))
+            ue = float(np.max(np.abs(u_host - ur) / np.maximum(1.0, np.abs(ur))))
             parity_ok = xe <= PARITY_TOL and ue <= PARITY_TOL
             out["parity"] = {"max_rel_err_x": xe, "max_rel_err_u": ue, "tolerance": PARITY_TOL, "ok": parity_ok,
                              "against": "oracle/lqr.py on identical inputs"}
@@ -464,10 +407,14 @@ def main():
             except Exception as e:  # pragma: no cover
                 sec["cfg5_shard"] = {"error": repr(e)}
             out["secondary"] = sec
+            secondary_failed = "error" in sec or any(isinstance(v, dict) and "error" in v for v in sec.values())
         print(json.dumps(out))
         if not parity_ok:        # a fast kernel whose results differ from the reference's is not done
             print("PARITY FAILURE: %r" % (out["parity"],), file=sys.stderr)
             sys.exit(3)
+        if secondary_failed and not args.allow_secondary_failure:
+            print("SECONDARY MEASUREMENT FAILED (see the \"error\" entries of the JSON line)", file=sys.stderr)
+            sys.exit(4)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

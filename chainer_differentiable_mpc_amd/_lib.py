@@ -25,6 +25,7 @@ _c_sz = ctypes.c_size_t
 SIGNATURES = {
     "dmpc_version": (_c_i, []),
     "dmpc_source_hash": (ctypes.c_char_p, []),
+    "dmpc_last_kernel_name": (_c_i, [ctypes.c_char_p, _c_sz]),
     "dmpc_lqr_kernel_family": (_c_i, [_c_i, _c_i]),
     "dmpc_lqr_solve_path": (_c_i, [_c_i] * 4),
     "dmpc_lqr_workspace_bytes": (_c_sz, [_c_i] * 4),
@@ -82,6 +83,13 @@ def load(path=None):
         if path is None:
             _lib = lib
         return lib
+
+
+def last_kernel_name():
+    """the kernel this thread's last library call launched last, as rocprofv3 lists it (asked of the HIP runtime)"""
+    buf = ctypes.create_string_buffer(512)
+    load().dmpc_last_kernel_name(buf, 512)
+    return buf.value.decode()
 
 
 def require_gpu():

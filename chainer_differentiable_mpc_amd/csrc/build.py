@@ -29,8 +29,10 @@ OUT = os.path.join(PKG, "libdmpc_hip.so")
 STAMP = OUT + ".srchash"
 OBJ_DIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize",
-         "-I" + os.path.join(ROOT, "include")] + os.environ.get("DMPC_EXTRA_FLAGS", "").split()   # experiment knobs
+BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize"] \
+    + os.environ.get("DMPC_EXTRA_FLAGS", "").split()   # experiment knobs
+FLAGS = BASE_FLAGS + ["-I" + os.path.join(ROOT, "include")]
+HASHED_FLAGS = BASE_FLAGS + ["-Iinclude"]     # what the hashes see: the same in every checkout path
 GENERATED = {"lqr_asm_gen.hpp": "gen_lqr_asm.py", "dpp_blocks_gen.hpp": "gen_dpp_blocks.py",
              "mpc_fwd_asm_gen.hpp": "gen_mpc_fwd_asm.py"}
 HASH_TU = "lu_api.hip"      # the translation unit that defines dmpc_source_hash()
@@ -45,7 +47,7 @@ def hipcc():
 
 def _sha(paths, extra=""):
     h = hashlib.sha256(extra.encode())
-    for p in sorted(paths):
+    for p in sorted(paths, key=os.path.basename):
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as fh:
             h.update(fh.read())
@@ -56,12 +58,22 @@ def hand_written_sources():
     """everything a human edits: .hip, hand-written headers, the generators, the public header, this script"""
     srcs = glob.glob(os.path.join(HERE, "*.hip")) + glob.glob(os.path.join(ROOT, "include", "*.h")) \
         + [p for p in glob.glob(os.path.join(HERE, "*.hpp")) if os.path.basename(p) not in GENERATED] \
-        + [os.path.join(HERE, g) for g in GENERATED.values()] + [os.path.abspath(__file__)]
+        + generators() + [os.path.abspath(__file__)]
     return srcs
 
 
+def gen_env():
+    """the GEN_* knobs of the generators (timing experiments; they change the generated streams)"""
+    return repr(sorted((k, v) for k, v in os.environ.items() if k.startswith("GEN_")))
+
+
+def generators():
+    """every generator script: they import from each other (gen_mpc_fwd_asm.py uses gen_lqr_asm.py's emitter)"""
+    return sorted(glob.glob(os.path.join(HERE, "gen_*.py")))
+
+
 def source_hash():
-    return _sha(hand_written_sources(), " ".join(FLAGS))[:32]
+    return _sha(hand_written_sources(), " ".join(HASHED_FLAGS) + gen_env())[:32]
 
 
 def is_current():
@@ -76,7 +88,7 @@ def generate(force=False):
         gen = os.path.join(HERE, gen_name)
         out = os.path.join(HERE, out_name)
         stamp = os.path.join(OBJ_DIR, out_name + ".genhash")
-        want = _sha([gen])
+        want = _sha(generators(), gen_env())     # the whole generator set and its knobs, not this script alone
         if force or not os.path.exists(out) or not os.path.exists(stamp) or open(stamp).read() != want:
             r = subprocess.run([sys.executable, gen], capture_output=True, text=True)
             if r.returncode != 0:
@@ -106,7 +118,7 @@ def compile_one(src, force, src_hash):
     flags = list(FLAGS)
     if base == HASH_TU:
         flags.append('-DDMPC_SOURCE_HASH="%s"' % src_hash)
-    want = _sha(deps, " ".join(flags))
+    want = _sha(deps, " ".join(f for f in flags if not f.startswith("-I")))
     if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read() != want:
         cmd = [hipcc()] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

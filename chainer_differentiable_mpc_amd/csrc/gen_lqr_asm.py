@@ -63,17 +63,26 @@ X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (n
 # straight-line code: 1-3 % faster than the loop when launched back to back, 4-5 us SLOWER per solve when other kernels
 # run in between (DiffLqr's forward + backward loop; scripts/unroll_ab.sh) - the launcher picks (api_util.hpp).
 # GEN_UNROLL_BWD=0: do not generate it.
-X_UNROLL_BWD = os.environ.get("GEN_UNROLL_BWD", "1") == "1"
+X_UNROLL_BWD = os.environ.get("GEN_UNROLL_BWD", "0") == "1"
 # Experiment: the prologue of the unrolled stream touches the stream's own code with 20 loads (64 lanes x one 64-byte
 # line each, clamped to the stream's end) so that the lines are in L2 before the fetcher asks for them.
 X_CODE_PREFETCH = os.environ.get("GEN_CODE_PREFETCH", "0") == "1"   # measured: makes both cases worse (+1.5 us); off
 N_CODE_PREFETCH = 20
+# Ring depth of the plain / saving / affine streams (the masked and MPC streams keep DB slots of whole 1 KB pieces: their
+# flags and bounds ride in the slot padding).  With more than DB slots the slot stride is the slot's own size (rounded up
+# to 64 B) and the last DMA of a group runs under an exec mask - whole pieces would not fit the 160 KB of a CU.
+RING_DEPTH = int(os.environ.get("GEN_RING_DEPTH", "3"))
+# nt (streaming) cache policy on the backward groups' LDS-DMA, per kind of stream (plain, save, affine, masked, mpc):
+# the inputs of a solve are read once; with the default policy they displace each other from L2 / the Infinity Cache on
+# their way through (HBM-streamed headline solve 38-40 -> 33.5-35 us, B = 8192: 78 -> 64 us; profiles/r03/ring_ab.txt)
+X_NT = set(os.environ.get("GEN_NT", "plain").split(","))
 USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
 
 
 class Layout:
-    def __init__(self, nx, nu):
+    def __init__(self, nx, nu, depth=DB):
         self.nx, self.nu, self.ns = nx, nu, nx + nu
+        self.depth = depth
         ns = self.ns
         self.nC, self.nc, self.nF, self.nf = ns * ns, ns, nx * ns, nx          # 16-byte chunks per wave-step
         self.OFF_C = 0
@@ -82,14 +91,20 @@ class Layout:
         self.OFF_f = self.OFF_F + 16 * self.nF
         self.nchunk_b = self.nC + self.nc + self.nF + self.nf
         self.ndma_b = (self.nchunk_b + 63) // 64
-        self.SLOT_B = self.ndma_b * 1024
+        self.compact = depth > DB
+        self.SLOT_B = self.ndma_b * 1024 if not self.compact else (16 * self.nchunk_b + 63) // 64 * 64
+        # lanes of a group's last DMA that stay inside the slot (compact: the others would land in the next slot)
+        self.last_lanes = (self.SLOT_B - (self.ndma_b - 1) * 1024) // 16
         self.FOFF_f = 16 * self.nF
         self.nchunk_f = self.nF + self.nf
         self.ndma_f = (self.nchunk_f + 63) // 64
         self.SLOT_F = self.ndma_f * 1024
-        self.RING = max(DB * self.SLOT_B, DF * self.SLOT_F)
+        # one ring size per shape, whatever the stream: RING_DEPTH compact slots or DB slots of whole pieces
+        deep = RING_DEPTH * ((16 * self.nchunk_b + 63) // 64 * 64) if RING_DEPTH > DB else 0
+        self.RING = max(deep, DB * self.ndma_b * 1024, DF * self.SLOT_F)
+        assert depth * self.SLOT_B <= self.RING
         assert self.ndma_b * 1024 - 1024 <= 4095 and ns + 1 <= 12 and nu in (1, 2)
-        assert (DB - 1) * self.ndma_b <= 63 and (DF - 1) * self.ndma_f <= 63
+        assert (depth - 1) * self.ndma_b <= 63 and (DF - 1) * self.ndma_f <= 63 and 1 <= self.last_lanes <= 64
         # ---- F stash (registers instead of a second HBM read of F), in the layout the forward sweep consumes:
         # lane i < 8 of a 16-lane row keeps columns [0, H) of row i of F_t, lane 8 + i columns [H, ns) - H
         # accumulation registers per timestep, read from the ring slot as pairs (ds_read2_b32) + a single
@@ -254,7 +269,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     timestep-solve instead of 832 B, and ~60 instructions per step instead of ~165.
     expand (mpc only): need_expand of MPCstep.forward (mpc_step.py:305-317) inside the sweep - the slot padding also
     takes x_t (4 nx more dwords) and every step starts with c_hat = C [x_t; u_t] + c in the affine column."""
-    L = Layout(nx, nu)
+    D = DB if (masked or mpc) else RING_DEPTH      # ring slots (the register sets stay three)
+    kind = "mpc" if mpc else "masked" if masked else "save" if save else "affine" if affine else "plain"
+    L = Layout(nx, nu, D)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
     unroll_bwd = unroll
@@ -362,7 +379,13 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             P.nop(1)
         for q, p in enumerate(ptrs):
             off = (" offset:%d" % (q * 1024)) if q else ""
-            P.raw("global_load_lds_dwordx4 %s, off%s" % (p, off))
+            part = ptrs is ptr and L.compact and q == len(ptrs) - 1 and L.last_lanes < 64
+            if part:     # the rest of this piece would land in the next slot
+                P.raw("s_mov_b64 exec, 0x%x" % ((1 << L.last_lanes) - 1))
+            P.raw("global_load_lds_dwordx4 %s, off%s%s" % (p, off, " nt" if kind in X_NT and ptrs is ptr else ""))
+            if part:
+                P.raw("s_mov_b64 exec, -1")
+                P.exec_written()
         if masked and ptrs is ptr:   # 4 * nu flag bytes = nu dwords, one per lane (the other lanes repeat dword 0)
             P.raw("global_load_lds_dword %%[pm], off offset:%d" % PADM)
 
@@ -371,8 +394,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     def advance(ptrs, strides, by_steps_left=None):
         """move the DMA pointers one timestep back unless they already sit on the first timestep.  In the prologue
         that is counted in tf.  Inside the backward sweep the strides left are a fixed distance from the loop counter
-        S_N (step n of the sweep, n = 0 peeled: tf = T-1-DB-n, S_N = T-2 for n = 0 and T-1-n after), so the sweep
-        tests S_N against by_steps_left (DB for the peeled step, DB+1 in the loop) and tf is not maintained there."""
+        S_N (step n of the sweep, n = 0 peeled: tf = T-1-D-n, S_N = T-2 for n = 0 and T-1-n after), so the sweep
+        tests S_N against by_steps_left (D for the peeled step, D+1 in the loop) and tf is not maintained there."""
         uniq[0] += 1
         lab = "Ladv%d_%%=" % uniq[0]
         if by_steps_left is not None:
@@ -779,11 +802,14 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 for i in range(nx):
                     P.fmac_dpp(Qs[i], Kt[m], Rr[m], i)
 
-    def bstep(s, first, extra_outstanding=0, stub_n=None):
+    def bstep(step, first, extra_outstanding=0, stub_n=None):
+        """step `step` of the sweep (0 is the peeled first step; the loop form passes its body position, the step modulo
+        the loop length): register set step % 3, ring slot step % D"""
+        s, slot, nslot = step % 3, step % D, (step + 1) % D
         p, n = (s + 2) % 3, (s + 1) % 3
         V = Q[p]
-        issue_group(ptr, s, L.SLOT_B, gap="s_waitcnt lgkmcnt(0)")   # the slot's last reads are in before it is refilled
-        advance(ptr, strd, by_steps_left=DB if first else DB + 1)
+        issue_group(ptr, slot, L.SLOT_B, gap="s_waitcnt lgkmcnt(0)")   # the slot's last reads are in before it is refilled
+        advance(ptr, strd, by_steps_left=D if first else D + 1)
         if expand:
             # c_hat = c + C tau: lane i holds row i of C_t (read_ct), tau_k comes from lane k of TAU by a DPP broadcast -
             # two accumulators; then entry i of the sum goes to the affine lane of row i of Q~ (one DPP FMA against e_aff).
@@ -831,23 +857,25 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             for i in range(nx):
                 P.fmac_dpp(W[i], V[i], "%[eaff]", aff)
         # The stores of a step (gains, the saved blocks) are younger than its DMA group and retire in order with it
-        # (one counter, gfx9): between the group this step needs and now lie two younger groups AND the stores of the
-        # two steps since - allowing for them keeps two groups in flight (without, eleven stores per step would leave
-        # one).  Register set 1 also runs the second step of the sweep, where only one step's stores and the
-        # prologue's extra loads lie in between: the smaller of the two counts.
+        # (one counter, gfx9): between the group this step needs and now lie D-1 younger groups AND the stores of the
+        # D-1 steps since - allowing for them keeps D-1 groups in flight (without, eleven stores per step would leave
+        # one).  Body positions j < D-1 also run step j of the sweep, where only j steps' stores and the prologue's
+        # extra loads lie in between: the smaller of the two counts.
         st_allow = 0
         if not first and not mpc and n_step_stores:
-            st_allow = n_step_stores + (min(n_extra, n_step_stores) if s == 1 else n_step_stores)
-        vmwait((DB - 1) * NDB_ALL + extra_outstanding + st_allow)
-        read_set(n, n)
+            st_allow = (D - 1) * n_step_stores
+            if step <= D - 2:
+                st_allow = step * n_step_stores + min(n_extra, (D - 1 - step) * n_step_stores)
+        vmwait((D - 1) * NDB_ALL + extra_outstanding + st_allow)
+        read_set(n, nslot)
         if stash and stub_n is not None:
             # unrolled sweep: this step's stash registers are known here
             for p_, (w, off) in enumerate(L.stash_pieces):
                 regs = stash_regs_of(p_, stub_n - 1)
                 if w == 2:
-                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], stub_n % 3, off, off + 1))
+                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], stub_n % D, off, off + 1))
                 else:
-                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], stub_n % 3, off * 4))
+                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], stub_n % D, off * 4))
         elif stash:
             # F of the NEXT step goes from its ring slot into this step's stash registers: the register numbers
             # differ per step, so the two reads live in a table of stubs (one per step) that is called here
@@ -857,9 +885,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 P.raw("s_setpc_b64 " + S_STUB)
                 P.lines.append(".p2align 6")
                 P.label("Lret%d_%%=" % callsite[0], reset=False)
-                bret.setdefault(s, callsite[0]) if not first else None
-                if first:
-                    bret["first"] = callsite[0]
+                bret["first" if first else step] = callsite[0]
             else:
                 P.raw("s_swappc_b64 %s, %s" % (S_RET, S_STUB))
             P.raw("s_add_u32 s%d, s%d, %d" % (lo, lo, BSTUB))
@@ -884,7 +910,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                     P.fmac_dpp(Q[s][i], F[s][k], W[k], i)
         gains(s, first)
         if expand:
-            read_ct(n)       # (the last step reads a slot nobody consumes)
+            read_ct(nslot)   # (the last step reads a slot nobody consumes)
         vupdate(s)
 
     n_step_stores = 0      # global stores per backward step (not mpc)
@@ -892,9 +918,10 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         n_step_stores += nu
     if save:
         n_step_stores += nx + (1 if nu == 1 or int(A[0][0][1:]) % 2 == 0 else nu * nu)
-    assert (DB - 1) * NDB_ALL + 2 * n_step_stores <= 63
+    assert (D - 1) * (NDB_ALL + n_step_stores) <= 63
+    LC = 3 * D // (3 if D % 3 == 0 else 1)     # steps per trip of the loop form: lcm(register sets, ring slots)
     callsite = [0]
-    bret = {}      # register set (or "first") -> return label number of its call site
+    bret = {}      # body position of the loop (or "first") -> return label number of its call site
     BSTUB = 32     # bytes per backward stub (two LDS reads + s_setpc_b64 = 20)
     assert 8 * len(L.stash_pieces) + 4 <= BSTUB
 
@@ -947,7 +974,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     P.raw("s_sub_i32 %s, %%[T], 1" % S_TF)
     issue_group(ptr, 0, L.SLOT_B)
     advance(ptr, str1)
-    for j in range(1, DB):
+    for j in range(1, D):
         issue_group(ptr, j, L.SLOT_B)
         advance(ptr, strd)
     P_first = P
@@ -1003,7 +1030,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         P.raw("s_sub_u32 %s, %s, 1" % (S_TMP, S_TMP))
         P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)
         P.raw("s_cbranch_scc1 Lwarm_%=")
-    P.raw("s_waitcnt vmcnt(%d)" % ((DB - 1) * NDB_ALL + n_extra))
+    P.raw("s_waitcnt vmcnt(%d)" % ((D - 1) * NDB_ALL + n_extra))
     read_set(0, 0)
     if expand:
         read_ct(0)
@@ -1017,16 +1044,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if unroll_bwd:
         for k in range(1, L.NSTASH):
             P.comment("---- backward step %d, register set %d" % (k, k % 3))
-            bstep(k % 3, False, stub_n=k + 1)
+            bstep(k, False, stub_n=k + 1)
             P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
             P.raw("s_cbranch_scc1 Lbwd_done_%=")
     else:
         P.label("Lbwd_%=")
-        for s in (1, 2, 0):
-            P.comment("---- backward step, register set %d" % s)
-            bstep(s, False)
+        for k in range(1, LC + 1):       # steps k, k + LC, k + 2 LC, ... of the sweep
+            P.comment("---- backward step, register set %d, ring slot %d" % (k % 3, k % D))
+            bstep(k, False)
             P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
-            if s != 0:
+            if k != LC:
                 P.raw("s_cbranch_scc1 Lbwd_done_%=")
             else:
                 P.raw("s_cbranch_scc0 Lbwd_%=")
@@ -1245,11 +1272,11 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             for p, (w, off) in enumerate(L.stash_pieces):
                 regs = stash_regs_of(p, n - 1)
                 if w == 2:
-                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], n % 3, off, off + 1))
+                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], n % D, off, off + 1))
                 else:
-                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], n % 3, off * 4))
-            if X_RET_DIRECT:   # stub n is called from step n-1: the peeled first step, then register sets 1, 2, 0, ...
-                P.raw("s_branch Lret%d_%%=" % (bret["first"] if n == 1 else bret[(n - 1) % 3]))
+                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], n % D, off * 4))
+            if X_RET_DIRECT:   # stub n is called from step n-1: the peeled first step, then body positions 1 .. LC, 1, ...
+                P.raw("s_branch Lret%d_%%=" % (bret["first"] if n == 1 else bret[(n - 2) % LC + 1]))
             else:
                 P.raw("s_setpc_b64 " + S_RET)
     P.label("Ldone_%=")
@@ -1293,7 +1320,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if stash:
         for q in range(L.NFD):
             ins.append(("fp%d" % q, '"v"(in.fp[%d])' % q))
-        for q in range(3):
+        for q in range(D):
             ins.append(("sr%d" % q, '"v"(in.sr[%d])' % q))
         ins += [("drowo", '"v"(in.drow)'), ("daff", '"v"(in.daff)'),
                 ("farea", '"s"(in.farea)')]
@@ -1324,8 +1351,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
              % (nx, nu, write_k, stash, masked, n_bwd, n_fwd, n_fwd_steps))
     o.append("template <>\nstruct %s {\n" % name)
     o.append("  static constexpr bool kAvailable = true;\n")
-    o.append("  static constexpr int NDB = %d, NDF = %d, SLOT_B = %d, SLOT_F = %d, RING_BYTES = %d, KROW = %d, DEPTH_F = %d;\n"
-             % (L.ndma_b, L.ndma_f, L.SLOT_B, L.SLOT_F, L.RING, KROW, DF))
+    o.append("  static constexpr int NDB = %d, NDF = %d, SLOT_B = %d, SLOT_F = %d, RING_BYTES = %d, KROW = %d, DEPTH_F = %d, DEPTH_B = %d;\n"
+             % (L.ndma_b, L.ndma_f, L.SLOT_B, L.SLOT_F, L.RING, KROW, DF, D))
     o.append("  static constexpr int OFF_C = %d, OFF_c = %d, OFF_F = %d, OFF_f = %d, FOFF_f = %d;\n"
              % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
     o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, HROW = %d, SPD = %d, PADM = %d;\n"
@@ -1393,7 +1420,7 @@ struct LqrAsmIn {
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
   uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
-  unsigned sr[3];                    // stash variant: LDS byte address of this lane's half row of F in ring slot 0, 1, 2
+  unsigned sr[6];                    // stash variant: LDS byte address of this lane's half row of F in ring slot q < DEPTH_B
   unsigned farea;                    // stash variant (wave-uniform): LDS byte address of this wave's f area
   unsigned arow, aaff, drow, drow2, daff, daff2;
   uint64_t pst, dst;                 // [x_{t+1} | u_t] store pointer and time stride

@@ -38,6 +38,7 @@ X_NO_DMA = os.environ.get("GEN_FWD_NO_DMA") == "1"
 X_NO_LDS = os.environ.get("GEN_FWD_NO_LDS") == "1"
 X_NO_COST = os.environ.get("GEN_FWD_NO_COST") == "1"
 X_NO_ADV = os.environ.get("GEN_FWD_NO_ADV") == "1"
+X_NT = os.environ.get("GEN_FWD_NT") == "1"      # nt cache policy on the input DMAs (measured, not a default: the search re-reads C and F)
 
 
 class FwdLayout:
@@ -106,7 +107,7 @@ def gen_fwd(nx, nu):
         for q in range(KD):
             off = (" offset:%d" % (q * 1024)) if q else ""
             if not (X_NO_DMA and in_body[0]):
-                P.raw("global_load_lds_dwordx4 %s, off%s" % (v2(PTR[q]), off))
+                P.raw("global_load_lds_dwordx4 %s, off%s%s" % (v2(PTR[q]), off, " nt" if X_NT else ""))
 
     slow = []   # (label, return label): the one advance of a pass that must leave the F / f lanes where they are
 

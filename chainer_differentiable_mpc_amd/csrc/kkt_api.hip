@@ -50,19 +50,19 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
       if (a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled()) {                                                \
         using Lay = CostateDmaLayout<NX_, NU_, kCostateDmaDepth>;                                           \
         const int waves = (a.B + 3) / 4;                                                                    \
-        hipLaunchKernelGGL((costate_dma_kernel<NX_, NU_, kCostateDmaDepth>), dim3((waves + 3) / 4), dim3(256), \
+        DMPC_LAUNCH_GGL((costate_dma_kernel<NX_, NU_, kCostateDmaDepth>), dim3((waves + 3) / 4), dim3(256), \
                            Lay::lds_bytes(), stream, a);                                                    \
         return (int)hipGetLastError();                                                                      \
       }                                                                                                     \
     }                                                                                                       \
-    hipLaunchKernelGGL((costate_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, a); \
+    DMPC_LAUNCH_GGL((costate_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, a); \
     return (int)hipGetLastError();                                                                          \
   }
   DMPC_COSTATE_SHAPES(X)
 #undef X
   if (nx + nu + 1 > 64) return DMPC_E_UNSUPPORTED;
   const size_t shmem = (size_t)(2 * (nx + nu) + 4 * nx) * sizeof(float);
-  hipLaunchKernelGGL(costate_generic_kernel, dim3(a.B), dim3(64), shmem, stream, a, CostateDims{nx, nu});
+  DMPC_LAUNCH_GGL(costate_generic_kernel, dim3(a.B), dim3(64), shmem, stream, a, CostateDims{nx, nu});
   return (int)hipGetLastError();
 }
 
@@ -127,7 +127,7 @@ static int kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c
     // ... the other kernels a concatenated copy
     const size_t rows = (size_t)T * B;
     const int blocks = (int)((rows * (nx + nu) + 255) / 256 > 4096 ? 4096 : (rows * (nx + nu) + 255) / 256);
-    hipLaunchKernelGGL(concat_tau_kernel, dim3(blocks), dim3(256), 0, stream, rows, nx, nu, grad_x, grad_u, drl, x0,
+    DMPC_LAUNCH_GGL(concat_tau_kernel, dim3(blocks), dim3(256), 0, stream, rows, nx, nu, grad_x, grad_u, drl, x0,
                        (size_t)B * nx);
     rc = dmpc_lqr_solve(T, B, nx, nu, C, drl, F, nullptr, x0, nullptr, nullptr, nullptr, dx, du, base + w.lqr,
                         w.total - w.lqr, info, stream_);
@@ -146,7 +146,6 @@ int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float 
                       const float *x, const float *u, const float *grad_x, const float *grad_u,
                       int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws,
                       size_t ws_bytes, int32_t *info, dmpc_stream_t stream) {
-  note_other_launch();
   return kkt_grad(T, B, nx, nu, C, c, F, x, u, nullptr, nullptr, nullptr, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF,
                   df, ws, ws_bytes, info, stream);
 }
@@ -158,7 +157,6 @@ int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const 
                             const float *grad_x, const float *grad_u, int strict_math, float *d_x_init, float *dC,
                             float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
                             dmpc_stream_t stream) {
-  note_other_launch();
   if (!Ks || !Quu || !Qxu) return DMPC_E_BADARG;
   return kkt_grad(T, B, nx, nu, C, c, F, x, u, Ks, Quu, Qxu, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF, df, ws,
                   ws_bytes, info, stream);

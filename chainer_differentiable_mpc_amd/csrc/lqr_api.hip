@@ -37,11 +37,6 @@ static bool wave_mfma_disabled() {  // DMPC_NO_WAVE_MFMA=1: large shapes on the 
   static const bool off = [] { const char *e = getenv("DMPC_NO_WAVE_MFMA"); return e && e[0] == '1'; }();
   return off;
 }
-static int g_before_this_solve = kLaunchOther;   // g_last_launch as dmpc_lqr_solve found it
-static bool unroll_disabled() {  // DMPC_NO_UNROLL=1: always the three-step loop form of the headline stream (A/B timing)
-  static const bool off = [] { const char *e = getenv("DMPC_NO_UNROLL"); return e && e[0] == '1'; }();
-  return off;
-}
 static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
   static const bool off = [] { const char *e = getenv("DMPC_NO_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -77,7 +72,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   const bool masked = a.mask != nullptr;
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
 #define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
-  hipLaunchKernelGGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
+  DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
   if (a.c_u != nullptr || (a.x_init == nullptr && a.x != nullptr)) {
     // c in two arrays / x_init = 0: forms only the generated streams take (lqr_second_solve below)
     bool ok = false;
@@ -91,7 +86,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       if (mode == kSolve && !masked && a.f == nullptr && a.Ks == nullptr && solve_path<NX, NU, L>(a.T, a.B) == 4) {
         const int waves = (a.B + 3) / 4;
         const size_t shmem = lqr_asm_lds_bytes<NX, NU, true>(a.T);
-        hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, true, false, false, false, true>), dim3((waves + 3) / 4),
+        DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, false, true, false, false, false, true>), dim3((waves + 3) / 4),
                            block, shmem, stream, a);
         return (int)hipGetLastError();
       }
@@ -113,8 +108,8 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #define DMPC_ASM_LAUNCH_M(STASH)                                                                                        \
   do {                                                                                                                  \
     const size_t shmem = lqr_asm_lds_bytes<NX, NU, STASH>(a.T);                                                         \
-    if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, STASH, true>), g, block, shmem, stream, a);      \
-    else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, STASH, true>), g, block, shmem, stream, a);           \
+    if (has_f) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, false, STASH, true>), g, block, shmem, stream, a);      \
+    else DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, false, STASH, true>), g, block, shmem, stream, a);           \
     return (int)hipGetLastError();                                                                                      \
   } while (0)
         if constexpr (LqrAsm<NX, NU, false, true, true>::kAvailable) {
@@ -130,9 +125,9 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       const int waves = (a.B + 3) / 4;
       const size_t shmem = lqr_asm_lds_bytes<NX, NU, false>(a.T);
       if (a.f != nullptr)
-        hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, false>), dim3((waves + 3) / 4), block, shmem, stream, a);
+        DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, true, false>), dim3((waves + 3) / 4), block, shmem, stream, a);
       else
-        hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, false>), dim3((waves + 3) / 4), block, shmem, stream, a);
+        DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, true, false>), dim3((waves + 3) / 4), block, shmem, stream, a);
       return (int)hipGetLastError();
     }
     const int path = (mode == kSolve && !masked) ? solve_path<NX, NU, L>(a.T, a.B) : 0;
@@ -145,29 +140,18 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
     const size_t shmem = lqr_asm_lds_bytes<NX, NU, STASH>(a.T);                                                  \
     if constexpr (LqrAsm<NX, NU, true, STASH, false, false, true>::kAvailable) {                                 \
       if (a.Quu_out != nullptr && write_k) { /* training form: Quu, Qxu saved too */                             \
-        if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, STASH, false, false, true>), g, block, shmem, stream, a); \
-        else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, STASH, false, false, true>), g, block, shmem, stream, a); \
+        if (has_f) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, true, STASH, false, false, true>), g, block, shmem, stream, a); \
+        else DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, true, STASH, false, false, true>), g, block, shmem, stream, a); \
         return (int)hipGetLastError();                                                                           \
       }                                                                                                          \
     }                                                                                                            \
     if (a.Quu_out != nullptr) return DMPC_E_UNSUPPORTED;                                                         \
-    if (has_f && !write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, STASH>), g, block, shmem, stream, a); \
-    else if (has_f) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, true, STASH>), g, block, shmem, stream, a); \
-    else if (!write_k) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, false, STASH>), g, block, shmem, stream, a); \
-    else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, false, true, STASH>), g, block, shmem, stream, a);           \
+    if (has_f && !write_k) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, false, STASH>), g, block, shmem, stream, a); \
+    else if (has_f) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, true, STASH>), g, block, shmem, stream, a); \
+    else if (!write_k) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, false, STASH>), g, block, shmem, stream, a); \
+    else DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, true, STASH>), g, block, shmem, stream, a);           \
     return (int)hipGetLastError();                                                                               \
   } while (0)
-      if constexpr (LqrAsm<NX, NU, false, true, false, true>::kAvailable) {
-        // the plain solve launched back to back: the sweep unrolled over the horizon (api_util.hpp: g_last_launch)
-        if (path == 4 && has_f && !write_k) {
-          const bool hot = g_before_this_solve == kLaunchPlainSolve && !unroll_disabled();
-          g_last_launch = kLaunchPlainSolve;
-          const size_t shmem = lqr_asm_lds_bytes<NX, NU, true>(a.T);
-          if (hot) hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, true, false, true>), g, block, shmem, stream, a);
-          else hipLaunchKernelGGL((lqr_asm_kernel<NX, NU, true, false, true>), g, block, shmem, stream, a);
-          return (int)hipGetLastError();
-        }
-      }
       if constexpr (LqrAsm<NX, NU, false, true>::kAvailable) {
         if (path == 4) DMPC_ASM_LAUNCH(true);
       }
@@ -192,7 +176,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
     if (mode == kSolve && !masked && a.B >= 4 && a.T >= 2 && Lay::lds_bytes(a.T) <= kDmaLdsBudget &&
         !dma_path_disabled()) {
       const int waves = (a.B + 3) / 4;
-      hipLaunchKernelGGL((lqr_dma_kernel<NX, NU, kDmaDepthB, kDmaDepthF>), dim3((waves + 3) / 4), block,
+      DMPC_LAUNCH_GGL((lqr_dma_kernel<NX, NU, kDmaDepthB, kDmaDepthF>), dim3((waves + 3) / 4), block,
                          Lay::lds_bytes(a.T), stream, a);
       return (int)hipGetLastError();
     }
@@ -206,8 +190,8 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       LqrArgs s = a;  // long horizon: gains go through HBM (caller's Ks/ks, else the workspace)
       if (s.Ks == nullptr) { s.Ks = s.wsK; s.ks = s.wsk; }
       if (s.Ks == nullptr) return DMPC_E_WORKSPACE;
-      if (masked) hipLaunchKernelGGL((lqr_kernel<NX, NU, L, true, kSolve, false>), grid, block, 0, stream, s);
-      else hipLaunchKernelGGL((lqr_kernel<NX, NU, L, false, kSolve, false>), grid, block, 0, stream, s);
+      if (masked) DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, L, true, kSolve, false>), grid, block, 0, stream, s);
+      else DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, L, false, kSolve, false>), grid, block, 0, stream, s);
     }
   } else if (mode == kBackwardOnly) {
     if (masked) DMPC_LAUNCH(true, kBackwardOnly, false, 0);
@@ -267,8 +251,6 @@ int lqr_second_solve(int T, int B, int nx, int nu, const float *C, const float *
     a.Quu_in = Quu;
     a.Qxu_in = Qxu;
   }
-  g_before_this_solve = kLaunchOther;
-  g_last_launch = kLaunchOther;
   return dispatch_lqr(kSolve, nx, nu, a, stream);
 }
 
@@ -312,15 +294,12 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
     a.wsK = static_cast<float *>(ws);
     a.wsk = a.wsK + (size_t)T * B * nu * nx;
   }
-  g_before_this_solve = g_last_launch;
-  g_last_launch = kLaunchOther;          // (launch_lqr sets kLaunchPlainSolve when it takes the plain stash solve)
   return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
 }
 
 int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                           const float *f, const float *x_init, float *Ks_out, float *ks_out, float *Quu_out,
                           float *Qxu_out, float *x_out, float *u_out, int32_t *info, dmpc_stream_t stream) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !F || !x_init || !x_out || !u_out || !Ks_out || !ks_out || !Quu_out || !Qxu_out) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(Quu_out)) return DMPC_E_BADARG;
@@ -335,7 +314,6 @@ int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const fl
 int dmpc_lqr_saved_solve(int T, int B, int nx, int nu, const float *c, const float *F, const float *Ks,
                          const float *Quu, const float *Qxu, const float *x_init, float *x_out, float *u_out,
                          int32_t *info, dmpc_stream_t stream) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!c || !F || !Ks || !Quu || !Qxu || !x_init || !x_out || !u_out) return DMPC_E_BADARG;
   if (!aligned16(c) || !aligned16(F) || !aligned16(Ks) || !aligned16(Quu) || !aligned16(Qxu)) return DMPC_E_BADARG;
@@ -350,7 +328,6 @@ int dmpc_lqr_saved_solve(int T, int B, int nx, int nu, const float *c, const flo
 int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                             const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
                             int32_t *info, dmpc_stream_t stream) {
-  note_other_launch();
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !Ks_out || !ks_out || (T > 1 && !F)) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;
@@ -361,7 +338,6 @@ int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const 
 int dmpc_lqr_forward_sweep(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *F,
                            const float *f, const float *x_init, const uint8_t *u_zero_mask, float *x_out,
                            float *u_out, int32_t *info, dmpc_stream_t stream) {
-  note_other_launch();
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!Ks || !ks || !x_init || !x_out || !u_out || (T > 1 && !F)) return DMPC_E_BADARG;
   if (!aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;

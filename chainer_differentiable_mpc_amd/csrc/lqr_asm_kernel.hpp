@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     const int i8 = (lane & 7) < NX ? (lane & 7) : NX - 1;
     const unsigned half_row = (unsigned)(G::OFF_F + ((r * NX + i8) * NS + (lane >> 3) * G::HROW) * 4);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) in.sr[q] = ring + (unsigned)(q * G::SLOT_B) + half_row;
+    for (int q = 0; q < 6; ++q) in.sr[q] = q < G::DEPTH_B ? ring + (unsigned)(q * G::SLOT_B) + half_row : 0u;
   }
   in.farea = __builtin_amdgcn_readfirstlane(farea);
   if constexpr (STASH) {

@@ -5,6 +5,7 @@
 // It is the completeness path, not the fast path.
 // Follows lqr/lqr_recursion.py:69-209 and mpc/active_constrained_lqr.py:67-202.
 #pragma once
+#include "api_util.hpp"
 #include "lqr_kernels.hpp"
 
 namespace dmpc {
@@ -236,7 +237,7 @@ static int launch_lqr_generic(int mode, int nx, int nu, const LqrArgs &a, hipStr
     }
   }
   if (shmem > 64 * 1024) return DMPC_E_UNSUPPORTED;
-  hipLaunchKernelGGL(lqr_generic_kernel, dim3(a.B), dim3(64), shmem, stream, args, d);
+  DMPC_LAUNCH_GGL(lqr_generic_kernel, dim3(a.B), dim3(64), shmem, stream, args, d);
   return (int)hipGetLastError();
 }
 

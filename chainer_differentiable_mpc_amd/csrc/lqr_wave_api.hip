@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/dmpc.h"
+#include "api_util.hpp"
 #include "lqr_wave_api.hpp"
 #include "lqr_wave_mfma.hpp"
 
@@ -12,10 +13,10 @@ int launch_lqr_wave_mfma_backward(int nx, int nu, bool masked, bool rollout, con
   const dim3 grid((a.B + 3) / 4), block(256);   // four wavefronts (= trajectories) per workgroup, one per SIMD
 #define X(NX_, NU_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                           \
-    if (masked && rollout) hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, true, true>), grid, block, 0, stream, a);   \
-    else if (masked) hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, true, false>), grid, block, 0, stream, a);        \
-    else if (rollout) hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, false, true>), grid, block, 0, stream, a);       \
-    else hipLaunchKernelGGL((lqr_wave_mfma_backward<NX_, NU_, false, false>), grid, block, 0, stream, a);                   \
+    if (masked && rollout) DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, true, true>), grid, block, 0, stream, a);   \
+    else if (masked) DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, true, false>), grid, block, 0, stream, a);        \
+    else if (rollout) DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, false, true>), grid, block, 0, stream, a);       \
+    else DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, false, false>), grid, block, 0, stream, a);                   \
     return (int)hipGetLastError();                                                                        \
   }
   X(32, 8)

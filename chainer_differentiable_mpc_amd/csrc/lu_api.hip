@@ -5,6 +5,11 @@
 // exist so that callers of the reference's util functions have a drop-in.
 #include <hip/hip_runtime.h>
 
+#include <cxxabi.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
 #include "colwise.hpp"
@@ -135,20 +140,32 @@ extern "C" {
 // SHA-256 prefix of the source set this library was compiled from (csrc/build.py writes it)
 const char *dmpc_source_hash(void) { return DMPC_SOURCE_HASH; }
 
+int dmpc_last_kernel_name(char *buf, size_t buf_bytes) {
+  if (buf == nullptr || buf_bytes == 0) return DMPC_E_BADARG;
+  buf[0] = 0;
+  if (dmpc::t_last_kernel == nullptr) return 0;
+  const char *mangled = hipKernelNameRefByPtr(dmpc::t_last_kernel, nullptr);
+  if (mangled == nullptr) return 0;
+  int status = 0;
+  char *plain = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+  snprintf(buf, buf_bytes, "%s", status == 0 && plain != nullptr ? plain : mangled);
+  free(plain);
+  return (int)strlen(buf);
+}
+
 
 int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, int32_t *info,
                          dmpc_stream_t stream_) {
-  note_other_launch();
   if (B <= 0 || n <= 0 || !A || !LU || !piv) return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const dim3 block(256), grid((B + 255) / 256);
   switch (n) {
 #define CASE(N) \
-  case N: hipLaunchKernelGGL((lu_factor_kernel<N>), grid, block, 0, stream, B, A, LU, piv, info); break;
+  case N: DMPC_LAUNCH_GGL((lu_factor_kernel<N>), grid, block, 0, stream, B, A, LU, piv, info); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     default:
-      hipLaunchKernelGGL(lu_factor_generic_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, n, A, LU, piv,
+      DMPC_LAUNCH_GGL(lu_factor_generic_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, B, n, A, LU, piv,
                          info);
   }
   return (int)hipGetLastError();
@@ -156,18 +173,17 @@ int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, 
 
 int dmpc_batch_lu_solve(int B, int n, int k, const float *LU, const int32_t *piv, const float *b, float *x,
                         dmpc_stream_t stream_) {
-  note_other_launch();
   if (B <= 0 || n <= 0 || k <= 0 || !LU || !piv || !b || !x) return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   const int total = B * k;
   const dim3 block(256), grid((total + 255) / 256);
   switch (n) {
 #define CASE(N) \
-  case N: hipLaunchKernelGGL((lu_solve_kernel<N>), grid, block, 0, stream, B, k, LU, piv, b, x); break;
+  case N: DMPC_LAUNCH_GGL((lu_solve_kernel<N>), grid, block, 0, stream, B, k, LU, piv, b, x); break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
     default:
-      hipLaunchKernelGGL(lu_solve_generic_kernel, dim3((total + 63) / 64), dim3(64), 0, stream, B, n, k, LU,
+      DMPC_LAUNCH_GGL(lu_solve_generic_kernel, dim3((total + 63) / 64), dim3(64), 0, stream, B, n, k, LU,
                          piv, b, x);
   }
   return (int)hipGetLastError();

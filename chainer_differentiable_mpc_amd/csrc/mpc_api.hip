@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void pnqp_kernel(const PnqpArgs a) {
 // A kernel whose workgroups meet at grid barriers needs all of them resident: cooperative launch (the runtime
 // refuses a grid that does not fit instead of letting it deadlock).
 static int launch_cooperative(const void *kernel, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t stream) {
+  note_kernel(kernel);
   const hipError_t e = hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds, stream);
   if (e == hipErrorCooperativeLaunchTooLarge) {
     (void)hipGetLastError();
@@ -127,8 +128,8 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     const dim3 grid((a.B + 15) / 16 + n_sel), block(256);
     const int variant = a.states != nullptr ? 2 : (a.f != nullptr ? 1 : 0);   // re-centring / with f_hat / plain
 #define L_(K_, ...)                                                                                            \
-  if (sel != nullptr) hipLaunchKernelGGL((mpc_backward_asm_select_kernel<__VA_ARGS__>), grid, block, K_, stream, a, *sel, n_sel, sel_sync); \
-  else hipLaunchKernelGGL((mpc_backward_asm_kernel<__VA_ARGS__>), grid, block, K_, stream, a);
+  if (sel != nullptr) DMPC_LAUNCH_GGL((mpc_backward_asm_select_kernel<__VA_ARGS__>), grid, block, K_, stream, a, *sel, n_sel, sel_sync); \
+  else DMPC_LAUNCH_GGL((mpc_backward_asm_kernel<__VA_ARGS__>), grid, block, K_, stream, a);
 #define A(NX_, NU_)                                                                                            \
   if (nx == NX_ && nu == NU_) {                                                                                \
     constexpr size_t lds = mpc_asm_lds_bytes<NX_, NU_>();                                                      \
@@ -149,13 +150,13 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
       if constexpr (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes() <= 65536) {                                  \
         if (dma_ok && sel != nullptr) {                                                                       \
           const int n_sel = select_parts(a.B);                                                                \
-          hipLaunchKernelGGL((mpc_backward_rec_dma_select_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16 + n_sel), \
+          DMPC_LAUNCH_GGL((mpc_backward_rec_dma_select_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16 + n_sel), \
                              dim3(256), (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes()), stream, a, *sel, n_sel, \
                              sel_sync);                                                                       \
           return (int)hipGetLastError();                                                                      \
         }                                                                                                     \
         if (dma_ok) {                                                                                         \
-          hipLaunchKernelGGL((mpc_backward_rec_dma_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16), dim3(256),  \
+          DMPC_LAUNCH_GGL((mpc_backward_rec_dma_kernel<NX_, NU_, DB_>), dim3((a.B + 15) / 16), dim3(256),  \
                              (MpcBackDmaLayout<NX_, NU_, DB_>::lds_bytes()), stream, a);                      \
           return (int)hipGetLastError();                                                                      \
         }                                                                                                     \
@@ -164,7 +165,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     if (a.sync != nullptr)                                                                                    \
       return launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, L_>),       \
                                 dim3((a.B + GPB - 1) / GPB), dim3(256), args1, 0, stream);                    \
-    hipLaunchKernelGGL((mpc_backward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
+    DMPC_LAUNCH_GGL((mpc_backward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
                        a);                                                                                    \
     return (int)hipGetLastError();                                                                            \
   }
@@ -179,7 +180,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     if (a.sync != nullptr)                                                                                        \
       return launch_cooperative(reinterpret_cast<const void *>(&mpc_generic_backward_kernel<NU_>), dim3(a.B),     \
                                 dim3(64), args2, mpc_generic_back_lds_bytes<NU_>(nx), stream);                    \
-    hipLaunchKernelGGL((mpc_generic_backward_kernel<NU_>), dim3(a.B), dim3(64), mpc_generic_back_lds_bytes<NU_>(nx), \
+    DMPC_LAUNCH_GGL((mpc_generic_backward_kernel<NU_>), dim3(a.B), dim3(64), mpc_generic_back_lds_bytes<NU_>(nx), \
                        stream, a, nx);                                                                            \
     return (int)hipGetLastError();
     switch (nu) { G(1) G(2) G(3) G(4) G(5) G(6) G(7) G(8) }
@@ -200,9 +201,9 @@ static bool spec4_disabled_early() {  // (DMPC_NO_SPEC4 also selects the lane-pe
 // rollout + linearisation of the built-in pendulum: four lanes per trajectory when the 16-byte row accesses are aligned
 static void launch_pendulum_rollout(const PendulumArgs &pa, hipStream_t stream) {
   if (aligned16(pa.F, pa.C) && !spec4_disabled_early())
-    hipLaunchKernelGGL(pendulum_rollout_linearize4_kernel, dim3((4 * pa.B + 255) / 256), dim3(256), 0, stream, pa);
+    DMPC_LAUNCH_GGL(pendulum_rollout_linearize4_kernel, dim3((4 * pa.B + 255) / 256), dim3(256), 0, stream, pa);
   else
-    hipLaunchKernelGGL(pendulum_rollout_linearize_kernel, dim3((pa.B + 63) / 64), dim3(64), 0, stream, pa);
+    DMPC_LAUNCH_GGL(pendulum_rollout_linearize_kernel, dim3((pa.B + 63) / 64), dim3(64), 0, stream, pa);
 }
 
 static bool spec4_disabled() {  // DMPC_NO_SPEC4=1: the lane-per-candidate speculative search (A/B timing, longer horizons' path)
@@ -216,7 +217,7 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     // the pendulum's line search usually walks ten or more step sizes: 16 candidates per trajectory at once; every
     // candidate keeps its trajectory in LDS (T * 4 KB per workgroup) when that fits
     if (a.T <= kSpec4MaxT && !spec4_disabled()) {   // a wavefront per trajectory, all inputs and candidates in LDS
-      hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec4_kernel, dim3((a.B + 3) / 4), dim3(256),
+      DMPC_LAUNCH_GGL(mpc_forward_rec_pendulum_spec4_kernel, dim3((a.B + 3) / 4), dim3(256),
                          Spec4Layout::lds_bytes(a.T), stream, a);
       return (int)hipGetLastError();
     }
@@ -225,10 +226,10 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     const bool dma = a.B >= 4 && a.B % 4 == 0 && !mpc_dma_disabled() &&
                      aligned16(a.C, a.c, a.Ks, a.ks, a.controls, a.lower, a.upper, a.states);
     if (dma)
-      hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel<true>, dim3((a.B + 15) / 16), dim3(256),
+      DMPC_LAUNCH_GGL(mpc_forward_rec_pendulum_spec_kernel<true>, dim3((a.B + 15) / 16), dim3(256),
                          (a.traj_in_lds ? lds : 0) + SpecDmaLayout::lds_bytes(), stream, a);
     else
-      hipLaunchKernelGGL(mpc_forward_rec_pendulum_spec_kernel<false>, dim3((a.B + 15) / 16), dim3(256),
+      DMPC_LAUNCH_GGL(mpc_forward_rec_pendulum_spec_kernel<false>, dim3((a.B + 15) / 16), dim3(256),
                          a.traj_in_lds ? lds : 0, stream, a);
     return (int)hipGetLastError();
   }
@@ -240,7 +241,7 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     const dim3 grid((a.B + 15) / 16), block(256);
 #define A(NX_, NU_)                                                                                          \
   if (nx == NX_ && nu == NU_) {                                                                              \
-    hipLaunchKernelGGL((mpc_forward_asm_kernel<NX_, NU_>), grid, block, (mpc_fwd_asm_lds_bytes<NX_, NU_>()), stream, a); \
+    DMPC_LAUNCH_GGL((mpc_forward_asm_kernel<NX_, NU_>), grid, block, (mpc_fwd_asm_lds_bytes<NX_, NU_>()), stream, a); \
     return (int)hipGetLastError();                                                                           \
   }
     A(8, 2) A(3, 1) A(4, 2) A(6, 2) A(2, 2) A(1, 1) A(2, 1) A(3, 2)
@@ -251,19 +252,19 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     constexpr int GPB = 256 / L_;                                                                            \
     if constexpr (L_ == 16 && MpcFwdDmaLayout<NX_, NU_>::lds_bytes() <= 96 * 1024) {                          \
       if (fwd_dma) {                                                                                         \
-        hipLaunchKernelGGL((mpc_forward_rec_kernel<NX_, NU_, L_, true>), dim3((a.B + GPB - 1) / GPB), dim3(256), \
+        DMPC_LAUNCH_GGL((mpc_forward_rec_kernel<NX_, NU_, L_, true>), dim3((a.B + GPB - 1) / GPB), dim3(256), \
                            (MpcFwdDmaLayout<NX_, NU_>::lds_bytes()), stream, a);                             \
         return (int)hipGetLastError();                                                                       \
       }                                                                                                      \
     }                                                                                                        \
-    hipLaunchKernelGGL((mpc_forward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
+    DMPC_LAUNCH_GGL((mpc_forward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
                        a);                                                                                   \
     return (int)hipGetLastError();                                                                           \
   }
   DMPC_MPC_SHAPES(X)
 #undef X
   if (a.dyn_kind == 0 && nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
-    hipLaunchKernelGGL(mpc_generic_forward_kernel, dim3(a.B), dim3(64), mpc_generic_fwd_lds_bytes(nx, nu), stream, a,
+    DMPC_LAUNCH_GGL(mpc_generic_forward_kernel, dim3(a.B), dim3(64), mpc_generic_fwd_lds_bytes(nx, nu), stream, a,
                        nx, nu);
     return (int)hipGetLastError();
   }
@@ -351,7 +352,6 @@ size_t dmpc_coupled_workspace_bytes(int T, int n_qp_iter_max) {
 int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
               const float *x_init, int n_iter, int batch_coupled, float *x, float *fac, int32_t *piv, float *index_f,
               int32_t *n_iter_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
-  note_other_launch();
   if (B <= 0 || n <= 0 || n_iter <= 0 || !H || !q || !lower || !upper || !x || !fac || !index_f || !n_iter_out)
     return DMPC_E_BADARG;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -370,7 +370,7 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
   case N:                                                                                                        \
     if (sync != nullptr)                                                                                         \
       return launch_cooperative(reinterpret_cast<const void *>(&pnqp_kernel<N>), grid, block, args, 0, stream);  \
-    hipLaunchKernelGGL((pnqp_kernel<N>), grid, block, 0, stream, a);                                             \
+    DMPC_LAUNCH_GGL((pnqp_kernel<N>), grid, block, 0, stream, a);                                             \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
@@ -383,7 +383,6 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
                           const float *u_upper, int n_qp_iter_max, int batch_coupled, float *Ks_out, float *ks_out,
                           int32_t *n_qp_iter, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (!C_hat || !c_hat || !F_hat || !controls || !u_lower || !u_upper || !Ks_out || !ks_out || !n_qp_iter)
     return DMPC_E_BADARG;
@@ -400,7 +399,6 @@ int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const fl
                          int max_ls_iter, float *x_out, float *u_out, float *costs, float *old_costs,
                          float *alphas, float *objs, float *u_first, int32_t *n_ls_iter, int32_t *info,
                          dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!Ks || !ks || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true || !x_out ||
       !u_out || !costs || !alphas || !n_ls_iter)
@@ -417,7 +415,6 @@ int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks
                                   float max_torque, float ls_decay, int max_ls_iter, float *x_out, float *u_out,
                                   float *costs, float *old_costs, float *alphas, float *objs, float *u_first,
                                   int32_t *n_ls_iter, int32_t *info, dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 1 || B <= 0) return DMPC_E_BADARG;
   if (!Ks || !ks || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !x_out || !u_out || !costs ||
       !alphas || !n_ls_iter)
@@ -432,7 +429,6 @@ int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks
 int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const float *u, float g, float m, float l,
                                     float dt, float max_torque, float *x_out, float *F_out, float *f_out,
                                     dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 0 || B <= 0 || !x_init || !u || !x_out) return DMPC_E_BADARG;
   if (f_out != nullptr && F_out == nullptr) return DMPC_E_BADARG;
   PendulumArgs pa{T, B, x_init, u, g, m, l, dt, max_torque, x_out, F_out, f_out};
@@ -453,7 +449,6 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                           float *Ks_out, float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
                           float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
                           int32_t *info, dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (batch_coupled && n_qp_iter_max > kSyncQpIterMax) return DMPC_E_UNSUPPORTED;
   if (!C_hat || !c_hat || !F_hat || !controls || !states || !u_lower || !u_upper || !C_true || !c_true || !F_true ||
@@ -481,9 +476,8 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
 
 int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const float *u, const float *F,
                      const float *f, float *x_out, dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0 || !x_init || !u || !x_out || (T > 1 && !F)) return DMPC_E_BADARG;
-  hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), T, B, nx,
+  DMPC_LAUNCH_GGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), T, B, nx,
                      nu, x_init, u, F, f, x_out, nullptr, ChainClear{});
   return (int)hipGetLastError();
 }
@@ -499,7 +493,6 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
                  float best_cost_eps, int max_iter, int n_qp_iter_max, int scrambled_norm, int batch_coupled,
                  float *x_best, float *u_best, float *costs_best, float *du_norm_best, float *du_norm_last,
                  int32_t *state, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0 || max_iter <= 0 || n_qp_iter_max <= 0) return DMPC_E_BADARG;
   if (batch_coupled && n_qp_iter_max > kSyncQpIterMax) return DMPC_E_UNSUPPORTED;
   if (!x_init || !C || !c || !u_init || !u_lower || !u_upper || !x_best || !u_best || !costs_best || !du_norm_best ||
@@ -551,7 +544,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
         launch_pendulum_rollout(pa, stream);
       }
     } else {
-      hipLaunchKernelGGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
+      DMPC_LAUNCH_GGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
                          f, xs_it, it == 0 ? nullptr : done, it == 0 ? clear : ChainClear{});
     }
     // MPCstep.forward with need_expand: f_hat = None                                        mpc_step.py:305-328
@@ -582,20 +575,20 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
                        x_best, u_best};
     if (fused_select) continue;   // rides in the next sweep's launch (the last one: in the summary launch)
     if (nx == 3 && nu == 1)
-      hipLaunchKernelGGL((box_ddp_select_kernel<3, 1>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
+      DMPC_LAUNCH_GGL((box_ddp_select_kernel<3, 1>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
     else
-      hipLaunchKernelGGL((box_ddp_select_kernel<0, 0>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
+      DMPC_LAUNCH_GGL((box_ddp_select_kernel<0, 0>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);
     if (!copy_here)
-      hipLaunchKernelGGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
+      DMPC_LAUNCH_GGL(box_ddp_keep_kernel, dim3(grid_for(rows * nx)), dim3(256), 0, stream, T, B, nx, nu,
                          ip(w.keep), xn_it, u_new, x_best, u_best);
   }
   // fused chain: the last iteration's bookkeeping - with the summary when one workgroup does it, else as the fused
   // launch splits it
   const bool split_last = fused_select && select_parts(B) > 1;
   if (split_last)
-    hipLaunchKernelGGL((box_ddp_select_parts_kernel<3, 1>), dim3(select_parts(B)), dim3(256), 0, stream, sa,
+    DMPC_LAUNCH_GGL((box_ddp_select_parts_kernel<3, 1>), dim3(select_parts(B)), dim3(256), 0, stream, sa,
                        reinterpret_cast<unsigned *>(base + w.sel_sync));
-  hipLaunchKernelGGL(box_ddp_summary_kernel, dim3(1), dim3(1024), 0, stream, rows * nu, B, u_init, u_lower, u_upper, info,
+  DMPC_LAUNCH_GGL(box_ddp_summary_kernel, dim3(1), dim3(1024), 0, stream, rows * nu, B, u_init, u_lower, u_upper, info,
                      (int)DMPC_INFO_NONFINITE, du_norm_best, eps, state, sa, fused_select && !split_last ? 1 : 0);
   return (int)hipGetLastError();
 }
@@ -605,7 +598,6 @@ int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, con
                            const float *u_upper, const float *grad_x, const float *grad_u, float *d_x_init,
                            float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
                            dmpc_stream_t stream_) {
-  note_other_launch();
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C_hat || !c_hat || !F_hat || !x || !u || !u_lower || !u_upper || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(dC) || !aligned16(dF))
@@ -620,7 +612,7 @@ int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, con
   float *du = reinterpret_cast<float *>(base + w.du);
   uint8_t *mask = reinterpret_cast<uint8_t *>(base + w.mask);
   const size_t rows = (size_t)T * B;
-  hipLaunchKernelGGL(active_mask_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, u,
+  DMPC_LAUNCH_GGL(active_mask_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, u,
                      u_lower, u_upper, grad_x, grad_u, mask, neg, x0, (size_t)B * nx);
   // LQR_active(0, C, -d_tau, F, None, u_zero_Index=active)                               mpc_step.py:374-376
   int rc = dmpc_lqr_solve(T, B, nx, nu, C_hat, neg, F_hat, nullptr, x0, mask, nullptr, nullptr, dx, du,

@@ -142,8 +142,10 @@ class DiffLqr:
             if use_saving:
                 self.info.zero_()
             x, u, _, _ = solve_device(d[1], d[2], d[3], d[4], d[0], None, T, nx, nu, info=self.info)
+        # d[i] may share storage with the caller's tensors (detach() keeps the version counter): an in-place update of C
+        # or F between forward and backward would be mixed with gains computed from their old values - checked in backward
         self._retained = dict(x_init=d[0], C=d[1], c=d[2], F=d[3], x=x, u=u, saved=saved, out_dtype=C.dtype,
-                              out_device=C.device)
+                              out_device=C.device, versions=tuple(t._version for t in d[:4]))
         return x.to(device=C.device, dtype=C.dtype), u.to(device=C.device, dtype=C.dtype)
 
     # -- reference API ---------------------------------------------------------------------------
@@ -164,6 +166,10 @@ class DiffLqr:
         """-> (d_x_init, dC, dc, dF, df) for upstream (grad_x, grad_u)  (differentiable_lqr.py:78-142)"""
         r = self._retained if retained is None else retained
         assert r is not None, "backward() before forward()"
+        now = tuple(r[k]._version for k in ("x_init", "C", "c", "F"))
+        if now != r.get("versions", now):
+            raise RuntimeError("DiffLqr.backward: x_init, C, c or F was modified in place after forward() (tensor versions "
+                               "%r -> %r); the retained solution and gains belong to the old values" % (r["versions"], now))
         T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
         grad_x, grad_u = grad_outputs
         dev = r["C"].device

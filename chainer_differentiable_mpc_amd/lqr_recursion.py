@@ -5,6 +5,8 @@ Inputs may be torch tensors (any device / float dtype) or numpy arrays; arithmet
 the GPU; outputs are torch tensors with the dtype and device of `C`.
 """
 import numpy as np
+import collections
+
 import torch
 
 from . import _lib
@@ -132,20 +134,29 @@ class LqrRecursion:
         return self._out(x), self._out(u)
 
 
-_ws_cache = {}
+_ws_cache = collections.OrderedDict()
+_WS_CACHE_STREAMS = 4      # scratch buffers kept (least recently used first out): programs with short-lived streams
 
 
 def _workspace(nbytes, device):
     """grow-only scratch per (device, stream) - the C library allocates nothing itself.  Calls enqueued on one stream
     are ordered, so they may share a buffer; calls on different streams get different buffers.  A buffer that is
-    replaced by a larger one goes back to torch's caching allocator, which keeps it tied to the stream it was
-    allocated on (the same one), so kernels still in flight on it are safe."""
-    stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+    replaced by a larger one, or dropped as the least recently used, goes back to torch's caching allocator, which keeps
+    it tied to the stream it was allocated on (the same one), so kernels still in flight on it are safe; a buffer
+    found under a stream handle that torch has recycled was allocated on another stream and is marked as used on this
+    one (`record_stream`)."""
+    stream = _lib.stream_ptr(device) if device.type == "cuda" else 0
     key = (device.type, device.index, stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
+        while len(_ws_cache) > _WS_CACHE_STREAMS:
+            _ws_cache.popitem(last=False)
+    elif device.type == "cuda":
+        ws.record_stream(torch.cuda.current_stream(device)) if stream != getattr(ws, "_dmpc_stream", stream) else None
+    ws._dmpc_stream = stream
+    _ws_cache.move_to_end(key)
     return ws
 
 

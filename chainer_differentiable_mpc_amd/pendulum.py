@@ -86,11 +86,20 @@ class PendulumDx(torch.nn.Module):
                 not self.params.requires_grad and not x_init.requires_grad and not u.requires_grad)
 
     def host_params(self):
-        """(g, m, l) as Python floats; read back from the parameter tensor only when it has changed"""
-        key = (self.params.data_ptr(), self.params._version)
+        """(g, m, l) as Python floats for the kernels' scalar arguments.  Host-resident parameters (the default) are read
+        on every call - three floats, cheaper than any staleness check, and writes through `.data` are seen.  Parameters
+        on the GPU cost a synchronising read-back, so that one is cached on (storage, version counter); a write through
+        `.data` changes neither: call `invalidate_host_params()` after one."""
+        p = self.params
+        if not p.is_cuda:
+            return tuple(float(v) for v in p.detach().tolist()[:3])
+        key = (p.data_ptr(), p._version)
         if getattr(self, "_host_params", None) is None or self._host_params[0] != key:
-            self._host_params = (key, tuple(float(v) for v in self.params.detach().cpu().tolist()[:3]))
+            self._host_params = (key, tuple(float(v) for v in p.detach().cpu().tolist()[:3]))
         return self._host_params[1]
+
+    def invalidate_host_params(self):
+        self._host_params = None
 
     def rollout_linearize(self, x_init, u, want_model=True):
         """(x [T,B,3], F [T-1,B,3,4], f [T-1,B,3]) from x_init [B,3], u [T,B,1] in one kernel launch

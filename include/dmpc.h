@@ -44,6 +44,11 @@ int dmpc_version(void);
 /* Hash of the source set the library was built from (csrc/build.py); lets a loader refuse a stale binary. */
 const char *dmpc_source_hash(void);
 
+/* Demangled name - as a profiler (rocprofv3 --kernel-trace) lists it - of the kernel the calling thread's last dmpc_*
+ * call launched last, asked of the HIP runtime (hipKernelNameRefByPtr), not kept by hand.  Writes a NUL-terminated string
+ * into buf (truncated to buf_bytes) and returns its length; 0 = nothing launched yet.  Diagnostics / benchmark labels. */
+int dmpc_last_kernel_name(char *buf, size_t buf_bytes);
+
 /* Which kernel family a shape dispatches to: 1 = DPP row kernel (16 lanes / trajectory),
  * 2 = wave kernel (64 lanes / trajectory), 3 = generic LDS kernel, <0 unsupported. */
 int dmpc_lqr_kernel_family(int nx, int nu);
