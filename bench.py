@@ -90,6 +90,99 @@ def kernel_name():
     return _lib.last_kernel_name()
 
 
+def cpu_baseline(p, T, nx, nu, budget_s=12.0):
+    """the oracle (kind "port") on this host, float64, one thread; bounded sample"""
+    from oracle import lqr as olqr
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        import contextlib
+        ctx = contextlib.nullcontext()
+    B = p["C"].shape[1]
+    times = []
+    with ctx:
+        t_all = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 3 and time.perf_counter() - t_all > budget_s:
+                break
+            if len(times) >= 25:
+                break
+    med = statistics.median(times)
+    return dict(value=B * T / med, unit="timestep-solves/s", cores=1, kind="port",
+                sample="numpy float64 oracle (oracle/lqr.py, restates lqr/lqr_recursion.py), full workload "
+                       "B=%d T=%d, median of %d runs, %d host cores present, BLAS limited to 1 thread"
+                       % (B, T, len(times), os.cpu_count() or 0)), xr, ur
+
+
+_MP_PROBLEM = None
+
+
+def _mp_solve_shard(job):
+    """worker: the oracle on one contiguous batch shard of the fork-inherited problem"""
+    from oracle import lqr as olqr
+    b0, b1, T, nx, nu = job
+    p = _MP_PROBLEM
+    try:
+        from threadpoolctl import threadpool_limits
+        ctx = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        import contextlib
+        ctx = contextlib.nullcontext()
+    with ctx:
+        x, u = olqr.lqr_solve(p["x_init"][b0:b1], p["C"][:, b0:b1], p["c"][:, b0:b1], p["F"][:, b0:b1],
+                              p["f"][:, b0:b1], T, nx, nu)
+    return float(x.sum() + u.sum())
+
+
+def cpu_baseline_multiprocess(p, T, nx, nu, procs, reps=3):
+    """the same oracle with the batch sharded over `procs` worker processes (fork; started BEFORE this process touches
+    the GPU).  Wall time of one whole-batch solve = the slowest shard; median of `reps`."""
+    import multiprocessing as mp
+    from chainer_differentiable_mpc_amd.dist import shard_bounds
+    global _MP_PROBLEM
+    _MP_PROBLEM = p
+    B = p["C"].shape[1]
+    jobs = [shard_bounds(B, r, procs) + (T, nx, nu) for r in range(procs)]
+    times = []
+    with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_mp_solve_shard, jobs)          # warm-up: page in numpy in every worker
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            pool.map(_mp_solve_shard, jobs, chunksize=1)
+            times.append(time.perf_counter() - t0)
+    _MP_PROBLEM = None
+    med = statistics.median(times)
+    return dict(value=B * T / med, unit="timestep-solves/s", cores=procs, kind="port",
+                sample="numpy float64 oracle, full workload B=%d T=%d sharded over %d worker processes (one BLAS "
+                       "thread each), median of %d runs; %d host cores present, %d usable by this process"
+                       % (B, T, procs, reps, os.cpu_count() or 0, usable_cores()))
+
+
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def event_time(fn, reps, warm=3):
+    """average duration of fn() in seconds: HIP events on the current stream around `reps` back-to-back calls"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
 def hbm_copy_calibration(device, gib=1.0, reps=5):
     """what THIS box's memory system sustains on the plainest streaming pattern: a device-to-device copy of `gib` GiB
     (read + write, far beyond the Infinity Cache), GB/s of traffic, median of `reps` - MI355X_MICROARCH.md quotes

@@ -108,7 +108,8 @@ class BoxDDP(torch.nn.Module):
             kind, params, Fd, fd = 0, None, dynamics.F, dynamics.f
         elif hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x_init, u) and (nx, nu) == (3, 1):
             g_, m_, l_ = dynamics.host_params()
-            params = (ctypes.c_float * 5)(g_, m_, l_, float(dynamics.dt), float(dynamics.max_torque))
+            params = (ctypes.c_float * 6)(g_, m_, l_, float(dynamics.dt), float(dynamics.max_torque),
+                                          1.0 if dynamics.clamp_grad_closed else 0.0)
             kind, Fd, fd = 1, None, None
         else:
             return None

@@ -427,11 +427,11 @@ int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks
 }
 
 int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const float *u, float g, float m, float l,
-                                    float dt, float max_torque, float *x_out, float *F_out, float *f_out,
-                                    dmpc_stream_t stream_) {
+                                    float dt, float max_torque, int clamp_grad_closed, float *x_out, float *F_out,
+                                    float *f_out, dmpc_stream_t stream_) {
   if (T <= 0 || B <= 0 || !x_init || !u || !x_out) return DMPC_E_BADARG;
   if (f_out != nullptr && F_out == nullptr) return DMPC_E_BADARG;
-  PendulumArgs pa{T, B, x_init, u, g, m, l, dt, max_torque, x_out, F_out, f_out};
+  PendulumArgs pa{T, B, x_init, u, g, m, l, dt, max_torque, clamp_grad_closed, x_out, F_out, f_out};
   launch_pendulum_rollout(pa, static_cast<hipStream_t>(stream_));
   return (int)hipGetLastError();
 }
@@ -516,6 +516,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   const float pg = dyn_kind == 1 ? dyn_params[0] : 0.f, pm = dyn_kind == 1 ? dyn_params[1] : 0.f,
               pl = dyn_kind == 1 ? dyn_params[2] : 0.f, pdt = dyn_kind == 1 ? dyn_params[3] : 0.f,
               pmax = dyn_kind == 1 ? dyn_params[4] : 0.f;
+  const int pclosed = dyn_kind == 1 ? (dyn_params[5] != 0.f) : 0;
   const size_t rows = (size_t)T * B;
   // loop state, the bookkeeping workgroups' meeting words and the flags are cleared by the chain's first launch
   ChainClear clear;
@@ -539,7 +540,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
     if (dyn_kind == 1) {
       if (it == 0 || !fuse_lin) {
-        PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, xs_it, fp(w.F), fp(w.f), it == 0 ? nullptr : done, C, c,
+        PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, pclosed, xs_it, fp(w.F), fp(w.f), it == 0 ? nullptr : done, C, c,
                         c_back, it == 0 ? clear : ChainClear{}};
         launch_pendulum_rollout(pa, stream);
       }
@@ -564,7 +565,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs_it, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
                   dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1, costs,
                   /*old_costs: nobody reads them here*/ nullptr,
-                  alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, done,
+                  alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, pclosed, done,
                   fuse_lin ? fp(w.F) : nullptr, fuse_lin ? fp(w.f) : nullptr, fuse_lin ? c_back : nullptr, 0,
                   fused_select && info != nullptr ? ip(w.info_back) : nullptr};
     rc = launch_mpc_fwd(nx, nu, fa, stream);

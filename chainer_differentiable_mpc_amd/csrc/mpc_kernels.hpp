@@ -249,9 +249,19 @@ __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs
 // nominal trajectory and its cost EQUALS the old one (mpc_step.py:196), which needs bit-equal dynamics.
 struct PendulumModel {
   float kg, ku, dt, max_torque;  // 3g/(2l), 3/(m l^2)
+  // Derivative of the torque clamp AT the limits +-max_torque: 1 (closed interval) or 0 (open).  Box-DDP's bounds equal
+  // the torque limit, so saturated controls sit exactly there and the choice decides d x_{t+1} / d u_t for them.  The
+  // reference differentiates F.clip with chainer.grad; Chainer's ClipGrad is taken to be inclusive (DESIGN.md section 4
+  // states this as an assumption) - callers pass PendulumDx.clamp_grad_closed, the one place where it is set.
+  bool clamp_closed;
+  __device__ __forceinline__ float clamp_grad(float u) const {
+    const float a = fabsf(u);
+    return (clamp_closed ? a <= max_torque : a < max_torque) ? 1.f : 0.f;
+  }
 };
-__device__ __forceinline__ PendulumModel pendulum_model(float g, float m, float l, float dt, float max_torque) {
-  return PendulumModel{3.f * g / (2.f * l), 3.f / (m * (l * l)), dt, max_torque};
+__device__ __forceinline__ PendulumModel pendulum_model(float g, float m, float l, float dt, float max_torque,
+                                                        int clamp_closed) {
+  return PendulumModel{3.f * g / (2.f * l), 3.f / (m * (l * l)), dt, max_torque, clamp_closed != 0};
 }
 // sin and cos of a small angle.  The rotation below takes them of the per-step increment wn * dt (|.| < pi/4 for any
 // angular velocity below 15 rad/s at dt = 0.05): no argument reduction is needed there, and the library routine's
@@ -294,7 +304,7 @@ __device__ __forceinline__ void pendulum_next(const PendulumModel &p, float c, f
 // kernel and for the line search's accepted pass (which hands the next iLQR iteration its model).
 __device__ __forceinline__ void pendulum_jacobian_store(const PendulumModel &p, float c, float s, float w, float u, float cn,
                                                         float sn, float nw, float *Fp, float *fq) {
-  const float inside = (u >= -p.max_torque && u <= p.max_torque) ? 1.f : 0.f;   // closed interval, as F.clip's backward
+  const float inside = p.clamp_grad(u);
   const float r2 = c * c + s * s;
   const float dnw[4] = {0.f, p.dt * p.kg, 1.f, p.dt * p.ku * inside};
   const float dnth[4] = {-s / r2 + p.dt * dnw[0], c / r2 + p.dt * dnw[1], p.dt * dnw[2], p.dt * dnw[3]};
@@ -336,6 +346,7 @@ struct MpcFwdArgs {
   //   0 LinDx (F, f above)   1 the pendulum of env_dx/pendulum.py:65-102, simple model (nx = 3, nu = 1)
   int dyn_kind;
   float pend_g, pend_m, pend_l, pend_dt, pend_max_torque;
+  int pend_clamp_closed;                 // derivative of the torque clamp at its limits (PendulumModel::clamp_grad)
   const int32_t *done;                   // device flag of the BoxDDP loop: non-zero -> no-op
   // The accepted trajectory IS the next iLQR iteration's nominal one (BoxDDP re-rolls it with get_traj and linearises
   // it, mpc/box_ddp.py:123-136): the speculative pendulum search can write that model while it writes the
@@ -560,7 +571,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
         if constexpr (NX == 3 && NU == 1) {
           const float cs = G::template bcast<0>(tau), sn = G::template bcast<1>(tau), dth = G::template bcast<2>(tau);
           const float uu = G::template bcast<3>(tau);
-          const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+          const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque, a.pend_clamp_closed);
           float cn, sn2, wn, nth;
           pendulum_next(pm, cs, sn, dth, uu, cn, sn2, wn, nth);
           xh = lane == 0 ? cn : (lane == 1 ? sn2 : (lane == 2 ? wn : 0.f));
@@ -672,7 +683,7 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
   if (!live) b = a.B - 1;
   const int T = a.T;
   const size_t B = (size_t)a.B;
-  const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+  const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque, a.pend_clamp_closed);
   extern __shared__ float traj[];                            // [T][4][256] when a.traj_in_lds
   const bool keep_traj = a.traj_in_lds != 0 && a.objs == nullptr;
 
@@ -998,7 +1009,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(con
   if (b >= a.B) return;   // whole wavefront; no workgroup barrier below
   const int T = a.T;
   const size_t B = (size_t)a.B;
-  const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque);
+  const PendulumModel pm = pendulum_model(a.pend_g, a.pend_m, a.pend_l, a.pend_dt, a.pend_max_torque, a.pend_clamp_closed);
   extern __shared__ float spec4_lds[];
   float *in_ = spec4_lds + (size_t)wave * 2 * T * Lay::SLOT, *traj = in_ + (size_t)T * Lay::SLOT;
 
@@ -1183,7 +1194,7 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(con
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)
 // (env_dx/pendulum.py:84-98, simple model), F_t = d x_{t+1} / d [x_t; u_t], f_t = x_{t+1} - F_t [x_t; u_t] - what
 // BoxDDP obtains from get_traj (util.py:201-277) followed by linearize_dynamics (mpc/approximate.py:77-119, there
-// through chainer.grad).  The torque clamp has derivative 1 on the CLOSED interval [-max_torque, max_torque] (Chainer's F.clip backward, torch.clamp autograd), else 0: box-DDP's bounds equal the torque limit, so saturated controls sit exactly on it.
+// through chainer.grad).  The derivative of the torque clamp at its limits is the caller's choice (PendulumModel::clamp_grad).
 // The first launch of a dmpc_box_ddp chain clears the words the chain accumulates into (a memset or fill launch of its
 // own costs 2-5 us of GPU time each for a few bytes): thread g of the grid zeroes word g of each range.
 struct ChainClear {
@@ -1200,6 +1211,7 @@ struct PendulumArgs {
   int T, B;
   const float *x_init, *u;   // [B,3], [T,B,1]
   float g, m, l, dt, max_torque;
+  int clamp_closed;          // derivative of the torque clamp at its limits (PendulumModel::clamp_grad)
   float *x, *F, *f;          // [T,B,3], [T-1,B,3,4] or nullptr, [T-1,B,3] or nullptr
   const int32_t *done;       // device flag of the BoxDDP loop: non-zero -> no-op
   // optional Taylor re-centring of a QuadCost at the rolled-out trajectory (what taylor_c_kernel computes):
@@ -1215,7 +1227,7 @@ __device__ __forceinline__ void pendulum_rollout_linearize_body(const PendulumAr
   if (a.done != nullptr && *a.done != 0) return;
   const size_t B = (size_t)a.B;
   float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
-  const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque);
+  const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque, a.clamp_closed);
   const bool taylor = a.c_back != nullptr;
   // inputs of step t + 1 are fetched while step t runs its atan2 / sin / cos (one lane per trajectory: nothing else
   // hides the latency)
@@ -1289,7 +1301,7 @@ __global__ __launch_bounds__(256) void pendulum_rollout_linearize4_kernel(const 
   if (a.done != nullptr && *a.done != 0) return;
   const size_t B = (size_t)a.B;
   float c = a.x_init[b * 3 + 0], s = a.x_init[b * 3 + 1], w = a.x_init[b * 3 + 2];
-  const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque);
+  const PendulumModel pm = pendulum_model(a.g, a.m, a.l, a.dt, a.max_torque, a.clamp_closed);
   const bool taylor = a.c_back != nullptr;
   const unsigned m0 = sub == 0 ? ~0u : 0u, m1 = sub == 1 ? ~0u : 0u, m2 = sub == 2 ? ~0u : 0u, m3 = sub == 3 ? ~0u : 0u;
   auto pick4 = [&](float e0, float e1, float e2, float e3) {   // element `sub` (bit masks: no exec-mask branches)
@@ -1325,7 +1337,7 @@ __global__ __launch_bounds__(256) void pendulum_rollout_linearize4_kernel(const 
     float cn, sn, nw, nth;
     pendulum_next(pm, c, s, w, ur, cn, sn, nw, nth);
     if (a.F != nullptr && sub < 3) {
-      const float inside = (ur >= -pm.max_torque && ur <= pm.max_torque) ? 1.f : 0.f;
+      const float inside = pm.clamp_grad(ur);
       const float r2 = c * c + s * s;
       const float dnw[4] = {0.f, pm.dt * pm.kg, 1.f, pm.dt * pm.ku * inside};
       const float dnth[4] = {-s / r2 + pm.dt * dnw[0], c / r2 + pm.dt * dnw[1], pm.dt * dnw[2], pm.dt * dnw[3]};

@@ -10,6 +10,13 @@ class PendulumDx(torch.nn.Module):
         super().__init__()
         self.simple = simple
         self.max_torque = 2.0
+        # Derivative of the torque clamp AT u = +-max_torque (forward(): torch.clamp; the reference: F.clip, env_dx/
+        # pendulum.py:86, differentiated by chainer.grad in linearize_dynamics).  True = 1 there (closed interval: what
+        # Chainer's ClipGrad and torch.clamp's autograd are taken to compute), False = 0.  Box-DDP's bounds equal the
+        # torque limit, so saturated controls sit exactly on it and this decides their column of F_t.  THE one place
+        # where the convention is set: `linearize`, the kernels (`rollout_linearize`, `dmpc_box_ddp`) and the tests'
+        # oracle all read it.  Chainer is not installable here, so the closed interval is an assumption.
+        self.clamp_grad_closed = True
         self.dt = 0.05
         self.n_state = 3
         self.n_ctrl = 1
@@ -62,7 +69,8 @@ class PendulumDx(torch.nn.Module):
             xt, ut = xs[t], u[t]
             c, s, w = xt[:, 0], xt[:, 1], xt[:, 2]
             uc = torch.clamp(ut[:, 0], -self.max_torque, self.max_torque)
-            inside = ((ut[:, 0] >= -self.max_torque) & (ut[:, 0] <= self.max_torque)).to(xt.dtype)   # closed, like F.clip's backward
+            au = ut[:, 0].abs()
+            inside = (au <= self.max_torque if self.clamp_grad_closed else au < self.max_torque).to(xt.dtype)
             r2 = c * c + s * s
             th = torch.atan2(s, c)
             nw = w + dt * (3. * g / (2. * l) * s + 3. * uc / (m * l ** 2))
@@ -115,7 +123,8 @@ class PendulumDx(torch.nn.Module):
         g_, m_, l_ = self.host_params()
         with _lib.guard(d):
             rc = lib.dmpc_pendulum_rollout_linearize(T, B, _lib.ptr(x0), _lib.ptr(ud), g_, m_, l_, float(self.dt),
-                                                     float(self.max_torque), _lib.ptr(x), _lib.ptr(F), _lib.ptr(f),
+                                                     float(self.max_torque), int(self.clamp_grad_closed), _lib.ptr(x),
+                                                     _lib.ptr(F), _lib.ptr(f),
                                                      _lib.stream_ptr(d))
         _lib.check(rc, "dmpc_pendulum_rollout_linearize")
         return x.to(x_init.dtype), (None if F is None else F.to(x_init.dtype)), (None if f is None else f.to(x_init.dtype))

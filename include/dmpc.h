@@ -201,10 +201,13 @@ int dmpc_mpc_forward_rec_pendulum(int T, int B, const float *Ks, const float *ks
 /* Caller-side helper of the pendulum experiments: rollout x_{t+1} = pendulum(x_t, u_t)
  * (util.py:201-277 get_traj with env_dx/pendulum.py:65-102) and its analytic linearisation
  * F_t [x_t;u_t] + f_t = pendulum(x_t, u_t) (mpc/approximate.py:77-119, there by chainer.grad) in one launch.
- *   x_out [T,B,3];  F_out [T-1,B,3,4] or NULL;  f_out [T-1,B,3] or NULL */
+ *   x_out [T,B,3];  F_out [T-1,B,3,4] or NULL;  f_out [T-1,B,3] or NULL
+ *   clamp_grad_closed: derivative of the torque clamp (env_dx/pendulum.py:86, F.clip) AT u = +-max_torque: != 0 -> 1 (the
+ *   closed interval, what Chainer's ClipGrad is taken to compute), 0 -> 0.  Box-DDP's bounds equal the torque limit, so
+ *   saturated controls sit exactly there. */
 int dmpc_pendulum_rollout_linearize(int T, int B, const float *x_init, const float *u, float g, float m, float l,
-                                    float dt, float max_torque, float *x_out, float *F_out, float *f_out,
-                                    dmpc_stream_t stream);
+                                    float dt, float max_torque, int clamp_grad_closed, float *x_out, float *F_out,
+                                    float *f_out, dmpc_stream_t stream);
 
 /* Nominal rollout under a LinDx (util.py:239-277 get_traj): x_0 = x_init, x_{t+1} = F_t [x_t; u_t] + f_t (f may be
  * NULL), with the summation order of the MPC step's own line-search rollout - so that a trajectory re-rolled from
@@ -214,7 +217,8 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
 
 /* The outer box-DDP loop (BoxDDP.forward, mpc/box_ddp.py:93-230) for a QuadCost and either a LinDx (dyn_kind 0:
  * F [T-1|T,B,nx,ns], f [T-1,B,nx] or NULL) or the built-in pendulum (dyn_kind 1: F = f = NULL, dyn_params = HOST
- * array {g, m, l, dt, max_torque}, nx = 3, nu = 1), as ONE chain of launches: per iteration the nominal rollout
+ * array {g, m, l, dt, max_torque, clamp_grad_closed (0 or 1, as dmpc_pendulum_rollout_linearize)}, nx = 3, nu = 1), as
+ * ONE chain of launches: per iteration the nominal rollout
  * (util.py:239-277) and, for the pendulum, its linearisation (mpc/approximate.py:77-119), the MPC step with
  * need_expand (mpc_step.py:288-328), the per-sample "best so far" update (box_ddp.py:200-209) and the stop tests
  * (:223-230), all decided on the device: max_iter iterations are enqueued, those after the stop are no-ops.

@@ -86,17 +86,18 @@ def pendulum_step(x, u, g=10.0, m=1.0, l=1.0, dt=0.05, max_torque=2.0):
     return np.stack((np.cos(newth), np.sin(newth), newdth), axis=1)
 
 
-def pendulum_linearize(x, u, g=10.0, m=1.0, l=1.0, dt=0.05, max_torque=2.0):
-    """F_t = d step / d [x;u], f_t = step - F_t [x;u] along the trajectory re-rolled from x[0] (approximate.py:77-119)"""
+def pendulum_linearize(x, u, g=10.0, m=1.0, l=1.0, dt=0.05, max_torque=2.0, clamp_grad_closed=True):
+    """F_t = d step / d [x;u], f_t = step - F_t [x;u] along the trajectory re-rolled from x[0] (approximate.py:77-119).
+    clamp_grad_closed: the derivative of F.clip AT the limits (1 on the closed interval, else 0) - the tests pass the
+    product's one flag (PendulumDx.clamp_grad_closed); the fixture recorded through the stand-in's F.clip pins True."""
     T = x.shape[0]
     xs = [x[0]]
     Fs, fs = [], []
     for t in range(T - 1):
         xt, ut = xs[t], u[t]
         c, s, w = xt[:, 0], xt[:, 1], xt[:, 2]
-        # d clip(u) / du = 1 on the CLOSED interval (Chainer's F.clip backward, torch.clamp autograd): the box-DDP
-        # bounds equal the torque limit, so saturated controls sit exactly on it
-        inside = ((ut[:, 0] >= -max_torque) & (ut[:, 0] <= max_torque)).astype(xt.dtype)
+        au = np.abs(ut[:, 0])
+        inside = (au <= max_torque if clamp_grad_closed else au < max_torque).astype(xt.dtype)
         r2 = c * c + s * s
         new_x = pendulum_step(xt, ut, g, m, l, dt, max_torque)
         nth = np.arctan2(s, c) + new_x[:, 2] * dt

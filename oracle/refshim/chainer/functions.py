@@ -308,10 +308,17 @@ def mean_squared_error(a, b):
 
 
 # ---- what env_dx/pendulum.py:65-102 (PendulumDx.forward) needs on top of the hot path's list
+# Derivative of F.clip AT the limits.  Chainer's ClipGrad is TAKEN to be inclusive, (x_min <= x) & (x <= x_max); Chainer is
+# not installable here, so this is an assumption and not a pin.  Every fixture that goes through
+# chainer.grad of PendulumDx.forward (pendulum.npz, pendulum_boxddp.npz, imitation_*.npz) inherits the setting; the
+# product's counterpart is PendulumDx.clamp_grad_closed.
+CLIP_GRAD_CLOSED = True
+
+
 def clip(x, x_min, x_max):
-    """F.clip; the derivative is 1 on the closed interval [x_min, x_max] (Chainer's ClipGrad: (x_min <= x) & (x <= x_max))"""
+    """F.clip; derivative 1 inside (x_min, x_max), CLIP_GRAD_CLOSED at the two limits, 0 outside"""
     r = _raw(x)
-    inside = (x_min <= r) & (r <= x_max)
+    inside = ((x_min <= r) & (r <= x_max)) if CLIP_GRAD_CLOSED else ((x_min < r) & (r < x_max))
     return make(np.clip(r, x_min, x_max), (x,), lambda g: (g * inside,))
 
 

@@ -114,6 +114,34 @@ def test_approximations_keep_the_graph_to_learnable_parameters():
     assert not f2.requires_grad and torch.equal(F2, F)
 
 
+def test_clamp_derivative_convention_is_one_flag():
+    """The derivative of the torque clamp AT u = +-max_torque is set in ONE place, PendulumDx.clamp_grad_closed (an
+    assumption about Chainer's F.clip backward): `linearize` follows it, the oracle takes it as an
+    argument, and the two agree in both settings; inside and outside the interval nothing depends on it."""
+    from oracle import box_ddp as obox
+    T, B = 6, 5
+    x0 = sample_xinit(B, seed=2)
+    u = np.random.RandomState(5).uniform(-3.0, 3.0, size=(T, B, 1))
+    u[1, :, 0] = 2.0          # exactly on the upper limit
+    u[2, :, 0] = -2.0         # ... and on the lower one
+    u[3, :, 0] = [2.5, -2.5, 1.0, -1.0, 0.0]
+    col = {}
+    for closed in (True, False):
+        dx = PendulumDx()
+        assert dx.clamp_grad_closed is True       # the default the fixtures were recorded with
+        dx.clamp_grad_closed = closed
+        x = util.get_traj(T, _t(u), _t(x0), dx)
+        F, f = dx.linearize(x, _t(u))
+        Fo, fo = obox.pendulum_linearize(x.numpy(), u, clamp_grad_closed=closed)
+        np.testing.assert_allclose(F.numpy(), Fo, atol=1e-13)
+        np.testing.assert_allclose(f.numpy(), fo, atol=1e-13)
+        col[closed] = F.numpy()[:, :, 2, 3]         # d (new dtheta) / d u
+    np.testing.assert_allclose(col[True][1:3], 0.15, rtol=1e-12)      # dt * 3 / (m l^2) at the limits ...
+    assert np.all(col[False][1:3] == 0.0)                             # ... or nothing
+    np.testing.assert_allclose(col[True][3], [0, 0, 0.15, 0.15, 0.15], rtol=1e-12)
+    np.testing.assert_array_equal(col[True][[0, 3, 4]], col[False][[0, 3, 4]])
+
+
 def test_pendulum_host_functions_match_the_reference():
     """PendulumDx.forward / get_true_obj / constants (env_dx/pendulum.py:31-145), the analytic and the autograd
     linearisation, IL_Env.sample_xinit (il_env.py:55-69)"""

@@ -31,6 +31,84 @@ def test_util_helpers_match_the_oracle_on_the_device():
     helpers_against_oracle("cuda")
 
 
+def test_approximate_cost_matches_the_reference_on_the_device():
+    """SURVEY 8f-4, mpc/approximate.py:18-54: `approximate_cost` on CUDA tensors against the vectors recorded from the
+    reference's own function (tests/golden/approx_cost.npz) - float64 on the device at 1e-10, float32 at the float32
+    tolerance - for a quadratic and a non-quadratic cost; and `linearize_dynamics` by autograd on the device against the
+    reference's chainer.grad linearisation of PendulumDx.forward (pendulum.npz)."""
+    from chainer_differentiable_mpc_amd.approximate import approximate_cost, linearize_dynamics
+    g = load("approx_cost.npz")
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+        x, u = dev(g["x"], dtype), dev(g["u"], dtype)
+        Cq, cq = dev(g["Cq"], dtype), dev(g["cq"], dtype)
+
+        def quad(tau):
+            return 0.5 * ((tau @ Cq) * tau).sum(1) + (tau * cq).sum(1)
+
+        def nonquad(tau):
+            return torch.sqrt(1.0 + (tau ** 2).sum(1)) + (torch.sin(tau[:, :-1]) * tau[:, 1:]).sum(1)
+
+        for name, fn in (("quad", quad), ("nonquad", nonquad)):
+            H, gr, c = approximate_cost(x, u, fn)
+            assert H.is_cuda and gr.is_cuda and c.is_cuda and H.dtype == dtype
+            assert_close(npy(H), g[name + "_H"], tol, name + " H")
+            assert_close(npy(gr), g[name + "_g"], tol, name + " grads - H tau")
+            assert_close(npy(c), g[name + "_cost"], tol, name + " cost")
+    gp = load("pendulum.npz")
+    dx = PendulumDx()
+    F, f = linearize_dynamics(dev(gp["lin_x"], torch.float64), dev(gp["lin_u"], torch.float64), lambda a, b: dx(a, b))
+    assert F.is_cuda
+    assert_close(npy(F), gp["lin_F"], 1e-10, "autograd F")
+    assert_close(npy(f), gp["lin_f"], 1e-10, "autograd f")
+
+
+def test_clamp_derivative_flag_reaches_the_kernels():
+    """PendulumDx.clamp_grad_closed (the ONE place where the derivative of the torque clamp at u = +-max_torque is set,
+    DESIGN.md section 4) reaches dmpc_pendulum_rollout_linearize and the device-driven box-DDP loop: both settings
+    against the oracle called with the same flag; with torques exactly on the limits the model differs, and so does the
+    second iterate of box-DDP started from saturated controls."""
+    from oracle import box_ddp as obox
+    T, B = 8, 24
+    x0 = sample_xinit_np(B)
+    u = np.random.RandomState(7).uniform(-3.0, 3.0, size=(T, B, 1)).astype(np.float32)
+    u[::2, :, 0] = np.where(np.arange(B) % 2 == 0, 2.0, -2.0)      # every other step exactly on a limit
+    models = {}
+    for closed in (True, False):
+        dx = PendulumDx()
+        dx.clamp_grad_closed = closed
+        x, F, f = dx.rollout_linearize(dev(x0), dev(u))
+        Fo, fo = obox.pendulum_linearize(npy(x).astype(np.float64), u.astype(np.float64), clamp_grad_closed=closed)
+        assert_close(npy(F), Fo, 2e-5, "F closed=%r" % closed)
+        assert_close(npy(f), fo, 5e-5, "f closed=%r" % closed)
+        Fh, fh = dx.linearize(x, dev(u))                           # the torch restatement reads the same flag
+        assert_close(npy(F), npy(Fh), 2e-5, "F kernel vs PendulumDx.linearize closed=%r" % closed)
+        models[closed] = npy(F)[:, :, 2, 3]
+    assert np.allclose(models[True][0], 0.15, rtol=1e-6) and np.all(models[False][0] == 0.0)
+    # through the device loop: two iterations from controls saturated on the limit
+    outs = {}
+    for closed in (True, False):
+        dx = PendulumDx()
+        dx.clamp_grad_closed = closed
+        q, pp = dx.get_true_obj()
+        Q = torch.diag(q).cuda()[None, None].expand(T, B, -1, -1).contiguous()
+        pv = pp.cuda()[None, None].expand(T, B, -1).contiguous()
+        solver = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, dev(np.full((T, B, 1), 2.0)), eps=dx.mpc_eps, max_iter=2,
+                        exit_unconverged=False, line_search_decay=dx.linesearch_decay,
+                        max_line_search_iter=dx.max_linesearch_iter, quiet=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with torch.no_grad():
+                xs, us, _ = solver((dev(x0), QuadCost(Q, pv), dx))
+        outs[closed] = npy(us)
+        assert np.isfinite(outs[closed]).all()
+    assert np.abs(outs[True] - outs[False]).max() > 1e-3      # the convention is live in the fused loop
+
+
+def sample_xinit_np(B, seed=3):
+    from chainer_differentiable_mpc_amd.pendulum import sample_xinit
+    return sample_xinit(B, seed=seed).astype(np.float32)
+
+
 def test_pendulum_kernel_matches_the_reference_on_and_beyond_the_clamp():
     """dmpc_pendulum_rollout_linearize against PendulumDx.forward + linearize_dynamics of the reference
     (tests/golden/pendulum.npz), with torques exactly ON the clamp: d clip / du = 1 there"""
