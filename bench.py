@@ -220,9 +220,9 @@ def secondary_metrics(device, d_headline):
     sv = [None]
 
     def fwd_bwd():          # what DiffLqr runs: the forward solve leaves K, Quu, Qxu, the second solve reuses them
-        xs, us, Ks, _, Quu, Qxu = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
-        sv[0] = (xs, us, (Ks, Quu, Qxu))
-        kkt_grad_device(d["C"], d["c"], d["F"], xs, us, gx, gu, T, nx, nu, saved=(Ks, Quu, Qxu))
+        xs, us, Ks, _, Quu, Qxu, Vv = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
+        sv[0] = (xs, us, (Ks, Quu, Qxu, Vv))
+        kkt_grad_device(d["C"], d["c"], d["F"], xs, us, gx, gu, T, nx, nu, saved=(Ks, Quu, Qxu, Vv))
 
     t_full = event_time(fwd_bwd_full, 50)
     tb_full = event_time(lambda: kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu), 50)

@@ -22,6 +22,10 @@ static inline void note_kernel(const void *host_function) { t_last_kernel = host
     hipLaunchKernelGGL(kernel, __VA_ARGS__);                         \
   } while (0)
 
+// lqr_api.hip: DiffLqr.backward in one launch from the saving solve's gains and value functions (reads neither C nor c)
+int lqr_adjoint(int T, int B, int nx, int nu, const float *F, const float *grad_x, const float *grad_u, const float *Ks,
+                const float *Quu, const float *Qxu, const float *Vv, const float *x, const float *u, int strict_math,
+                float *d_x_init, float *dC, float *dc, float *dF, float *df, int32_t *info, hipStream_t stream);
 // lqr_api.hip: DiffLqr.backward's second solve on [grad_x; grad_u] as two arrays (kkt_api.hip)
 int lqr_second_solve(int T, int B, int nx, int nu, const float *C, const float *cx, const float *cu, const float *F,
                      const float *Ks, const float *Quu, const float *Qxu, float *x_out, float *u_out, int32_t *info,

@@ -246,7 +246,7 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, unroll=False, save=False, affine=False):
+def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, unroll=False, save=False, affine=False, adj=False):
     """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
     is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
     rollout needs no change); the value update keeps the unmasked blocks (:143-145).
@@ -267,10 +267,18 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     qu + Quu k = 0), then the same rollout.  The slot's C region carries [K_t | Qxu_t | Quu_t] instead of C_t (36
     chunks instead of 100 at (8,2); the other lanes of those groups fetch a resident zero chunk): 504 B per
     timestep-solve instead of 832 B, and ~60 instructions per step instead of ~165.
+    adj (affine only): DiffLqr.backward in ONE launch that never reads C (differentiable_lqr.py:78-142).  The reference's
+    solve is exact block elimination of the KKT system, so its co-states are the value function's gradients:
+    lambda_t = V_t x_t + v_t and d_lambda_t = V_t dx_t + v'_t (v' the affine value term of the second solve) for any, also
+    non-symmetric, C (tests/test_saved_gains_identity_cpu.py).  With [V_t | v_t] left in HBM by the saving solve the backward
+    sweep is the affine recursion above (v'_t kept in LDS, in the area f would take), and the rollout of d_tau computes
+    lambda_{t+1}, d_lambda_{t+1} on the way and writes dC_t, dc_t, dF_t, df_t (:128-134) itself - rows through an LDS
+    staging area, whole 16-byte chunks to HBM.  [V_t | v_t | x_t | u_t] come through a four-slot LDS-DMA ring in the idle
+    backward ring.
     expand (mpc only): need_expand of MPCstep.forward (mpc_step.py:305-317) inside the sweep - the slot padding also
     takes x_t (4 nx more dwords) and every step starts with c_hat = C [x_t; u_t] + c in the affine column."""
     D = DB if (masked or mpc) else RING_DEPTH      # ring slots (the register sets stay three)
-    kind = "mpc" if mpc else "masked" if masked else "save" if save else "affine" if affine else "plain"
+    kind = "mpc" if mpc else "masked" if masked else "save" if save else "adj" if adj else "affine" if affine else "plain"
     L = Layout(nx, nu, D)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
@@ -280,6 +288,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     assert not expand or (mpc and 12 * nu + 4 * nx <= 64)
     assert not save or (write_k and not masked and not mpc and not unroll)
     assert not affine or (stash and not write_k and not masked and not mpc and not unroll and not save and ns >= 4)
+    assert not adj or affine
     P = Prog()
     R = Regs(VBASE)
     # ---- operand names (C++ side: struct LqrAsmIn of lqr_asm_gen.hpp, filled by lqr_asm_kernel.hpp)
@@ -288,8 +297,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     strd = ["%%[str%d]" % q for q in range(L.ndma_b)]
     aq = ["%%[aq%d]" % i for i in range(ns)]
     af = ["%%[af%d]" % k for k in range(nx)]
-    fptr = ["%%[fptr%d]" % q for q in range(L.ndma_f)]
-    fstr = ["%%[fstr%d]" % q for q in range(L.ndma_f)]
+    fptr = ["%%[fptr%d]" % q for q in range(2 if adj else L.ndma_f)]
+    fstr = ["%%[fstr%d]" % q for q in range(2 if adj else L.ndma_f)]
     fp = ["%%[fp%d]" % q for q in range(L.NFD)]
     pk = ["%%[pk%d]" % m for m in range(nu)]
 
@@ -778,9 +787,14 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         for m in range(nu):
             off = (" offset:%d" % (m * KROW * 4)) if m else ""
             P.raw("ds_write_b32 %%[ak], %s%s" % (Kt[m], off))
+        if adj:      # v'_t (lanes < nx of G10) goes where f_t would be: the rollout's d_lambda_t = V_t dx_t + v'_t reads it
+            P.raw("s_mov_b64 exec, " + S_XM)
+            P.raw("ds_write_b32 %%[avp], %s" % G10)
         P.raw("s_mov_b64 exec, -1")
         P.exec_written()
         P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
+        if adj:
+            P.v("v_add_u32_e32 %%[avp], %d, %%[avp]" % ((-nx * 16) & 0xffffffff))
 
     def vupdate(s):
         """V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~) in place in Q[s][0..nx-1]   (lqr_recursion.py:151-152)"""
@@ -912,12 +926,22 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         if expand:
             read_ct(nslot)   # (the last step reads a slot nobody consumes)
         vupdate(s)
+        if save:
+            # the value function of the step, [V_t | v_t] (row i of Q~ now: V_t[i][:] in lanes < nx, v_t[i] in lane aff), as
+            # rows of nx + 1 floats: what the one-pass gradient reads instead of C (lambda_t = V_t x_t + v_t, the `adj` form)
+            P.uses(Q[s][:nx])
+            P.raw("s_mov_b64 exec, " + S_KM)
+            for i in range(nx):
+                P.raw("global_store_dword %%[pvv], %s, off offset:%d" % (Q[s][i], i * (nx + 1) * 4))
+            P.raw("s_mov_b64 exec, -1")
+            P.exec_written()
+            P.v("v_lshl_add_u64 %[pvv], %[pvv], 0, %[dvv]")
 
     n_step_stores = 0      # global stores per backward step (not mpc)
     if write_k:
         n_step_stores += nu
     if save:
-        n_step_stores += nx + (1 if nu == 1 or int(A[0][0][1:]) % 2 == 0 else nu * nu)
+        n_step_stores += nx + (1 if nu == 1 or int(A[0][0][1:]) % 2 == 0 else nu * nu) + nx
     assert (D - 1) * (NDB_ALL + n_step_stores) <= 63
     LC = 3 * D // (3 if D % 3 == 0 else 1)     # steps per trip of the loop form: lcm(register sets, ring slots)
     callsite = [0]
@@ -980,7 +1004,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     P_first = P
     P = P_main
     n_extra = 0
-    if stash:
+    if stash and not adj:
         # all of f (the forward sweep's only input from memory) goes to LDS now, BEHIND the first groups: the
         # backward sweep's first two waits allow for these NFD younger operations, later ones are merely conservative
         n_extra = L.NFD
@@ -1103,6 +1127,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                     P.fmac_dpp(ACC[a], ACC[a], M[c][nx + m], nx + m)
         for f in fillers:
             f()
+        if adj:        # d_tau leaves as dc, through the staging area
+            return
         if "store" not in skip:
             P.raw("s_mov_b64 exec, " + mask)
             P.raw("global_store_dword %%[pst], %s, off" % ACC[a])
@@ -1118,10 +1144,11 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     P.raw("v_readfirstlane_b32 %s, %%[bwd_only]" % S_TMP)   # (a VGPR operand: hipcc ran out of SGPRs for an "s" one at (1,1))
     P.raw("s_cmp_lg_u32 %s, 0" % S_TMP)                    # LqrRecursion.backward(): gains only
     P.raw("s_cbranch_scc1 Ldone_%=")
-    P.raw("s_mov_b64 exec, " + S_XM)                       # x_0 = x_init
-    P.raw("global_store_dword %%[px0], %s, off" % XV0)
-    P.raw("s_mov_b64 exec, -1")
-    P.exec_written()
+    if not adj:
+        P.raw("s_mov_b64 exec, " + S_XM)                   # x_0 = x_init
+        P.raw("global_store_dword %%[px0], %s, off" % XV0)
+        P.raw("s_mov_b64 exec, -1")
+        P.exec_written()
     if not stash:
         P.raw("s_sub_i32 %s, %%[T], 2" % S_TF)
         for j in range(DF):
@@ -1221,49 +1248,262 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             P.lines, P.n_instr, P.age, P.trans = save
             return k
 
-        FSTUB = 64
-        while FSTUB < 8 * (2 * (2 * L.H + ns // 2 + 6) + 4):
-            FSTUB *= 2
-        lo = int(S_JMP[2:S_JMP.index(":")])
-        P.raw("s_getpc_b64 " + S_JMP)
-        P.label("Lpcf_%=", reset=False)
-        P.raw("s_sub_i32 %s, %%[T], 2" % S_TMP)                 # entry stub index: (T-1) - 1
-        P.raw("s_mul_i32 %s, %s, %d" % (S_TMP, S_TMP, FSTUB))
-        P.raw("s_add_u32 s%d, s%d, Lfstub_%%=-Lpcf_%%=" % (lo, lo))
-        P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
-        P.raw("s_add_u32 s%d, s%d, %s" % (lo, lo, S_TMP))
-        P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
-        P.raw("s_setpc_b64 " + S_JMP)
-        n_fwd0 = P.n_instr
-        in_loop[0] = True
-        for n in range(L.NSTASH, 0, -1):
-            c, a, ap = sets(n)
-            P.label("Lfs%d_%%=" % n)
-            P.raw("s_waitcnt lgkmcnt(%d)" % group_size(n - 1))   # rows of step n are in; those of n-1 may be in flight
-            fill = []
-            if n >= 2:
-                fill = [lambda m=n - 2: prefetch_a(m), lambda m=n - 2: prefetch_b(m)]
-                if nu == 1:
-                    fill = [lambda m=n - 2: prefetch(m)]
-            fcompute(c, a, ap, S_SM, False, fill)
-        n_fwd = P.n_instr - n_fwd0
-        n_fwd_steps = L.NSTASH
-        in_loop[0] = False
-        c, a, ap = sets(0)
-        P.raw("s_waitcnt lgkmcnt(0)")
-        fcompute(c, a, ap, S_UM, True)
-        P.v("v_mov_b32_e32 %%[xvout], %s" % ACC[a])
-        P.raw("s_branch Ldone_%=")
-        # ---- entry stubs: stage F of the first two steps, read their rows, place x_init
-        P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
-        P.label("Lfstub_%=")
-        for n in range(1, L.NSTASH + 1):
-            c, a, ap = sets(n)
+        if adj:
+            # =========================================================== the one-pass gradient's forward sweep
+            # Step n (time t = T-1-n) rolls d_tau out as above and, with [V | v | x | u] of time t+1 from the ring,
+            #   lambda_{t+1} = V_{t+1} x_{t+1} + v_{t+1}        d_lambda_{t+1} = V_{t+1} dx_{t+1} + v'_{t+1}
+            #   dC_t = wa dtau (x) tau + wb tau (x) dtau   dc_t = dtau   dF_t = d_lambda_{t+1} (x) tau + lambda_{t+1} (x) dtau
+            #   df_t = d_lambda_t (the reference's index, differentiable_lqr.py:133) or d_lambda_{t+1} (strict)
+            # (differentiable_lqr.py:128-134; wa = 0.5, wb = 1 reproduce :128's precedence).  Rows are columns-per-lane
+            # registers (lane j = column j), written to the staging area under the mask of the tau lanes and sent to
+            # HBM as the contiguous 16-byte chunks they form there: [dC | dc | dF | df] of the wave's four trajectories.
+            DFA = 4                                     # ring slots of [Vv | x | u]
+            nVv, nX, nU = nx * (nx + 1), nx, nu         # 16-byte chunks per wave-step
+            nda = (nVv + nX + nU + 63) // 64
+            SLOTA = nda * 1024
+            STG = DFA * SLOTA                           # staging area, byte offset in the ring
+            nout = L.nchunk_b                           # [dC | dc | dF | df]: ns^2 + ns + nx ns + nx chunks
+            nst = (nout + 63) // 64
+            assert STG + 16 * nout <= L.RING and (DFA - 1) * nda + 4 * nst <= 63
+            O_dc, O_dF, O_df = 16 * ns * ns, 16 * (ns * ns + ns), 16 * (ns * ns + ns + nx * ns)
+            fixed = set(r_ for grp in M for r_ in grp) | set(ACC) | {MINPIV, XV0} | set(TS)
+            pool = ["v%d" % i for i in range(VBASE, 256) if "v%d" % i not in fixed]
+
+            def take(k, align=1):
+                for st in range(len(pool)):
+                    blk = pool[st:st + k]
+                    if len(blk) == k and int(blk[0][1:]) % align == 0 and int(blk[-1][1:]) - int(blk[0][1:]) == k - 1:
+                        del pool[st:st + k]
+                        return blk
+                raise AssertionError("out of forward registers")
+
+            VR = [take(nx, align=2) for _ in range(2)]  # row min(lane, nx-1) of V of the step two ahead / one ahead
+            LN = take(2)                                # v -> lambda_{t+1}
+            DLN = take(3)                               # v' -> d_lambda: accumulating, current (df), being loaded
+            TAUR = take(3)
+            DTAU, HDT, WT, DFV = take(4)
+            RC = take(ns)
+            RFm = take(nx)
+            SD = [take(4, align=4) for _ in range(nst)]
+            S_DFSEL = "s[86:87]"
+
+            def load_data(m):
+                """LDS reads of [V | v | tau] of step m from its ring slot (v' comes with prefetch_b) - issued two steps
+                ahead of their use, behind the counted wait for the slot's DMA group"""
+                off = (m % DFA) * SLOTA
+                Vs = VR[m % 2]
+                av = "%%[avr%d]" % (m % DFA)           # (ds_read2_b32 reaches 1 KB: one row address per slot)
+                for j in range(0, nx - 1, 2):
+                    P.raw("ds_read2_b32 %s, %s offset0:%d offset1:%d" % (vrange(Vs[j:j + 2]), av, j, j + 1))
+                if nx % 2:
+                    P.raw("ds_read_b32 %s, %s offset:%d" % (Vs[nx - 1], av, (nx - 1) * 4))
+                P.raw("ds_read_b32 %s, %s offset:%d" % (LN[m % 2], av, nx * 4))
+                P.raw("ds_read_b32 %s, %%[atx] offset:%d" % (TAUR[m % 3], off))
+
+            def issue_data(m):
+                """LDS-DMA group of step m (time T-1-m; the pointers walk forward in time) into slot m % DFA"""
+                if m < 0:
+                    return
+                issue_group(fptr[:nda], m % DFA, SLOTA)
+                for q in range(nda):
+                    P.v("v_lshl_add_u64 %s, %s, 0, %s" % (fptr[q], fptr[q], fstr[q]))
+
+            def adj_prefetch_b(m):
+                """gain rows of step m into lanes nx..15, k_t into the accumulator (f = 0 in its state lanes), v'_t"""
+                c, a, _ = sets(m)
+                P.v("v_mov_b32_e32 %s, 0" % ACC[a], writes=(ACC[a],))
+                P.raw("ds_read_b32 %s, %%[aaff]" % DLN[m % 3])
+                P.raw("s_mov_b64 exec, " + S_HI)
+                read_rows(c, a, aff_too=False)
+                P.raw("ds_read_b32 %s, %%[aaff]" % ACC[a])
+                P.raw("s_mov_b64 exec, -1")
+                P.exec_written()
+
+            def store_chunks(n_valid):
+                """the first n_valid chunks of the staging area -> HBM, then the store pointers move on one timestep"""
+                nq = (n_valid + 63) // 64
+                for q in range(nq):
+                    P.raw("ds_read_b128 %s, %%[ach] offset:%d" % (vrange(SD[q]), STG + q * 1024))
+                P.raw("s_waitcnt lgkmcnt(0)")
+                return nq
+
+            def outputs(n, last):
+                """everything of step n after its rollout"""
+                c, a, ap = sets(n)
+                TAU = TAUR[n % 3]
+                P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (DTAU, ACC[a], ACC[ap], S_XM), writes=(DTAU,), reads=(ACC[a], ACC[ap]))
+                P.v("v_mul_f32_e32 %s, %%[wa], %s" % (HDT, DTAU), writes=(HDT,), reads=(DTAU,))
+                P.v("v_mul_f32_e32 %s, %%[wb], %s" % (WT, TAU), writes=(WT,), reads=(TAU,))
+                if not last:      # d_lambda_{t+1} += V_{t+1} dx_{t+1}
+                    Vs, dl = VR[(n - 1) % 2], DLN[(n - 1) % 3]
+                    for j in range(nx):
+                        P.fmac_dpp(dl, ACC[a], Vs[j], j)
+                for i in range(ns):
+                    P.mul_dpp(RC[i], HDT, TAU, i)
+                for i in range(ns):
+                    P.fmac_dpp(RC[i], WT, DTAU, i)
+                if not last:
+                    ln, dl = LN[(n - 1) % 2], DLN[(n - 1) % 3]
+                    for i in range(nx):
+                        P.mul_dpp(RFm[i], dl, TAU, i)
+                    for i in range(nx):
+                        P.fmac_dpp(RFm[i], ln, DTAU, i)
+                    P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (DFV, DLN[n % 3], dl, S_DFSEL), writes=(DFV,), reads=(DLN[n % 3], dl))
+                P.raw("s_mov_b64 exec, " + S_SM)
+                for i in range(ns):
+                    P.raw("ds_write_b32 %%[awc], %s offset:%d" % (RC[i], STG + i * ns * 4))
+                P.raw("ds_write_b32 %%[awe], %s offset:%d" % (DTAU, STG + O_dc))
+                if not last:
+                    for i in range(nx):
+                        P.raw("ds_write_b32 %%[awf], %s offset:%d" % (RFm[i], STG + O_dF + i * ns * 4))
+                    P.raw("s_mov_b64 exec, " + S_XM)
+                    P.raw("ds_write_b32 %%[awd], %s offset:%d" % (DFV, STG + O_df))
+                P.raw("s_mov_b64 exec, -1")
+                P.exec_written()
+                n_valid = nout if not last else ns * ns + ns
+                nq = store_chunks(n_valid)
+                if not last and n - 2 - DFA >= 0:
+                    issue_data(n - 2 - DFA)       # the slot read at the top of this step is free (the wait above)
+                P.uses([r_ for q in range(nq) for r_ in SD[q]])
+                for q in range(nq):
+                    part = n_valid - 64 * q
+                    if part <= 32:
+                        P.raw("s_mov_b64 exec, 0x%x" % ((1 << part) - 1))       # (a 32-bit literal, zero-extended)
+                    elif part < 64:
+                        P.raw("s_mov_b32 exec_hi, 0x%x" % ((1 << (part - 32)) - 1))
+                    P.raw("global_store_dwordx4 %%[pso%d], %s, off" % (q, vrange(SD[q])))
+                    if part < 64:
+                        P.raw("s_mov_b64 exec, -1")
+                        P.exec_written()
+                if not last:
+                    for q in range(nst):
+                        P.v("v_lshl_add_u64 %%[pso%d], %%[pso%d], 0, %%[sso%d]" % (q, q, q))
+
+            def data_wait(n):
+                """counted wait for the DMA group of step n-2 at the top of step n: younger are the groups of the steps in
+                between that exist, and the stores of the DFA steps since it was issued"""
+                younger = len([m for m in range(n - 1 - DFA, n - 2) if m >= 0])
+                P.raw("s_waitcnt vmcnt(%d)" % (younger * nda + DFA * nst))
+
+            def emit_stub(n):
+                """entry at step n = T-1 (time 0): the first DFA groups, everything landed once (the only exposed round
+                trip), tau_0, d_lambda_0 = v'_0 = dx_init, the data of time 1, the rows of the first two steps; then the
+                next two groups - and, so that the counted waits of the first steps see as many younger stores as later
+                ones do, dx_init stored 2 nst + 1 times instead of once"""
+                c, a, ap = sets(n)
+                for m in range(n, n - DFA, -1):
+                    issue_data(m)
+                P.raw("s_waitcnt vmcnt(0)")
+                prefetch_a(n, move=False)
+                adj_prefetch_b(n)
+                P.raw("ds_read_b32 %s, %%[atx] offset:%d" % (TAUR[n % 3], (n % DFA) * SLOTA))
+                prefetch_a(n - 1)
+                adj_prefetch_b(n - 1)
+                load_data(n - 1)
+                P.v("v_mov_b32_e32 %s, 0" % ACC[ap], writes=(ACC[ap],))       # dx_0 = 0
+                P.raw("s_waitcnt lgkmcnt(0)")
+                issue_data(n - DFA)
+                issue_data(n - DFA - 1)
+                P.raw("s_mov_b64 exec, " + S_XM)
+                for _ in range(2 * nst + 1):
+                    P.raw("global_store_dword %%[px0], %s, off" % DLN[n % 3])
+                P.raw("s_mov_b64 exec, -1")
+                P.exec_written()
+                P.raw("s_branch Lfs%d_%%=" % n)
+
+            P_keep = P
+            stubs = []
+            for n in range(1, L.NSTASH + 1):
+                P = Prog()
+                emit_stub(n)
+                stubs.append(P)
+            P = P_keep
+            FSTUB = 64
+            while FSTUB < 8 * max(q.n_instr for q in stubs):
+                FSTUB *= 2
+            lo = int(S_JMP[2:S_JMP.index(":")])
+            P.v("v_cmp_ne_u32_e64 %s, 0, %%[dfshift]" % S_DFSEL)
+            P.raw("s_getpc_b64 " + S_JMP)
+            P.label("Lpcf_%=", reset=False)
+            P.raw("s_sub_i32 %s, %%[T], 2" % S_TMP)                 # entry stub index: (T-1) - 1
+            P.raw("s_mul_i32 %s, %s, %d" % (S_TMP, S_TMP, FSTUB))
+            P.raw("s_add_u32 s%d, s%d, Lfstub_%%=-Lpcf_%%=" % (lo, lo))
+            P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+            P.raw("s_add_u32 s%d, s%d, %s" % (lo, lo, S_TMP))
+            P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+            P.raw("s_setpc_b64 " + S_JMP)
+            n_fwd0 = P.n_instr
+            for n in range(L.NSTASH, 0, -1):
+                c, a, ap = sets(n)
+                P.label("Lfs%d_%%=" % n)
+                P.raw("s_waitcnt lgkmcnt(0)")
+                Vn, ln = VR[(n - 1) % 2], LN[(n - 1) % 2]
+                lam = [lambda j=j: P.fmac_dpp(ln, TAUR[(n - 1) % 3], Vn[j], j) for j in range(nx)]   # lambda_{t+1} += V x_{t+1}
+                if n >= 2:
+                    data_wait(n)
+                    fill = [lambda m=n - 2: prefetch_a(m), lambda m=n - 2: (adj_prefetch_b(m), load_data(m))]
+                else:
+                    fill = []
+                fcompute(c, a, ap, S_SM, False, fill + lam)
+                outputs(n, False)
+            n_fwd = P.n_instr - n_fwd0
+            n_fwd_steps = L.NSTASH
+            c, a, ap = sets(0)
+            P.raw("s_waitcnt lgkmcnt(0)")
+            fcompute(c, a, ap, S_UM, True)
+            outputs(0, True)
+            P.v("v_mov_b32_e32 %%[xvout], %s" % ACC[a])
+            P.raw("s_branch Ldone_%=")
             P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
-            prefetch(n, move=False)
-            prefetch(n - 1)
-            P.v("v_mov_b32_e32 %s, %s" % (ACC[ap], XV0), writes=(ACC[ap],))
-            P.raw("s_branch Lfs%d_%%=" % n)
+            P.label("Lfstub_%=")
+            for q in stubs:
+                P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
+                P.lines += q.lines
+                P.n_instr += q.n_instr
+        else:
+            FSTUB = 64
+            while FSTUB < 8 * (2 * (2 * L.H + ns // 2 + 6) + 4):
+                FSTUB *= 2
+            lo = int(S_JMP[2:S_JMP.index(":")])
+            P.raw("s_getpc_b64 " + S_JMP)
+            P.label("Lpcf_%=", reset=False)
+            P.raw("s_sub_i32 %s, %%[T], 2" % S_TMP)                 # entry stub index: (T-1) - 1
+            P.raw("s_mul_i32 %s, %s, %d" % (S_TMP, S_TMP, FSTUB))
+            P.raw("s_add_u32 s%d, s%d, Lfstub_%%=-Lpcf_%%=" % (lo, lo))
+            P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+            P.raw("s_add_u32 s%d, s%d, %s" % (lo, lo, S_TMP))
+            P.raw("s_addc_u32 s%d, s%d, 0" % (lo + 1, lo + 1))
+            P.raw("s_setpc_b64 " + S_JMP)
+            n_fwd0 = P.n_instr
+            in_loop[0] = True
+            for n in range(L.NSTASH, 0, -1):
+                c, a, ap = sets(n)
+                P.label("Lfs%d_%%=" % n)
+                P.raw("s_waitcnt lgkmcnt(%d)" % group_size(n - 1))   # rows of step n are in; those of n-1 may be in flight
+                fill = []
+                if n >= 2:
+                    fill = [lambda m=n - 2: prefetch_a(m), lambda m=n - 2: prefetch_b(m)]
+                    if nu == 1:
+                        fill = [lambda m=n - 2: prefetch(m)]
+                fcompute(c, a, ap, S_SM, False, fill)
+            n_fwd = P.n_instr - n_fwd0
+            n_fwd_steps = L.NSTASH
+            in_loop[0] = False
+            c, a, ap = sets(0)
+            P.raw("s_waitcnt lgkmcnt(0)")
+            fcompute(c, a, ap, S_UM, True)
+            P.v("v_mov_b32_e32 %%[xvout], %s" % ACC[a])
+            P.raw("s_branch Ldone_%=")
+            # ---- entry stubs: stage F of the first two steps, read their rows, place x_init
+            P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
+            P.label("Lfstub_%=")
+            for n in range(1, L.NSTASH + 1):
+                c, a, ap = sets(n)
+                P.lines.append(".p2align %d" % (FSTUB.bit_length() - 1))
+                prefetch(n, move=False)
+                prefetch(n - 1)
+                P.v("v_mov_b32_e32 %s, %s" % (ACC[ap], XV0), writes=(ACC[ap],))
+                P.raw("s_branch Lfs%d_%%=" % n)
         # ---- backward stubs: F block of ring slot (n % 3) -> stash slot n-1
         P.lines.append(".p2align 5")
         P.label("Lbstub_%=")
@@ -1297,9 +1537,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     rw = []
     for q in range(L.ndma_b):
         rw.append(("ptr%d" % q, '"+v"(in.ptr[%d])' % q))
-    if not stash:
-        for q in range(L.ndma_f):
+    NDA = (nx * (nx + 1) + ns + 63) // 64          # adj: DMAs per group of [Vv | x | u]
+    NST = (L.nchunk_b + 63) // 64                  # adj: store instructions per step
+    assert NDA <= 2
+    if not stash or adj:
+        for q in range(NDA if adj else L.ndma_f):
             rw.append(("fptr%d" % q, '"+v"(in.fptr[%d])' % q))
+    if adj:
+        rw.append(("avp", '"+v"(in.avp)'))
+        for q in range(NST):
+            rw.append(("pso%d" % q, '"+v"(in.pso[%d])' % q))
     rw += [("tf", '"+s"(in.tf)'), ("gz", '"+v"(in.gz)'), ("ak", '"+v"(in.ak)'), ("arow", '"+v"(in.arow)'), ("aaff", '"+v"(in.aaff)'), ("pst", '"+v"(in.pst)')]
     if write_k:
         for m in range(nu):
@@ -1307,7 +1554,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if masked:
         rw.append(("pm", '"+v"(in.pm)'))
     if save:
-        rw += [("pqx", '"+v"(in.pqx)'), ("psq", '"+v"(in.psq)')]
+        rw += [("pqx", '"+v"(in.pqx)'), ("psq", '"+v"(in.psq)'), ("pvv", '"+v"(in.pvv)')]
     ins = []
     for q in range(L.ndma_b):
         ins.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
@@ -1328,10 +1575,20 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         for q in range(L.ndma_f):
             ins.append(("fstr%d" % q, '"v"(in.fstr[%d])' % q))
         ins += [("drow", '"v"(in.drow)'), ("drow2", '"v"(in.drow2)'), ("daff", '"v"(in.daff)'), ("daff2", '"v"(in.daff2)')]
+    if adj:
+        for q in range(NDA):
+            ins.append(("fstr%d" % q, '"v"(in.fstr[%d])' % q))
+        for q in range(NST):
+            ins.append(("sso%d" % q, '"v"(in.sso[%d])' % q))
+        for q in range(4):
+            ins.append(("avr%d" % q, '"v"(in.avr[%d])' % q))
+        ins += [("atx", '"v"(in.atx)'), ("awc", '"v"(in.awc)'), ("awe", '"v"(in.awe)'), ("awf", '"v"(in.awf)'),
+                ("awd", '"v"(in.awd)'), ("ach", '"v"(in.ach)'), ("wa", '"v"(in.wa)'), ("wb", '"v"(in.wb)'),
+                ("dfshift", '"v"(in.dfshift)')]
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
     if save:
-        ins += [("dqx", '"v"(in.dqx)'), ("dsq", '"v"(in.dsq)')]
+        ins += [("dqx", '"v"(in.dqx)'), ("dsq", '"v"(in.dsq)'), ("dvv", '"v"(in.dvv)')]
     if masked:
         ins += [("dm", '"v"(in.dm)'), ("am", '"v"(in.am)')]
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)'), ("bwd_only", '"v"(in.bwd_only)')]
@@ -1339,11 +1596,11 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         ins.append(("nqp_iter", '"s"(in.n_qp_iter)'))
     if expand:
         ins += [("atau", '"v"(in.atau)'), ("act", '"v"(in.act)')]
-    clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
+    clob = ['"v%d"' % i for i in range(VBASE, (255 if adj else last_vgpr) + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
         ['"s%d"' % i for i in ([70] + list(range(72, 102 if (mpc or affine) else (100 if save else 98))))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
-    name = "LqrAsm<%d, %d, %s, %s, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(unroll), tf(save), tf(affine))
+    name = "LqrAsm<%d, %d, %s, %s, %s, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(unroll), tf(save), tf(affine), tf(adj))
     if mpc:
         name = "MpcAsm<%d, %d, %s>" % (nx, nu, tf(expand))
     o = []
@@ -1357,6 +1614,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
              % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
     o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, HROW = %d, SPD = %d, PADM = %d;\n"
              % (L.NSTASH, L.NFD, L.FAREA, L.H, L.SPD, 16 * L.nchunk_b))
+    if adj:
+        o.append("  static constexpr int ADJ_NDA = %d, ADJ_SLOT = %d, ADJ_NST = %d;\n" % (NDA, NDA * 1024, NST))
     # block 1: the first DB groups
     rw1 = [("ptr%d" % q, '"+v"(in.ptr[%d])' % q) for q in range(L.ndma_b)] + [("tf", '"+s"(in.tf)')]
     if masked:
@@ -1412,6 +1671,7 @@ struct LqrAsmIn {
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
   uint64_t pqx, dqx, psq, dsq;       // save: Qxu store pointer (lanes nx..ns-1: column m of row 0) / Quu (lane 0), time strides
+  uint64_t pvv, dvv;                 // save: [V_t | v_t] store pointer (lane j < nx: column j of row 0, lane ns: column nx), time stride
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
   unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
   int n_qp_iter;                     // mpc (wave-uniform): iteration cap of the box QP
@@ -1429,12 +1689,24 @@ struct LqrAsmIn {
   unsigned ring;                     // LDS byte address of this wave's ring
   int T;
   unsigned ts[4];                    // GEN_TIMING builds only: s_memtime at the phase boundaries
+  // adj (the one-pass gradient; fptr / fstr carry the DMA sources of [Vv | x | u], walking forward in time)
+  unsigned avp;                      // LDS byte address of v'_{T-1}[lane] in the f area (lanes < nx), moves back per step
+  unsigned avr[4];                   // LDS byte address of row min(lane, nx-1) of this trajectory's [V | v] in ring slot q
+  unsigned atx;                      // ... of [x; u][min(lane, ns-1)] in ring slot 0
+  unsigned awc, awe, awf, awd;       // staging area (without its ring offset): column `lane` of row 0 of dC / dc / dF, df[lane]
+  unsigned ach;                      // ring + lane64 * 16: this lane's chunk of the staging area
+  uint64_t pso[4], sso[4];           // store pointer of this lane's chunk of [dC | dc | dF | df] at t = 0, time stride
+  float wa, wb;                      // dC = wa dtau (x) tau + wb tau (x) dtau
+  int dfshift;                       // 0: df[t] = d_lambda[t] (the reference), 1: d_lambda[t+1]
 };
 
 // UNROLL: the backward sweep unrolled over the horizon (no per-step stash stubs), generated for the headline shape only
 // SAVE (with WRITE_K): Quu_t and Qxu_t of every step go to HBM as well (DiffLqr's training form)
 // AFFINE (STASH, no gains out): the re-solve with saved K_t, Quu_t, Qxu_t and another c (DiffLqr.backward's second solve)
-template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false, bool AFFINE = false>
+// ADJ (with AFFINE): DiffLqr.backward in one launch - the affine re-solve whose rollout writes dC, dc, dF, df, dx_init from
+// [V_t | v_t] of the saving solve instead of C (see gen_kernel)
+template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false, bool AFFINE = false,
+          bool ADJ = false>
 struct LqrAsm {
   static constexpr bool kAvailable = false;
 };
@@ -1466,6 +1738,7 @@ def main():
                     out.append(gen_kernel(nx, nu, write_k, stash, save=True))
                 if stash and not write_k and nx + nu >= 4:
                     out.append(gen_kernel(nx, nu, write_k, stash, affine=True))
+                    out.append(gen_kernel(nx, nu, write_k, stash, affine=True, adj=True))
                 if X_UNROLL_BWD and stash and not write_k and (nx, nu) == (8, 2):
                     out.append(gen_kernel(nx, nu, write_k, stash, unroll=True))
                 if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding

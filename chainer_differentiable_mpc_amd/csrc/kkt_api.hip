@@ -100,13 +100,26 @@ size_t dmpc_lqr_kkt_workspace_bytes(int T, int B, int nx, int nu) {
 }
 
 // DiffLqr.backward.  Ks != nullptr: the gains of the forward solve are reused (dmpc_lqr_kkt_grad_saved).
+static bool adjoint_disabled() {  // DMPC_NO_ADJOINT=1: the re-solve + co-state kernels instead of the one-pass gradient (A/B)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_ADJOINT"); return e && e[0] == '1'; }();
+  return off;
+}
+
 static int kkt_grad(int T, int B, int nx, int nu, const float *C, const float *c, const float *F, const float *x,
-                    const float *u, const float *Ks, const float *Quu, const float *Qxu, const float *grad_x,
-                    const float *grad_u, int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df,
-                    void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
+                    const float *u, const float *Ks, const float *Quu, const float *Qxu, const float *Vv,
+                    const float *grad_x, const float *grad_u, int strict_math, float *d_x_init, float *dC, float *dc,
+                    float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !F || !x || !u || !grad_x || !grad_u || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(dC) || !aligned16(dF)) return DMPC_E_BADARG;
+  if (Ks != nullptr && Vv != nullptr && dC != nullptr && dF != nullptr && df != nullptr && !adjoint_disabled() &&
+      aligned16(grad_x) && aligned16(grad_u) && aligned16(Ks) && aligned16(Quu) && aligned16(Qxu) && aligned16(Vv) &&
+      aligned16(x) && aligned16(u) && aligned16(dc) && aligned16(df)) {
+    // one launch, no C: the affine re-solve whose rollout writes the gradients (lqr_adjoint, lqr_api.hip)
+    const int rc1 = lqr_adjoint(T, B, nx, nu, F, grad_x, grad_u, Ks, Quu, Qxu, Vv, x, u, strict_math, d_x_init, dC, dc, dF, df,
+                                info, static_cast<hipStream_t>(stream_));
+    if (rc1 != DMPC_E_UNSUPPORTED) return rc1;
+  }
   const KktWs w = kkt_layout(T, B, nx, nu);
   if (ws_bytes < w.total) return DMPC_E_WORKSPACE;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
@@ -146,19 +159,21 @@ int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float 
                       const float *x, const float *u, const float *grad_x, const float *grad_u,
                       int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws,
                       size_t ws_bytes, int32_t *info, dmpc_stream_t stream) {
-  return kkt_grad(T, B, nx, nu, C, c, F, x, u, nullptr, nullptr, nullptr, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF,
-                  df, ws, ws_bytes, info, stream);
+  return kkt_grad(T, B, nx, nu, C, c, F, x, u, nullptr, nullptr, nullptr, nullptr, grad_x, grad_u, strict_math, d_x_init, dC,
+                  dc, dF, df, ws, ws_bytes, info, stream);
 }
 
 // DiffLqr.backward with the gains of the forward solve (dmpc_lqr_solve_saving): the second solve shares C and F with it,
 // so K_t, Quu_t, Qxu_t are the same and only the affine recursion is redone (the `affine` stream of gen_lqr_asm.py).
+// With Vv (the saving solve's value functions) the whole gradient is ONE launch that reads neither C nor c: co-states are
+// value gradients, lambda_t = V_t x_t + v_t, d_lambda_t = V_t dx_t + v'_t (the `adj` stream of gen_lqr_asm.py).
 int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                             const float *x, const float *u, const float *Ks, const float *Quu, const float *Qxu,
-                            const float *grad_x, const float *grad_u, int strict_math, float *d_x_init, float *dC,
-                            float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
+                            const float *Vv, const float *grad_x, const float *grad_u, int strict_math, float *d_x_init,
+                            float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
                             dmpc_stream_t stream) {
   if (!Ks || !Quu || !Qxu) return DMPC_E_BADARG;
-  return kkt_grad(T, B, nx, nu, C, c, F, x, u, Ks, Quu, Qxu, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF, df, ws,
+  return kkt_grad(T, B, nx, nu, C, c, F, x, u, Ks, Quu, Qxu, Vv, grad_x, grad_u, strict_math, d_x_init, dC, dc, dF, df, ws,
                   ws_bytes, info, stream);
 }
 

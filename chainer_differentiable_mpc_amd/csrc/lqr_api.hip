@@ -73,12 +73,26 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
 #define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
   DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, L, MASKED, MODE, KLDS>), grid, block, SHMEM, stream, a)
-  if (a.c_u != nullptr || (a.x_init == nullptr && a.x != nullptr)) {
+  if (a.Vv_in == nullptr && (a.c_u != nullptr || (a.x_init == nullptr && a.x != nullptr))) {
     // c in two arrays / x_init = 0: forms only the generated streams take (lqr_second_solve below)
     bool ok = false;
     if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable)
       ok = mode == kSolve && !masked && a.Ks == nullptr && solve_path<NX, NU, L>(a.T, a.B) >= 3;
     if (!ok) return DMPC_E_UNSUPPORTED;
+  }
+  if (a.Vv_in != nullptr) {
+    // DiffLqr.backward in one launch (lqr_adjoint below): the affine re-solve whose rollout writes the gradients
+    if constexpr (L == 16 && LqrAsm<NX, NU, false, true, false, false, false, true, true>::kAvailable) {
+      if (mode == kSolve && !masked && a.f == nullptr && a.Ks == nullptr && a.Ks_in != nullptr &&
+          solve_path<NX, NU, L>(a.T, a.B) == 4) {
+        const int waves = (a.B + 3) / 4;
+        const size_t shmem = lqr_asm_lds_bytes<NX, NU, true>(a.T);
+        DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, false, true, false, false, false, true, true>), dim3((waves + 3) / 4),
+                        block, shmem, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
+    return DMPC_E_UNSUPPORTED;
   }
   if (a.Ks_in != nullptr) {
     // the re-solve from saved gains (dmpc_lqr_saved_solve): the affine form of the generated stream, F in the stash
@@ -231,7 +245,8 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
   DMPC_LQR_SHAPES(X)
 #undef X
   // (the generated streams' own argument forms - lqr_second_solve - stop here: nothing else reads them)
-  if (a.c_u != nullptr || a.Ks_in != nullptr || a.Quu_out != nullptr || (a.x_init == nullptr && a.x != nullptr))
+  if (a.c_u != nullptr || a.Ks_in != nullptr || a.Vv_in != nullptr || a.Quu_out != nullptr ||
+      (a.x_init == nullptr && a.x != nullptr))
     return DMPC_E_UNSUPPORTED;
   if (lqr_family(nx, nu) == 3) return launch_lqr_generic(mode, nx, nu, a, stream);
   return DMPC_E_UNSUPPORTED;
@@ -251,6 +266,29 @@ int lqr_second_solve(int T, int B, int nx, int nu, const float *C, const float *
     a.Quu_in = Quu;
     a.Qxu_in = Qxu;
   }
+  return dispatch_lqr(kSolve, nx, nu, a, stream);
+}
+
+// DiffLqr.backward (differentiable_lqr.py:78-142) in ONE launch that reads neither C nor c: the affine re-solve from the
+// saving solve's K_t, Quu_t, Qxu_t on [grad_x; grad_u], whose rollout of d_tau forms lambda_t = V_t x_t + v_t and
+// d_lambda_t = V_t dx_t + v'_t from the saved value functions Vv and writes dC, dc, dF, df, dx_init itself.
+// DMPC_E_UNSUPPORTED (nothing launched) unless the generated stream serves the size.
+int lqr_adjoint(int T, int B, int nx, int nu, const float *F, const float *grad_x, const float *grad_u, const float *Ks,
+                const float *Quu, const float *Qxu, const float *Vv, const float *x, const float *u, int strict_math,
+                float *d_x_init, float *dC, float *dc, float *dF, float *df, int32_t *info, hipStream_t stream) {
+  if (B % 4 != 0) return DMPC_E_UNSUPPORTED;
+  LqrArgs a{T, B, nullptr, grad_x, F, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, info};
+  a.c_u = grad_u;
+  a.Ks_in = Ks;
+  a.Quu_in = Quu;
+  a.Qxu_in = Qxu;
+  a.Vv_in = Vv;
+  a.tau_x = x;
+  a.tau_u = u;
+  a.dC = dC; a.dc = dc; a.dF = dF; a.df = df; a.dx0 = d_x_init;
+  a.w_a = 0.5f;
+  a.w_b = strict_math ? 0.5f : 1.0f;
+  a.df_shift = strict_math ? 1 : 0;
   return dispatch_lqr(kSolve, nx, nu, a, stream);
 }
 
@@ -299,14 +337,16 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
 
 int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                           const float *f, const float *x_init, float *Ks_out, float *ks_out, float *Quu_out,
-                          float *Qxu_out, float *x_out, float *u_out, int32_t *info, dmpc_stream_t stream) {
+                          float *Qxu_out, float *Vv_out, float *x_out, float *u_out, int32_t *info, dmpc_stream_t stream) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
-  if (!C || !c || !F || !x_init || !x_out || !u_out || !Ks_out || !ks_out || !Quu_out || !Qxu_out) return DMPC_E_BADARG;
+  if (!C || !c || !F || !x_init || !x_out || !u_out || !Ks_out || !ks_out || !Quu_out || !Qxu_out || !Vv_out)
+    return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(Quu_out)) return DMPC_E_BADARG;
   if (dmpc_lqr_solve_path(T, B, nx, nu) < 3 || B % 4 != 0) return DMPC_E_UNSUPPORTED;   // the generated streams only
   LqrArgs a{T, B, C, c, F, f, x_init, nullptr, Ks_out, ks_out, nullptr, nullptr, x_out, u_out, info};
   a.Quu_out = Quu_out;
   a.Qxu_out = Qxu_out;
+  a.Vv_out = Vv_out;
   a.info_store = true;
   return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
 }

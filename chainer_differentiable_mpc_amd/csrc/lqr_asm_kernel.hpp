@@ -166,10 +166,13 @@ __device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsi
 // B * nu to be a multiple of 4 (the flags of a wave's four trajectories are fetched as whole dwords).
 // a.x == nullptr: backward sweep only (LqrRecursion.backward(), gains to a.Ks / a.ks - WRITE_K).
 // AFFINE: the re-solve from saved gains (a.Ks_in, a.Quu_in, a.Qxu_in; a.c the new affine term, no f, a.C not read).
+// ADJ (with AFFINE): DiffLqr.backward in one launch - a.c / a.c_u are grad_x / grad_u, a.Vv_in the saving solve's value
+// functions, a.tau_x / a.tau_u its solution; dC, dc, dF, df, dx0 are written by the rollout (a.x, a.u are not).
 template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false,
-          bool AFFINE = false>
+          bool AFFINE = false, bool ADJ = false>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
-  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, UNROLL, SAVE, AFFINE>;
+  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, UNROLL, SAVE, AFFINE, ADJ>;
+  static_assert(!ADJ || AFFINE, "the one-pass gradient is a form of the affine re-solve");
   static_assert(!AFFINE || (!HAS_F && STASH), "the affine re-solve has no f and keeps F in the stash");
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU, AFF = NS, KROW = G::KROW;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.ring = __builtin_amdgcn_readfirstlane(ring);
   in.T = T;
   in.tf = 0;
-  in.bwd_only = a.x == nullptr ? 1 : 0;
+  in.bwd_only = (a.x == nullptr && !ADJ) ? 1 : 0;   // (the one-pass gradient has no x, u outputs: its rollout writes dC ...)
 
   if constexpr (AFFINE) lqr_asm_affine_sources<NX, NU, G>(in, a.Ks_in, a.Qxu_in, a.Quu_in, a.c, a.F, T, B, b0, lane64, a.c_u);
   else lqr_asm_backward_sources<NX, NU, G, HAS_F>(in, a.C, a.c, a.F, a.f, T, B, b0, lane64, a.c_u);
@@ -249,8 +252,11 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     in.dqx = (uint64_t)0 - (uint64_t)(B * NX * NU * 4);
     in.psq = reinterpret_cast<uint64_t>(a.Quu_out + tb * NU * NU);
     in.dsq = (uint64_t)0 - (uint64_t)(B * NU * NU * 4);
+    // [V_t | v_t]: lane j < nx owns column j, lane ns (the affine column) column nx; row i by the instruction offset
+    in.pvv = reinterpret_cast<uint64_t>(a.Vv_out + tb * NX * (NX + 1) + (lane < NX ? lane : NX));
+    in.dvv = (uint64_t)0 - (uint64_t)(B * NX * (NX + 1) * 4);
   } else {
-    in.pqx = in.dqx = in.psq = in.dsq = 0;
+    in.pqx = in.dqx = in.psq = in.dsq = in.pvv = in.dvv = 0;
   }
 
   // lane i < nx: row i of [F_t | f_t]; lane nx+m: gain row m; the other lanes shadow the last gain row
@@ -314,6 +320,53 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   in.pxi = a.x_init != nullptr ? reinterpret_cast<uint64_t>(a.x_init + (size_t)b * NX + (row_x ? lane : NX - 1))
                                : reinterpret_cast<uint64_t>(dmpc_zero_chunks);  // x_init = 0 (backward only: never used)
   in.px0 = reinterpret_cast<uint64_t>(a.x + (size_t)b * NX + (row_x ? lane : NX - 1));
+  if constexpr (ADJ) {
+    constexpr int nVv = NX * (NX + 1), nOutC = NS * NS, nOutc = NS, nOutF = NX * NS, nOutf = NX;   // 16-byte chunks per wave-step
+    const int lane_x = row_x ? lane : NX - 1;
+    in.px0 = reinterpret_cast<uint64_t>(a.dx0 + (size_t)b * NX + lane_x);     // dx_init = d_lambda_0 = v'_0
+    in.avp = farea + (unsigned)((T - 1) * NX * 16 + (r * NX + lane_x) * 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) in.avr[q] = ring + (unsigned)(q * G::ADJ_SLOT + (r * NX + lane_x) * (NX + 1) * 4);
+    in.atx = ring + (lane_c < NX ? (unsigned)(nVv * 16 + (r * NX + lane_c) * 4)
+                                  : (unsigned)((nVv + NX) * 16 + (r * NU + lane_c - NX) * 4));
+    in.awc = ring + (unsigned)((r * NS * NS + lane_c) * 4);
+    in.awe = ring + (unsigned)((r * NS + lane_c) * 4);
+    in.awf = ring + (unsigned)((r * NX * NS + lane_c) * 4);
+    in.awd = ring + (unsigned)((r * NX + lane_x) * 4);
+    in.ach = ring + (unsigned)lane64 * 16u;
+    in.wa = a.w_a;
+    in.wb = a.w_b;
+    in.dfshift = a.df_shift;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // DMA sources of chunk g of [Vv | x | u] at t = 0; padding lanes repeat chunk 0
+      if (q >= G::ADJ_NDA) continue;
+      const int g = q * 64 + lane64;
+      const bool isV = g < nVv, isX = !isV && g < nVv + NX, isU = !isV && !isX && g < nVv + NX + NU;
+      const uint64_t base = isX ? reinterpret_cast<uint64_t>(a.tau_x) : isU ? reinterpret_cast<uint64_t>(a.tau_u)
+                                                                           : reinterpret_cast<uint64_t>(a.Vv_in);
+      const size_t per = isX ? (size_t)NX * 4 : isU ? (size_t)NU * 4 : (size_t)NX * (NX + 1) * 4;
+      const int g0 = isV ? 0 : isX ? nVv : isU ? nVv + NX : g;
+      in.fptr[q] = base + (size_t)b0 * per + (size_t)(g - g0) * 16 - (uint64_t)q * 1024u;
+      in.fstr[q] = (uint64_t)(B * per);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {   // store pointers of chunk g of [dC | dc | dF | df] at t = 0 (the stream masks the rest)
+      const int g = q * 64 + lane64;
+      const bool isC = g < nOutC, isc = !isC && g < nOutC + nOutc, isF = !isC && !isc && g < nOutC + nOutc + nOutF;
+      const bool isf = !isC && !isc && !isF && g < nOutC + nOutc + nOutF + nOutf;
+      const uint64_t base = isC ? reinterpret_cast<uint64_t>(a.dC) : isc ? reinterpret_cast<uint64_t>(a.dc)
+                            : isF ? reinterpret_cast<uint64_t>(a.dF) : reinterpret_cast<uint64_t>(a.df);
+      const size_t per = isC ? (size_t)NS * NS * 4 : isc ? (size_t)NS * 4 : isF ? (size_t)NX * NS * 4 : (size_t)NX * 4;
+      const int g0 = isC ? 0 : isc ? nOutC : isF ? nOutC + nOutc : nOutC + nOutc + nOutF;
+      const bool any = isC || isc || isF || isf;
+      in.pso[q] = any ? base + (size_t)b0 * per + (size_t)(g - g0) * 16 : 0;
+      in.sso[q] = any ? (uint64_t)(B * per) : 0;
+    }
+  } else {
+    in.avp = in.atx = in.awc = in.awe = in.awf = in.awd = in.ach = 0;
+    in.wa = in.wb = 0.f;
+    in.dfshift = 0;
+  }
 
   float xvout, minpiv;
   G::run(in, xvout, minpiv);
@@ -332,7 +385,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     int bits = 0;
     if (minpiv == 0.f) bits |= 1;                       // a zero pivot in some Quu (uniform over the row)
     if (lane < NS && !is_finite(xvout)) bits |= 2;      // NaN/Inf propagate to u_{T-1} through the recursion
-    if (a.x == nullptr && !is_finite(minpiv)) bits |= 2;  // backward only: a NaN pivot is all there is to see
+    if (a.x == nullptr && !ADJ && !is_finite(minpiv)) bits |= 2;  // backward only: a NaN pivot is all there is to see
     if (a.info_store) {   // (uniform) one lane per trajectory writes the row's flags, zero included
       const unsigned long long nonfinite = __ballot((bits & 2) != 0);
       const int row_bits = (bits & 1) | ((((nonfinite >> (16 * r)) & 0xffffull) != 0) ? 2 : 0);

@@ -37,6 +37,17 @@ struct LqrArgs {
   // the re-solve with saved gains (lqr_asm_kernel<..., AFFINE>): K_t [T,B,nu,nx], Quu_t [T,B,nu,nu], Qxu_t [T,B,nx,nu] of
   // an earlier solve of the same C, F; `c` is the new affine cost term, C is not read
   const float *Ks_in = nullptr, *Quu_in = nullptr, *Qxu_in = nullptr;
+  // saving solve: [V_t | v_t] of every step, [T,B,nx,nx+1] (row i = V_t[i][:], v_t[i]) - the value function whose gradient the
+  // co-states are: lambda_t = V_t x_t + v_t (what the one-pass gradient reads instead of C)
+  float *Vv_out = nullptr;
+  // the one-pass gradient (lqr_asm_kernel<..., AFFINE, ADJ>; DiffLqr.backward, differentiable_lqr.py:78-142): with the
+  // saved gains above, Vv_in [T,B,nx,nx+1] and the forward solution tau_x [T,B,nx], tau_u [T,B,nu]; `c` / `c_u` are grad_x /
+  // grad_u; outputs dC [T,B,ns,ns], dc [T,B,ns], dF [T-1,B,nx,ns], df [T-1,B,nx], dx0 [B,nx];
+  // dC = w_a dtau (x) tau + w_b tau (x) dtau; df[t] = d_lambda[t + df_shift]
+  const float *Vv_in = nullptr, *tau_x = nullptr, *tau_u = nullptr;
+  float *dC = nullptr, *dc = nullptr, *dF = nullptr, *df = nullptr, *dx0 = nullptr;
+  float w_a = 0.5f, w_b = 1.0f;
+  int df_shift = 0;
 };
 
 enum LqrMode { kSolve = 0, kBackwardOnly = 1, kForwardOnly = 2 };

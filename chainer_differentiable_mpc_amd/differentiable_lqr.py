@@ -5,8 +5,10 @@ torch.autograd.Function wrapper / torch.nn.Module.
 Forward = fused LQR solve kernel (`dmpc_lqr_solve`); backward = analytic KKT gradient
 (`dmpc_lqr_kkt_grad`: second LQR solve + co-state sweeps + outer products), both hand-written HIP.
 Where the generated stream serves the size the pair runs in its training form: the forward solve also leaves its
-gains and the control blocks of its Q-functions in HBM (`dmpc_lqr_solve_saving`) and the gradient's second solve -
-same C, same F - only redoes the affine recursion with them (`dmpc_lqr_kkt_grad_saved`).
+gains, the control blocks of its Q-functions and its value functions [V_t | v_t] in HBM (`dmpc_lqr_solve_saving`), and
+the gradient is ONE launch that reads neither C nor c (`dmpc_lqr_kkt_grad_saved`): the second solve - same C, same F -
+only redoes the affine recursion with the saved gains, and the co-states are value gradients, lambda_t = V_t x_t + v_t,
+d_lambda_t = V_t dx_t + v'_t, formed while d_tau is rolled out (`DMPC_NO_ADJOINT=1`: re-solve + co-state sweep).
 
 Reference quirks kept by default, switch off with `strict_math=True`:
   dC_t = 0.5*(d_tau (x) tau) + (tau (x) d_tau)      differentiable_lqr.py:128
@@ -26,8 +28,9 @@ from .util import expand_time_batch
 def kkt_grad_device(C, c, F, x, u, grad_x, grad_u, T, n_state, n_ctrl, strict_math=False, info=None,
                     need_dC=True, need_dF=True, need_df=True, saved=None):
     """Raw KKT gradient on float32 device tensors -> (d_x_init, dC, dc, dF, df).
-    saved = (Ks, Quu, Qxu) of `solve_saving_device`: the second solve reuses the forward solve's gains
-    (`dmpc_lqr_kkt_grad_saved`) instead of repeating the Riccati sweep."""
+    saved = (Ks, Quu, Qxu, Vv) of `solve_saving_device`: the whole gradient is one launch that reads neither C nor c
+    (co-states as value gradients, `dmpc_lqr_kkt_grad_saved`); saved = (Ks, Quu, Qxu): the second solve reuses the
+    forward solve's gains instead of repeating the Riccati sweep, the co-state sweep reads C."""
     lib = _lib.load()
     _lib.require_gpu()
     dev = C.device
@@ -45,9 +48,11 @@ def kkt_grad_device(C, c, F, x, u, grad_x, grad_u, T, n_state, n_ctrl, strict_ma
     with _lib.guard(dev):
         rc = _lib.E_UNSUPPORTED
         if saved is not None:
-            Ks, Quu, Qxu = saved
+            Ks, Quu, Qxu = saved[:3]
+            Vv = saved[3] if len(saved) > 3 else None
             rc = lib.dmpc_lqr_kkt_grad_saved(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(x), _lib.ptr(u),
-                                             _lib.ptr(Ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(grad_x), _lib.ptr(grad_u),
+                                             _lib.ptr(Ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(Vv), _lib.ptr(grad_x),
+                                             _lib.ptr(grad_u),
                                              1 if strict_math else 0, _lib.ptr(dx0), _lib.ptr(dC), _lib.ptr(dc),
                                              _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need, _lib.ptr(info),
                                              _lib.stream_ptr(dev))
@@ -136,8 +141,8 @@ class DiffLqr:
             # backward pass's second solve only redoes the affine recursion with them
             got = solve_saving_device(d[1], d[2], d[3], d[4], d[0], T, nx, nu, info=self.info)
         if got is not None:
-            x, u, Ks, _, Quu, Qxu = got
-            saved = (Ks, Quu, Qxu)
+            x, u, Ks, _, Quu, Qxu, Vv = got
+            saved = (Ks, Quu, Qxu, Vv)
         else:
             if use_saving:
                 self.info.zero_()

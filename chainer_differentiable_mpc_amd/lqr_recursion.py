@@ -167,8 +167,9 @@ def saving_solve_available(T, B, n_state, n_ctrl):
 
 
 def solve_saving_device(C, c, F, f, x_init, T, n_state, n_ctrl, info=None):
-    """The training form of the fused solve (`dmpc_lqr_solve_saving`): (x, u, Ks, ks, Quu, Qxu), or None where the
-    generated stream does not serve the size (the caller then uses `solve_device`)."""
+    """The training form of the fused solve (`dmpc_lqr_solve_saving`): (x, u, Ks, ks, Quu, Qxu, Vv) - Vv [T,B,nx,nx+1] the
+    value functions [V_t | v_t] - or None where the generated stream does not serve the size (the caller then uses
+    `solve_device`)."""
     lib = _lib.load()
     _lib.require_gpu()
     dev = C.device
@@ -181,14 +182,15 @@ def solve_saving_device(C, c, F, f, x_init, T, n_state, n_ctrl, info=None):
     ks = torch.empty((T, B, nu), **f32)
     Quu = torch.empty((T, B, nu, nu), **f32)
     Qxu = torch.empty((T, B, nx, nu), **f32)
+    Vv = torch.empty((T, B, nx, nx + 1), **f32)
     with _lib.guard(dev):
         rc = lib.dmpc_lqr_solve_saving(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(x_init),
-                                       _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(x), _lib.ptr(u),
-                                       _lib.ptr(info), _lib.stream_ptr(dev))
+                                       _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(Quu), _lib.ptr(Qxu), _lib.ptr(Vv), _lib.ptr(x),
+                                       _lib.ptr(u), _lib.ptr(info), _lib.stream_ptr(dev))
     if rc == _lib.E_UNSUPPORTED:
         return None
     _lib.check(rc, "dmpc_lqr_solve_saving")
-    return x, u, Ks, ks, Quu, Qxu
+    return x, u, Ks, ks, Quu, Qxu, Vv
 
 
 def saved_solve_device(c, F, Ks, Quu, Qxu, x_init, T, n_state, n_ctrl, info=None):

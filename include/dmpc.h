@@ -77,15 +77,18 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
                    dmpc_stream_t stream);
 
 /* solve_recursion() in its training form: as dmpc_lqr_solve with gains, and the control blocks of every step's
- * Q-function left in HBM as well - Quu_out [T,B,nu,nu] and Qxu_out [T,B,nx,nu] (lqr_recursion.py:112-120).  The
+ * Q-function left in HBM as well - Quu_out [T,B,nu,nu] and Qxu_out [T,B,nx,nu] (lqr_recursion.py:112-120) - together
+ * with every step's value function Vv_out [T,B,nx,nx+1] (row i = V_t[i][:], v_t[i]; lqr_recursion.py:151-152).  The
  * gradient's second Riccati solve (DiffLqr.backward, lqr/differentiable_lqr.py:83-106) shares C and F with the
- * forward solve, so it can reuse K_t, Quu_t, Qxu_t and only redo the affine terms: dmpc_lqr_saved_solve below.
+ * forward solve, so it can reuse K_t, Quu_t, Qxu_t and only redo the affine terms (dmpc_lqr_saved_solve below), and
+ * the co-states are the value function's gradients, lambda_t = V_t x_t + v_t (dmpc_lqr_kkt_grad_saved).
  * Served by the generated instruction streams only (dmpc_lqr_solve_path >= 3, B % 4 == 0, all pointers 16-byte
  * aligned); DMPC_E_UNSUPPORTED otherwise - the caller then uses dmpc_lqr_solve and the full second solve.
  * `info` [B], if given, is WRITTEN (0 = clean) rather than or-ed into: the caller need not clear it first. */
 int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                           const float *f, const float *x_init, float *Ks_out, float *ks_out, float *Quu_out,
-                          float *Qxu_out, float *x_out, float *u_out, int32_t *info, dmpc_stream_t stream);
+                          float *Qxu_out, float *Vv_out, float *x_out, float *u_out, int32_t *info,
+                          dmpc_stream_t stream);
 
 /* The re-solve: the LQR problem of an earlier dmpc_lqr_solve_saving (same C, F) with another affine cost term c
  * [T,B,ns], f = 0 and another x_init.  K_t does not depend on c; k_t = -Quu_t^-1 (c_u + F_u^T v_{t+1}),
@@ -117,15 +120,19 @@ int dmpc_lqr_kkt_grad(int T, int B, int nx, int nu, const float *C, const float 
                       int strict_math, float *d_x_init, float *dC, float *dc, float *dF, float *df,
                       void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
 
-/* The same gradient when the forward solve was dmpc_lqr_solve_saving: the second Riccati solve of :108-114 shares C
- * and F with it, so its gains are Ks and only the affine recursion is redone (dmpc_lqr_saved_solve); C is then read
- * once (by the co-state sweep) instead of twice.  Same workspace; DMPC_E_UNSUPPORTED where dmpc_lqr_saved_solve is
- * (nothing has been launched then: call dmpc_lqr_kkt_grad instead). */
+/* The same gradient when the forward solve was dmpc_lqr_solve_saving.
+ * With Vv (its value functions) the whole gradient is ONE launch that reads neither C nor c: the reference's solve is exact
+ * block elimination of its KKT system, so its co-state recursions (:85-104, :115-126) equal lambda_t = V_t x_t + v_t and
+ * d_lambda_t = V_t dx_t + v'_t, v' the affine value term of the second solve (:108-114) - the affine re-solve from Ks, Quu,
+ * Qxu on [grad_x; grad_u] forms both while it rolls d_tau out and writes dC, dc, dF, df, d_x_init itself (all five
+ * required then; ws is not touched).  With Vv == NULL, or where that stream does not serve the size: the second solve
+ * reuses the gains (dmpc_lqr_saved_solve) and the co-state sweep reads C once.  DMPC_E_UNSUPPORTED where
+ * dmpc_lqr_saved_solve is (nothing has been launched then: call dmpc_lqr_kkt_grad instead). */
 int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                             const float *x, const float *u, const float *Ks, const float *Quu, const float *Qxu,
-                            const float *grad_x, const float *grad_u, int strict_math, float *d_x_init, float *dC,
-                            float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
-                            dmpc_stream_t stream);
+                            const float *Vv, const float *grad_x, const float *grad_u, int strict_math,
+                            float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes,
+                            int32_t *info, dmpc_stream_t stream);
 
 /* ---- D. batched LU (util.py:462-482 torch.lu, util.py:505-528 torch.lu_solve in float32) */
 /* A [B,n,n] -> LU [B,n,n], piv [B,n] int32 1-based (LAPACK getrf). */

@@ -25,5 +25,5 @@ def timeit(fn, reps=100):
 print("plain   %.1f us" % timeit(lambda: solve_device(C, c, F, f, x0, None, T, nx, nu)))
 print("gains   %.1f us" % timeit(lambda: solve_device(C, c, F, f, x0, None, T, nx, nu, want_gains=True)))
 print("saving  %.1f us" % timeit(lambda: solve_saving_device(C, c, F, f, x0, T, nx, nu)))
-x, u, Ks, ks, Quu, Qxu = solve_saving_device(C, c, F, f, x0, T, nx, nu)
+x, u, Ks, ks, Quu, Qxu, Vv = solve_saving_device(C, c, F, f, x0, T, nx, nu)
 print("resolve %.1f us" % timeit(lambda: saved_solve_device(c, F, Ks, Quu, Qxu, x0, T, nx, nu)))

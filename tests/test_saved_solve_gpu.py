@@ -36,7 +36,7 @@ def test_saving_solve_equals_the_plain_solve_and_leaves_the_q_blocks(case):
     info = torch.full((B,), 77, dtype=torch.int32, device="cuda")     # written, not or-ed into (include/dmpc.h)
     got = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu, info=info)
     assert got is not None
-    x, u, Ks, ks, Quu, Qxu = got
+    x, u, Ks, ks, Quu, Qxu, Vv = got
     assert int(info.abs().max()) == 0
     x1, u1, Ks1, ks1 = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, want_gains=True)
     torch.cuda.synchronize()
@@ -46,13 +46,16 @@ def test_saving_solve_equals_the_plain_solve_and_leaves_the_q_blocks(case):
     olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu, blocks=blocks)
     assert_close(npy(Quu), blocks["Quu"], TOL_PRIMAL, "Quu")
     assert_close(npy(Qxu), blocks["Qxu"], TOL_PRIMAL, "Qxu")
+    # the value functions [V_t | v_t] (lqr_recursion.py:151-152): what the one-pass gradient reads instead of C
+    assert_close(npy(Vv)[..., :nx], blocks["V"], TOL_PRIMAL, "V")
+    assert_close(npy(Vv)[..., nx], blocks["v"], TOL_PRIMAL, "v")
 
 
 @pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
 def test_saved_solve_is_the_full_solve_with_the_new_affine_term(case):
     B, T, nx, nu, with_f = case
     p, d = _problem(B, T, nx, nu, with_f)
-    _, _, Ks, _, Quu, Qxu = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
+    _, _, Ks, _, Quu, Qxu, _ = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
     rng = np.random.RandomState(17)
     c2 = rng.randn(T, B, nx + nu).astype(np.float32).astype(np.float64)
     x2 = rng.randn(B, nx).astype(np.float32).astype(np.float64)
@@ -93,6 +96,35 @@ def test_kkt_gradient_from_saved_gains_against_oracle(case, strict):
     out2 = plain.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
     for a, b, key in zip(out, out2, KEYS):
         assert_close(npy(a), npy(b), 1e-4, key + " saved vs full")
+
+
+@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("case", CASES, ids=[str(c) for c in CASES])
+def test_one_pass_gradient_equals_the_resolve_and_costate_path(case, strict):
+    """dmpc_lqr_kkt_grad_saved with the value functions (one launch, reads neither C nor c: lambda_t = V_t x_t + v_t,
+    d_lambda_t = V_t dx_t + v'_t) against the same call without them (affine re-solve + co-state sweep over C) and against
+    the oracle's own recursions (differentiable_lqr.py:85-134) at the stated tolerances; dc = d_tau comes out of the same
+    affine recursion and rollout in both, bit for bit"""
+    B, T, nx, nu, with_f = case
+    p, d = _problem(B, T, nx, nu, with_f, seed=11)
+    rng = np.random.RandomState(29)
+    gx = rng.randn(T, B, nx).astype(np.float32)
+    gu = rng.randn(T, B, nu).astype(np.float32)
+    x, u, Ks, _, Quu, Qxu, Vv = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
+    gxd, gud = torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()
+    one = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gxd, gud, T, nx, nu, strict_math=strict, saved=(Ks, Quu, Qxu, Vv))
+    assert _lib.last_kernel_name().endswith("true, true>(dmpc::LqrArgs)"), _lib.last_kernel_name()   # ... AFFINE, ADJ
+    two = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gxd, gud, T, nx, nu, strict_math=strict, saved=(Ks, Quu, Qxu))
+    assert "costate" in _lib.last_kernel_name()
+    torch.cuda.synchronize()
+    for a, b, key in zip(one, two, KEYS):
+        assert_close(npy(a), npy(b), TOLS[key], key + " one launch vs re-solve + co-state sweep")
+    assert torch.equal(one[2], two[2]), "dc = d_tau"
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx.astype(np.float64), gu.astype(np.float64),
+                                T, nx, nu, strict_math=strict)
+    for got, want, key in zip(one, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)
 
 
 def test_non_symmetric_cost_matrix():
@@ -196,8 +228,9 @@ def test_outputs_that_are_not_asked_for_leave_the_others_unchanged(skip, use_sav
     """include/dmpc.h: any of dC / dF / df may be NULL - the remaining outputs are the same numbers"""
     B, T, nx, nu = 8, 12, 8, 2
     _, d = _problem(B, T, nx, nu, True, seed=9)
-    x, u, Ks, _, Quu, Qxu = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
-    saved = (Ks, Quu, Qxu) if use_saved else None
+    x, u, Ks, _, Quu, Qxu, Vv = solve_saving_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], T, nx, nu)
+    saved = (Ks, Quu, Qxu, Vv) if use_saved else None     # (the one-pass form needs every output: a skipped one sends the
+    # call down the re-solve + co-state path, whose numbers must then agree with the one-pass form's to rounding)
     gx, gu = torch.ones_like(x), 0.5 * torch.ones_like(u)
     full = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu, saved=saved)
     part = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu, saved=saved, need_dC="dC" not in skip,
@@ -206,5 +239,7 @@ def test_outputs_that_are_not_asked_for_leave_the_others_unchanged(skip, use_sav
     for a, b, key in zip(full, part, KEYS):
         if key in skip:
             assert b is None
+        elif use_saved:
+            assert_close(npy(a), npy(b), TOLS[key], key)
         else:
             assert torch.equal(a, b), key
