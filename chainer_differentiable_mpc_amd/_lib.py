@@ -30,6 +30,7 @@ SIGNATURES = {
     "dmpc_lqr_solve_path": (_c_i, [_c_i] * 4),
     "dmpc_lqr_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_lqr_solve": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_lqr_saving_available": (_c_i, [_c_i] * 4),
     "dmpc_lqr_solve_saving": (_c_i, [_c_i] * 4 + [_c_f] * 14),
     "dmpc_lqr_saved_solve": (_c_i, [_c_i] * 4 + [_c_f] * 10),
     "dmpc_lqr_backward_sweep": (_c_i, [_c_i] * 4 + [_c_f] * 9),

@@ -311,13 +311,18 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     F = [R.take(nx) for _ in range(3)]
     W = R.take(max(nx, 8 if mpc else 4), align=4)     # DPP path: W = V F~ ; MFMA path: G = V^T F~ (rows = x columns of V); mpc: the QP's temporaries
     G10 = R.take(1)[0]                  # MFMA path: row "1" of G^ = F^T v
-    A = [R.take(nu, align=2 if save and nu == 2 and m_ == 0 else 1) for m_ in range(nu)]   # save: Quu leaves as one dwordx4
+    A = [R.take(nu, align=4 if save and nu == 2 and m_ == 0 else 1) for m_ in range(nu)]   # save: Quu is staged as one b128
+    # save: staging area [Vv | Qxu | Quu] of the wave's four trajectories (bytes), its chunks and store instructions
+    SV_Q, SV_U = 16 * nx * (nx + 1), 16 * (nx * (nx + 1) + nx * nu)
+    SV_N = nx * (nx + 1) + nx * nu + nu * nu
+    SV_NST = (SV_N + 63) // 64
     Kt = R.take(nu)
     Rr = R.take(nu)
     tP, tPQ, tL0, tM1, tRA, tRB, tRP, tT, tLL, tD2, tRD, tY1, tT2 = TMP13 = R.take(13, align=2 if expand else 1)
     MINPIV = R.take(1)[0]
     QB = R.take(1)[0] if affine else None   # affine: second accumulator of q = c + F^T v
     XV0 = R.take(1)[0]                  # x_init (lanes < nx), loaded by the stream itself
+    SVD = [R.take(4, align=4) for _ in range(SV_NST)] if save else None   # save: the staged chunks on their way out
     ACT = [R.take(nu) for _ in range(3)] if masked and not mpc else None   # clamped-control flags of the slot in each register set
     EPS = R.take(1)[0] if masked and not mpc else None
     UC = [R.take(nu) for _ in range(3)] if mpc else None      # mpc: u_t, lower_t, upper_t of the slot in each register set
@@ -694,30 +699,26 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             for m in range(nu):
                 P.raw("global_store_dword %s, %s, off" % (pk[m], Kt[m]))
         if save:
-            # Qxu_t: rows i < nx of Q~ hold it in lanes nx..ns-1 (the value update below writes over them);
-            # Quu_t: every lane has it in A - lane 0 of each row stores the nu * nu floats
+            # The saved blocks leave through an LDS staging area as the contiguous 16-byte chunks they form in HBM (the
+            # 8-byte row pieces of Qxu, 36-byte rows of [V | v] cost more as stores than the solve's arithmetic: the saving
+            # solve took 68 us with them against 40 us plain).  Qxu_t: rows i < nx of Q~ hold it in lanes nx..ns-1 (the value
+            # update below writes over them); Quu_t: every lane has it in A - lane 0 of each row writes the nu * nu floats
             P.uses(Qs[:nx] + [r_ for row_ in A for r_ in row_])
             P.raw("s_mov_b64 exec, " + S_UM)
             for i in range(nx):
-                P.raw("global_store_dword %%[pqx], %s, off offset:%d" % (Qs[i], i * nu * 4))
+                P.raw("ds_write_b32 %%[asq], %s offset:%d" % (Qs[i], SV_Q + i * nu * 4))
             P.raw("s_mov_b64 exec, " + S_ROW0)
-            if nu == 2:
-                quu = A[0] + A[1]
-                if int(quu[0][1:]) % 2 == 0:
-                    P.raw("global_store_dwordx4 %%[psq], %s, off" % vrange(quu))
-                else:                                   # register tuples start on even registers
-                    for j_, r_ in enumerate(quu):
-                        P.raw("global_store_dword %%[psq], %s, off offset:%d" % (r_, 4 * j_))
+            quu = [r_ for row_ in A for r_ in row_]
+            if nu == 2 and int(quu[0][1:]) % 4 == 0:
+                P.raw("ds_write_b128 %%[asu], %s offset:%d" % (vrange(quu), SV_U))
             else:
-                P.raw("global_store_dword %%[psq], %s, off" % A[0][0])
+                for j_, r_ in enumerate(quu):
+                    P.raw("ds_write_b32 %%[asu], %s offset:%d" % (r_, SV_U + 4 * j_))
         P.raw("s_mov_b64 exec, -1")
         P.exec_written()
         if write_k:
             for m in range(nu):
                 P.v("v_lshl_add_u64 %s, %s, 0, %%[dk]" % (pk[m], pk[m]))
-        if save:
-            P.v("v_lshl_add_u64 %[pqx], %[pqx], 0, %[dqx]")
-            P.v("v_lshl_add_u64 %[psq], %[psq], 0, %[dsq]")
         if not mpc:
             P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
 
@@ -928,20 +929,35 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         vupdate(s)
         if save:
             # the value function of the step, [V_t | v_t] (row i of Q~ now: V_t[i][:] in lanes < nx, v_t[i] in lane aff), as
-            # rows of nx + 1 floats: what the one-pass gradient reads instead of C (lambda_t = V_t x_t + v_t, the `adj` form)
+            # rows of nx + 1 floats: what the one-pass gradient reads instead of C (lambda_t = V_t x_t + v_t, the `adj` form);
+            # then [Vv | Qxu | Quu] of the wave's four trajectories go out as whole chunks
             P.uses(Q[s][:nx])
             P.raw("s_mov_b64 exec, " + S_KM)
             for i in range(nx):
-                P.raw("global_store_dword %%[pvv], %s, off offset:%d" % (Q[s][i], i * (nx + 1) * 4))
+                P.raw("ds_write_b32 %%[asv], %s offset:%d" % (Q[s][i], i * (nx + 1) * 4))
             P.raw("s_mov_b64 exec, -1")
             P.exec_written()
-            P.v("v_lshl_add_u64 %[pvv], %[pvv], 0, %[dvv]")
+            for q in range(SV_NST):
+                P.raw("ds_read_b128 %s, %%[ach] offset:%d" % (vrange(SVD[q]), q * 1024))
+            P.raw("s_waitcnt lgkmcnt(0)")
+            for q in range(SV_NST):
+                part = SV_N - 64 * q
+                if part <= 32:
+                    P.raw("s_mov_b64 exec, 0x%x" % ((1 << part) - 1))
+                elif part < 64:
+                    P.raw("s_mov_b32 exec_hi, 0x%x" % ((1 << (part - 32)) - 1))
+                P.raw("global_store_dwordx4 %%[pso%d], %s, off" % (q, vrange(SVD[q])))
+                if part < 64:
+                    P.raw("s_mov_b64 exec, -1")
+                    P.exec_written()
+            for q in range(SV_NST):
+                P.v("v_lshl_add_u64 %%[pso%d], %%[pso%d], 0, %%[sso%d]" % (q, q, q))
 
     n_step_stores = 0      # global stores per backward step (not mpc)
     if write_k:
         n_step_stores += nu
     if save:
-        n_step_stores += nx + (1 if nu == 1 or int(A[0][0][1:]) % 2 == 0 else nu * nu) + nx
+        n_step_stores += SV_NST
     assert (D - 1) * (NDB_ALL + n_step_stores) <= 63
     LC = 3 * D // (3 if D % 3 == 0 else 1)     # steps per trip of the loop form: lcm(register sets, ring slots)
     callsite = [0]
@@ -1554,7 +1570,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if masked:
         rw.append(("pm", '"+v"(in.pm)'))
     if save:
-        rw += [("pqx", '"+v"(in.pqx)'), ("psq", '"+v"(in.psq)'), ("pvv", '"+v"(in.pvv)')]
+        for q in range(SV_NST):
+            rw.append(("pso%d" % q, '"+v"(in.pso[%d])' % q))
     ins = []
     for q in range(L.ndma_b):
         ins.append(("str1_%d" % q, '"v"(in.str1[%d])' % q))
@@ -1588,7 +1605,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
     if save:
-        ins += [("dqx", '"v"(in.dqx)'), ("dsq", '"v"(in.dsq)'), ("dvv", '"v"(in.dvv)')]
+        for q in range(SV_NST):
+            ins.append(("sso%d" % q, '"v"(in.sso[%d])' % q))
+        ins += [("asv", '"v"(in.asv)'), ("asq", '"v"(in.asq)'), ("asu", '"v"(in.asu)'), ("ach", '"v"(in.ach)')]
     if masked:
         ins += [("dm", '"v"(in.dm)'), ("am", '"v"(in.am)')]
     ins += [("ring", '"s"(in.ring)'), ("T", '"s"(in.T)'), ("nz", '"s"(in.nz)'), ("bwd_only", '"v"(in.bwd_only)')]
@@ -1616,6 +1635,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
              % (L.NSTASH, L.NFD, L.FAREA, L.H, L.SPD, 16 * L.nchunk_b))
     if adj:
         o.append("  static constexpr int ADJ_NDA = %d, ADJ_SLOT = %d, ADJ_NST = %d;\n" % (NDA, NDA * 1024, NST))
+    if save:
+        o.append("  static constexpr int SAVE_STAGE_BYTES = %d, SAVE_NST = %d;\n" % (16 * SV_N, SV_NST))
     # block 1: the first DB groups
     rw1 = [("ptr%d" % q, '"+v"(in.ptr[%d])' % q) for q in range(L.ndma_b)] + [("tf", '"+s"(in.tf)')]
     if masked:
@@ -1670,8 +1691,9 @@ struct LqrAsmIn {
   int bwd_only;                      // 1 = stop after the backward sweep (LqrRecursion.backward()); same in every lane
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
-  uint64_t pqx, dqx, psq, dsq;       // save: Qxu store pointer (lanes nx..ns-1: column m of row 0) / Quu (lane 0), time strides
-  uint64_t pvv, dvv;                 // save: [V_t | v_t] store pointer (lane j < nx: column j of row 0, lane ns: column nx), time stride
+  // save: [Vv | Qxu | Quu] leave through a staging area (LDS byte addresses of: column min(lane, nx) of row 0 of this
+  // trajectory's [V | v] - lane ns is column nx -, column lane - nx of row 0 of Qxu, Quu) as 16-byte chunks: pso / sso / ach
+  unsigned asv, asq, asu;
   uint64_t pm, dm;                   // masked: DMA source of this lane's dword of clamped-control flags, time stride
   unsigned am;                       // masked: LDS byte address (ring slot 0, without the padding offset) of this row's flags
   int n_qp_iter;                     // mpc (wave-uniform): iteration cap of the box QP
@@ -1694,8 +1716,8 @@ struct LqrAsmIn {
   unsigned avr[4];                   // LDS byte address of row min(lane, nx-1) of this trajectory's [V | v] in ring slot q
   unsigned atx;                      // ... of [x; u][min(lane, ns-1)] in ring slot 0
   unsigned awc, awe, awf, awd;       // staging area (without its ring offset): column `lane` of row 0 of dC / dc / dF, df[lane]
-  unsigned ach;                      // ring + lane64 * 16: this lane's chunk of the staging area
-  uint64_t pso[4], sso[4];           // store pointer of this lane's chunk of [dC | dc | dF | df] at t = 0, time stride
+  unsigned ach;                      // staging area + lane64 * 16: this lane's chunk (adj: without the area's ring offset)
+  uint64_t pso[4], sso[4];           // store pointer of this lane's chunk (adj: of [dC | dc | dF | df] at t = 0), time stride
   float wa, wb;                      // dC = wa dtau (x) tau + wb tau (x) dtau
   int dfshift;                       // 0: df[t] = d_lambda[t] (the reference), 1: d_lambda[t+1]
 };

@@ -65,6 +65,14 @@ static int solve_path(int T, int B) {
   return 1;
 }
 
+// the saving solve: the stash form of the generated stream with room in LDS for the staging area of the saved blocks
+template <int NX, int NU, int L>
+static int saving_available(int T, int B) {
+  if constexpr (L == 16 && LqrAsm<NX, NU, true, true, false, false, true>::kAvailable)
+    return solve_path<NX, NU, L>(T, B) == 4 && lqr_asm_lds_bytes<NX, NU, true, true>(T) <= kAsmLdsBudget;
+  return 0;
+}
+
 template <int NX, int NU, int L>
 static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   constexpr int GPB = 256 / L;
@@ -153,9 +161,11 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   do {                                                                                                           \
     const size_t shmem = lqr_asm_lds_bytes<NX, NU, STASH>(a.T);                                                  \
     if constexpr (LqrAsm<NX, NU, true, STASH, false, false, true>::kAvailable) {                                 \
-      if (a.Quu_out != nullptr && write_k) { /* training form: Quu, Qxu saved too */                             \
-        if (has_f) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, true, STASH, false, false, true>), g, block, shmem, stream, a); \
-        else DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, true, STASH, false, false, true>), g, block, shmem, stream, a); \
+      if (a.Quu_out != nullptr && write_k) { /* training form: Quu, Qxu, [V | v] saved too (staged in LDS) */     \
+        const size_t shmem_s = lqr_asm_lds_bytes<NX, NU, STASH, true>(a.T);                                      \
+        if (shmem_s > kAsmLdsBudget) return DMPC_E_UNSUPPORTED;                                                  \
+        if (has_f) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, true, STASH, false, false, true>), g, block, shmem_s, stream, a); \
+        else DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, true, STASH, false, false, true>), g, block, shmem_s, stream, a); \
         return (int)hipGetLastError();                                                                           \
       }                                                                                                          \
     }                                                                                                            \
@@ -311,6 +321,15 @@ int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   return lqr_family(nx, nu) == 3 ? 0 : DMPC_E_UNSUPPORTED;
 }
 
+int dmpc_lqr_saving_available(int T, int B, int nx, int nu) {
+  if (T <= 1 || B <= 0 || B % 4 != 0) return 0;
+#define X(NX_, NU_, L_) \
+  if (nx == NX_ && nu == NU_) return saving_available<NX_, NU_, L_>(T, B);
+  DMPC_LQR_SHAPES(X)
+#undef X
+  return 0;
+}
+
 size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
   // gains [T,B,nu,nx] + [T,B,nu]; only touched when they do not fit in LDS (long horizons) or
@@ -342,7 +361,7 @@ int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const fl
   if (!C || !c || !F || !x_init || !x_out || !u_out || !Ks_out || !ks_out || !Quu_out || !Qxu_out || !Vv_out)
     return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(Quu_out)) return DMPC_E_BADARG;
-  if (dmpc_lqr_solve_path(T, B, nx, nu) < 3 || B % 4 != 0) return DMPC_E_UNSUPPORTED;   // the generated streams only
+  if (!dmpc_lqr_saving_available(T, B, nx, nu)) return DMPC_E_UNSUPPORTED;   // the stash form of the generated stream only
   LqrArgs a{T, B, C, c, F, f, x_init, nullptr, Ks_out, ks_out, nullptr, nullptr, x_out, u_out, info};
   a.Quu_out = Quu_out;
   a.Qxu_out = Qxu_out;

@@ -33,11 +33,24 @@ namespace dmpc {
 // segment (the library allocates nothing), so that the stream itself has no "f is absent" case.
 __device__ const float4 dmpc_zero_chunks[16] = {};
 
-template <int NX, int NU, bool STASH>
+// Bytes of a wave's gain rows + (saving solve) the staging area of the saved blocks behind them: the stream zero-fills
+// the gain rows in whole 1 KB pieces, and what that overshoots may be the staging area (scratch until the first step).
+template <int NX, int NU, bool STASH, bool SAVE = false>
+constexpr size_t lqr_asm_gain_bytes(int T) {
+  using G = LqrAsm<NX, NU, false, STASH>;
+  const size_t rows = (size_t)4 * T * NU * G::KROW * 4, filled = round_up(rows, 1024);
+  if constexpr (SAVE) {
+    const size_t both = round_up(rows, 16) + (size_t)LqrAsm<NX, NU, true, STASH, false, false, true>::SAVE_STAGE_BYTES;
+    return both > filled ? both : filled;
+  } else {
+    return filled;
+  }
+}
+
+template <int NX, int NU, bool STASH, bool SAVE = false>
 constexpr size_t lqr_asm_lds_bytes(int T) {
   using G = LqrAsm<NX, NU, false, STASH>;
-  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) +
-         4 * round_up((size_t)4 * T * NU * G::KROW * 4, 1024);  // per wave: whole 1 KB pieces (zero fill)
+  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) + 4 * lqr_asm_gain_bytes<NX, NU, STASH, SAVE>(T);
 }
 
 // Per-lane LDS-DMA sources of the backward groups: chunk g = q*64 + lane64 of the slot [C | c | F | f | padding]
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   const unsigned lds0 = lds_byte_address(lds);
   const unsigned ring = lds0 + (unsigned)wave * G::RING_BYTES;
   const unsigned farea = lds0 + 4u * G::RING_BYTES + (unsigned)wave * (STASH ? G::FAREA_BYTES : 0);
-  const unsigned gain_wave_bytes = (unsigned)round_up((size_t)4 * T * NU * KROW * 4, 1024);
+  const unsigned gain_wave_bytes = (unsigned)lqr_asm_gain_bytes<NX, NU, STASH, SAVE>(T);
   const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + (STASH ? 4u * G::FAREA_BYTES : 0u) + (unsigned)wave * gain_wave_bytes;
   const unsigned gain_traj = gain_wave + (unsigned)r * (unsigned)(T * NU * KROW * 4);
 
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   // is loaded and x_0 stored by the stream itself.
   G::issue_first(in);
   in.gz = gain_wave + (unsigned)lane64 * 16u;  // the stream zero-fills the gain rows behind its first DMAs
-  in.nz = (int)(gain_wave_bytes / 1024u);
+  in.nz = (int)(round_up((size_t)4 * T * NU * KROW * 4, 1024) / 1024u);
   const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
   const bool col_aff = lane == AFF;
   if constexpr (AFFINE) lqr_asm_affine_addresses<NX, NU, G>(in, ring, r, lane, a.c_u != nullptr);
@@ -245,18 +258,29 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
     for (int m = 0; m < NU; ++m) in.pk[m] = 0;
     in.dk = 0;
   }
-  if constexpr (SAVE) {   // Qxu: lane nx + m owns column m (row i by the instruction offset); Quu: lane 0 of the row
-    const size_t tb = (size_t)(T - 1) * B + (size_t)b;
+  if constexpr (SAVE) {
+    // [Vv | Qxu | Quu] of the wave's four trajectories are staged behind its gain rows and leave as 16-byte chunks
+    constexpr int nVv = NX * (NX + 1), nQx = NX * NU, nQu = NU * NU;
+    const unsigned stg = gain_wave + (unsigned)round_up((size_t)4 * T * NU * KROW * 4, 16);
     const int m_ = lane >= NX && lane < NS ? lane - NX : 0;
-    in.pqx = reinterpret_cast<uint64_t>(a.Qxu_out + tb * NX * NU + m_);
-    in.dqx = (uint64_t)0 - (uint64_t)(B * NX * NU * 4);
-    in.psq = reinterpret_cast<uint64_t>(a.Quu_out + tb * NU * NU);
-    in.dsq = (uint64_t)0 - (uint64_t)(B * NU * NU * 4);
-    // [V_t | v_t]: lane j < nx owns column j, lane ns (the affine column) column nx; row i by the instruction offset
-    in.pvv = reinterpret_cast<uint64_t>(a.Vv_out + tb * NX * (NX + 1) + (lane < NX ? lane : NX));
-    in.dvv = (uint64_t)0 - (uint64_t)(B * NX * (NX + 1) * 4);
+    in.asv = stg + (unsigned)((r * NX * (NX + 1) + (lane < NX ? lane : NX)) * 4);   // lane ns (the affine column) owns column nx
+    in.asq = stg + (unsigned)((r * NX * NU + m_) * 4);
+    in.asu = stg + (unsigned)(r * NU * NU * 4);
+    in.ach = stg + (unsigned)lane64 * 16u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int g = q * 64 + lane64;
+      const bool isV = g < nVv, isQx = !isV && g < nVv + nQx, isQu = !isV && !isQx && g < nVv + nQx + nQu;
+      const uint64_t base = isV ? reinterpret_cast<uint64_t>(a.Vv_out) : isQx ? reinterpret_cast<uint64_t>(a.Qxu_out)
+                                                                              : reinterpret_cast<uint64_t>(a.Quu_out);
+      const size_t per = isV ? (size_t)NX * (NX + 1) * 4 : isQx ? (size_t)NX * NU * 4 : (size_t)NU * NU * 4;
+      const int g0 = isV ? 0 : isQx ? nVv : nVv + nQx;
+      const bool any = isV || isQx || isQu;
+      in.pso[q] = any ? base + ((size_t)(T - 1) * B + (size_t)b0) * per + (size_t)(g - g0) * 16 : 0;
+      in.sso[q] = any ? (uint64_t)0 - (uint64_t)(B * per) : 0;
+    }
   } else {
-    in.pqx = in.dqx = in.psq = in.dsq = in.pvv = in.dvv = 0;
+    in.asv = in.asq = in.asu = 0;
   }
 
   // lane i < nx: row i of [F_t | f_t]; lane nx+m: gain row m; the other lanes shadow the last gain row
@@ -363,7 +387,8 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
       in.sso[q] = any ? (uint64_t)(B * per) : 0;
     }
   } else {
-    in.avp = in.atx = in.awc = in.awe = in.awf = in.awd = in.ach = 0;
+    in.avp = in.atx = in.awc = in.awe = in.awf = in.awd = 0;
+    if constexpr (!SAVE) in.ach = 0;
     in.wa = in.wb = 0.f;
     in.dfshift = 0;
   }

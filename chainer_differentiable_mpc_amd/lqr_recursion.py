@@ -163,7 +163,7 @@ def _workspace(nbytes, device):
 def saving_solve_available(T, B, n_state, n_ctrl):
     """does `solve_saving_device` (and with it the saved-gains gradient) serve this size?"""
     lib = _lib.load()
-    return B % 4 == 0 and n_ctrl <= 2 and lib.dmpc_lqr_solve_path(T, B, n_state, n_ctrl) == 4
+    return bool(lib.dmpc_lqr_saving_available(T, B, n_state, n_ctrl))
 
 
 def solve_saving_device(C, c, F, f, x_init, T, n_state, n_ctrl, info=None):

@@ -82,9 +82,11 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
  * gradient's second Riccati solve (DiffLqr.backward, lqr/differentiable_lqr.py:83-106) shares C and F with the
  * forward solve, so it can reuse K_t, Quu_t, Qxu_t and only redo the affine terms (dmpc_lqr_saved_solve below), and
  * the co-states are the value function's gradients, lambda_t = V_t x_t + v_t (dmpc_lqr_kkt_grad_saved).
- * Served by the generated instruction streams only (dmpc_lqr_solve_path >= 3, B % 4 == 0, all pointers 16-byte
- * aligned); DMPC_E_UNSUPPORTED otherwise - the caller then uses dmpc_lqr_solve and the full second solve.
+ * Served by the generated instruction stream that keeps F on chip only (dmpc_lqr_saving_available: dmpc_lqr_solve_path
+ * == 4, B % 4 == 0, room in LDS for the staging area of the saved blocks; all pointers 16-byte aligned);
+ * DMPC_E_UNSUPPORTED otherwise - the caller then uses dmpc_lqr_solve and the full second solve.
  * `info` [B], if given, is WRITTEN (0 = clean) rather than or-ed into: the caller need not clear it first. */
+int dmpc_lqr_saving_available(int T, int B, int nx, int nu);   /* 1: dmpc_lqr_solve_saving (and the saved-gains gradient) serves this size */
 int dmpc_lqr_solve_saving(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                           const float *f, const float *x_init, float *Ks_out, float *ks_out, float *Quu_out,
                           float *Qxu_out, float *Vv_out, float *x_out, float *u_out, int32_t *info,
