@@ -9,7 +9,7 @@ there is no CPU fallback.
 """
 from . import synthetic  # noqa: F401
 from ._lib import DmpcError, load as load_library  # noqa: F401
-from .util import (LinDx, QuadCost, batch_lu_factor, batch_lu_solve, bdot, bger, bmv, bquad,  # noqa: F401
+from .util import (LinDx, QuadCost, TiledQuadCost, batch_lu_factor, batch_lu_solve, bdot, bger, bmv, bquad,  # noqa: F401
                    clamp, expand_batch, expand_time_batch, get_cost, get_traj)
 from .lqr_recursion import LqrRecursion  # noqa: F401
 from .differentiable_lqr import DiffLqr, LqrNet, LqrNet_cost_dx  # noqa: F401

@@ -49,7 +49,8 @@ SIGNATURES = {
     "dmpc_mpc_forward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [ctypes.c_float, _c_i] + [_c_f] * 10),
     "dmpc_mpc_forward_rec_pendulum": (_c_i, [_c_i] * 2 + [_c_f] * 8 + [ctypes.c_float] * 6 + [_c_i] + [_c_f] * 10),
     "dmpc_pendulum_rollout_linearize": (_c_i, [_c_i] * 2 + [_c_f] * 2 + [ctypes.c_float] * 5 + [_c_i] + [_c_f] * 4),
-    "dmpc_mpc_step_backward": (_c_i, [_c_i] * 4 + [_c_f] * 9 + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_mpc_step_backward": (_c_i, [_c_i] * 4 + [_c_f] * 9 + [_c_f] * 7 + [_c_f, _c_f, ctypes.c_float]
+                               + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_lin_rollout": (_c_i, [_c_i] * 4 + [_c_f] * 6),
     "dmpc_box_ddp_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_box_ddp": (_c_i, [_c_i] * 4 + [_c_f] * 5 + [_c_i, _c_f] + [_c_f] * 3 +

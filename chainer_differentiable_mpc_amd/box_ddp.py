@@ -17,8 +17,11 @@ import torch
 from . import _lib
 from .approximate import approximate_cost, linearize_dynamics
 from .lqr_recursion import _as_tensor, _device_of, _workspace
-from .mpc_step import MPCstep
-from .util import LinDx, QuadCost, get_cost, get_traj
+from .mpc_step import MPCstep, _MPCstepTiledFn
+from .util import LinDx, QuadCost, TiledQuadCost, get_cost, get_traj
+
+
+_UNRESOLVED = []     # solvers whose device loop has not been read back yet (lazy_status)
 
 
 def table_log(tag, d, _seen=[]):
@@ -36,7 +39,7 @@ class BoxDDP(torch.nn.Module):
     def __init__(self, T, u_lower, u_upper, n_batch, n_state, n_ctrl, u_init, eps=1e-5, not_improved_lim=5,
                  line_search_decay=0.2, max_line_search_iter=10, best_cost_eps=1e-4, max_iter=10,
                  detach_unconverged=True, exit_unconverged=True, verbose=False, ilqr_verbose=False,
-                 update_dynamics=True, quiet=False, device_loop=True, batch_coupled=False):
+                 update_dynamics=True, quiet=False, device_loop=True, batch_coupled=False, lazy_status=False):
         super().__init__()
         self.T, self.n_batch, self.n_state, self.n_ctrl = T, n_batch, n_state, n_ctrl
         self.n_sc = n_state + n_ctrl
@@ -60,12 +63,20 @@ class BoxDDP(torch.nn.Module):
         # batch-global tests (pnqp.py:139-144,172,187; the batch must fit one cooperative launch).  The outer
         # stop tests (box_ddp.py:223-230) are batch-global in both modes, as in the reference.
         self.batch_coupled = batch_coupled
-        self.status = None
-        self.info = None            # MPC step flags of the device loop, per trajectory
+        # The device-driven loop ends with ONE read-back (loop state, input asserts, NaN flags).  lazy_status=True does
+        # not wait for it inside forward(): the solution and - for a `TiledQuadCost` - the gradient node with its detach
+        # mask need nothing from the host, so a training loop keeps launching while the GPU works.  `status`, `n_iter`,
+        # `info`, the asserts and the reference's non-convergence warning then happen on first access, and at the latest
+        # when the next solve of any BoxDDP starts (errors surface one call late instead of never).
+        self.lazy_status = lazy_status
+        self._pending = None        # (state [8] int32 on the device, info [B]) of a solve not read back yet
+        self._warn_unconverged = False
+        self._status = None
+        self._info = None           # MPC step flags of the device loop, per trajectory
+        self._n_iter = 0
         self._bounds_on = None
         self._u_zero = None
         self._best_norm_max = None
-        self.n_iter = 0
         if isinstance(u_lower, (int, float)):       # scalar bounds are broadcast to [T,B,nu] (:68-90)
             u_lower = torch.full((T, n_batch, n_ctrl), float(u_lower))
             u_upper = torch.full((T, n_batch, n_ctrl), float(u_upper))
@@ -75,9 +86,66 @@ class BoxDDP(torch.nn.Module):
         assert list(self.u_upper.shape) == [T, n_batch, n_ctrl]
 
     def _say(self, msg):
-        self.status = msg.strip()
+        self._status = msg.strip()
         if not self.quiet:
             print(msg)
+
+    # -- results of the loop's read-back (resolved on first access when lazy_status deferred it)
+    @property
+    def status(self):
+        self._resolve()
+        return self._status
+
+    @status.setter
+    def status(self, v):
+        self._status = v
+
+    @property
+    def n_iter(self):
+        self._resolve()
+        return self._n_iter
+
+    @n_iter.setter
+    def n_iter(self, v):
+        self._n_iter = v
+
+    @property
+    def info(self):
+        self._resolve()
+        return self._info
+
+    @info.setter
+    def info(self, v):
+        self._info = v
+
+    def _resolve(self):
+        """the one synchronisation of the device loop: loop state, the input asserts of MPCstep (mpc_step.py:133-138), NaN
+        flags, the reference's status line and its non-convergence warning (box_ddp.py:223-230,263-273)"""
+        if self._pending is None:
+            return
+        state, info = self._pending
+        self._pending = None
+        if self in _UNRESOLVED:
+            _UNRESOLVED.remove(self)
+        st = state.cpu().tolist()
+        self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
+        assert not st[4]
+        assert not st[5], " lower is larger than upper"
+        if st[6]:                                 # the reference asserts on NaN inside every MPC step
+            raise AssertionError("BoxDDP: NaN/Inf in the solution of %d trajectories" % st[6])
+        self._info = info
+        self._n_iter = st[1]
+        if st[2] in self._STATUS:
+            self._say(self._STATUS[st[2]])
+        if self._warn_unconverged and self._best_norm_max:
+            self._warn_unconverged = False
+            self._warn()
+
+    def _warn(self):
+        if self.verbose:
+            print("LQR Warning: All examples did not converge to a fixed point.")
+            print("Detaching and *not* backpropping through the bad examples.")
+        warnings.warn("LQR Warning: All examples did not converge to a fixed point.")
 
     _STATUS = {1: "Converged", 2: "Not improved lim", 3: "Not Converged "}
 
@@ -115,6 +183,9 @@ class BoxDDP(torch.nn.Module):
             return None
         lib = _lib.load()
         _lib.require_gpu()
+        if not torch.cuda.is_current_stream_capturing():
+            for other in list(_UNRESOLVED):       # earlier solves whose read-back was deferred: their asserts come now
+                other._resolve()
         d = _device_of(x_init, cost.C, u)
         x0 = _lib.f32c(x_init.detach(), d)
         C, c = _lib.f32c(_as_tensor(cost.C).detach(), d), _lib.f32c(_as_tensor(cost.c).detach(), d)
@@ -149,16 +220,13 @@ class BoxDDP(torch.nn.Module):
         if rc == _lib.E_UNSUPPORTED:
             return None
         _lib.check(rc, "dmpc_box_ddp")
-        st = state.cpu().tolist()                 # the one synchronisation of the loop
-        self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
-        assert not st[4]
-        assert not st[5], " lower is larger than upper"
-        if st[6]:                                 # the reference asserts on NaN inside every MPC step
-            raise AssertionError("BoxDDP: NaN/Inf in the solution of %d trajectories" % st[6])
-        self.info = info
-        self.n_iter = st[1]
-        if st[2] in self._STATUS:
-            self._say(self._STATUS[st[2]])
+        self._pending = (state, info)
+        self._loop_flag = state[7:8]              # device int: some trajectory's best full_du_norm is above eps (:263)
+        self._warn_unconverged = False
+        if self not in _UNRESOLVED:
+            _UNRESOLVED.append(self)
+        if not self.lazy_status:
+            self._resolve()                       # the one synchronisation of the loop
         dev, dt = x_init.device, x_init.dtype
         best = {'x': bx.to(device=dev, dtype=dt), 'u': bu.to(device=dev, dtype=dt),
                 'costs': bc.to(device=dev, dtype=dt), 'full_du_norm': bn.to(device=dev, dtype=dt)}
@@ -262,22 +330,31 @@ class BoxDDP(torch.nn.Module):
                 self._say("Not Converged ")
         x, u = best['x'], best['u']
         costs = best['costs']
-        unconverged = self._best_norm_max if last_norm is not None and self._best_norm_max is not None \
-            else (float(best['full_du_norm'].max()) > self.eps)
+        deferred = self._pending is not None      # lazy_status: the loop has not been read back (device loop only)
+
+        def unconverged():
+            """some trajectory's best full_du_norm is above eps (:263) - a host decision: resolves a deferred read-back"""
+            self._resolve()
+            if last_norm is not None and self._best_norm_max is not None:
+                return self._best_norm_max
+            return float(best['full_du_norm'].max()) > self.eps
+
         fused = hasattr(dynamics, "fused_ok") and dynamics.fused_ok(x[0], u) and isinstance(cost, QuadCost)
         # Can anything upstream receive a gradient?  Decidable before the Taylor models are built when both models are
         # plain tensors: then, with nothing to differentiate, the no-op node and the detach blend below (which returns
         # its input unchanged when there is no graph) are skipped - no launches after the loop's one read-back.
         leaves = None
+        tiled = isinstance(cost, TiledQuadCost) and not self.update_dynamics    # the gradient goes to (Q, p) alone
         if isinstance(cost, QuadCost) and (fused or isinstance(dynamics, LinDx)):
-            leaves = [x_init, cost.C, cost.c] + ([dynamics.F, dynamics.f] if isinstance(dynamics, LinDx) else [])
+            leaves = [x_init] + ([cost.Q, cost.p] if isinstance(cost, TiledQuadCost) else [cost.C, cost.c]) + \
+                ([dynamics.F, dynamics.f] if isinstance(dynamics, LinDx) else [])
         if not torch.is_grad_enabled() or (leaves is not None and not any(
                 isinstance(t, torch.Tensor) and t.requires_grad for t in leaves)):
-            if self.detach_unconverged and unconverged:
-                if self.verbose:
-                    print("LQR Warning: All examples did not converge to a fixed point.")
-                    print("Detaching and *not* backpropping through the bad examples.")
-                warnings.warn("LQR Warning: All examples did not converge to a fixed point.")
+            if self.detach_unconverged:
+                if deferred:
+                    self._warn_unconverged = True          # (the warning comes with the read-back)
+                elif unconverged():
+                    self._warn()
             return x, u, costs
         # Taylor models at the best point and a no-op MPCstep node that carries the gradient (:234-259)
         if fused:
@@ -290,17 +367,35 @@ class BoxDDP(torch.nn.Module):
         else:
             Fm = Fm.detach()
             fm = None if fm is None else fm.detach()
+        if tiled and last_norm is not None and x.is_cuda and (cost.Q.requires_grad or cost.p.requires_grad or
+                                                              x_init.requires_grad):
+            # One (Q, p) tiled over time and batch, solved by the device loop: the node's inputs are the un-tiled tensors,
+            # its backward returns the gradient summed inside the co-state kernel (no [T,B,ns,ns] gradient, no reduction
+            # launches after it), and the detach mask of :263-289 gates the incoming gradient there from the loop's own
+            # device flags - the same gradients as blending x, u with their detached copies, without a host decision
+            d = x.device
+            retained = dict(C=_lib.f32c(cost.C, d), c=_lib.f32c(cost.c, d), F=_lib.f32c(Fm, d), x=_lib.f32c(x, d),
+                            u=_lib.f32c(u, d))
+            detach = (_lib.f32c(last_norm, d), self._loop_flag, self.eps) if self.detach_unconverged else None
+            spec = (T, B, nx, nu, d, _lib.f32c(lo, d), _lib.f32c(hi, d), detach)
+            x, u = _MPCstepTiledFn.apply(x[0].detach(), cost.Q, cost.p, spec, retained, x, u)
+            if self.detach_unconverged:
+                if deferred:
+                    self._warn_unconverged = True
+                elif unconverged():
+                    self._warn()
+            return x, u, costs
         node = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu, current_states=x,
                        true_cost=detached_cost(), true_dynamics=detached_dyn(), ls_decay=self.ls_decay,
                        max_ls_iter=self.max_ls_iter, verbose=self.ilqr_verbose, need_expand=True, no_op_forward=True)
         needs_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (Cm, cm, Fm, fm, x_init))
         if needs_graph:
+            if isinstance(cost, TiledQuadCost) and not self.update_dynamics:   # (host loop / CPU tensors: tile on the graph)
+                Cm = cost.Q[None, None].expand(T, B, -1, -1)
+                cm = cost.p[None, None].expand(T, B, -1)
             x, u = node.apply((x[0].detach(), Cm, cm, Fm, fm))
-        if self.detach_unconverged and unconverged:                                        # :263-289
-            if self.verbose:
-                print("LQR Warning: All examples did not converge to a fixed point.")
-                print("Detaching and *not* backpropping through the bad examples.")
-            warnings.warn("LQR Warning: All examples did not converge to a fixed point.")
+        if self.detach_unconverged and unconverged():                                      # :263-289
+            self._warn()
             if last_norm is None:
                 last_norm = for_out.full_du_norm
             keep = (last_norm < self.eps).to(x.dtype)[None, :, None]

@@ -17,6 +17,11 @@ struct CostateArgs {
   int df_shift;          // 0: df[t] = d_lambda[t] (differentiable_lqr.py:133); 1: df[t] = d_lambda[t+1]
   float *dx0, *dC, *dc, *dF, *df;  // outputs (dC, dF, df may be nullptr)
   int r_cols = 0;        // row length of r; 0 = ns.  nx: r is the state part alone (DiffLqr: grad_x as it is)
+  // Gradients of a cost that is ONE (C, c) tiled over time and batch (env_dx/il_env.py:119-129: the imitation loop's
+  // learnable cost): dC_sum [ns,ns] += sum_{t,b} dC[t][b], dc_sum [ns] += sum_{t,b} dc[t][b] - what autograd's backward
+  // of the tiling would reduce dC, dc to (326 K floats at config 4).  Accumulated per wavefront over its trajectories and
+  // timesteps, one atomic add per element and wavefront; the caller zeroes them.  dC / dc may then be nullptr.
+  float *dC_sum = nullptr, *dc_sum = nullptr;
 };
 
 // Shape dispatch (defined in kkt_api.hip).

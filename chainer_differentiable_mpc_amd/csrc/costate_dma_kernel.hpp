@@ -145,6 +145,10 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
   };
 
   float lam = 0.f, dlam = 0.f;  // lambda_{t+1}[lane], d_lambda_{t+1}[lane]  (lanes < NX)
+  const bool summed = a.dC_sum != nullptr;   // (uniform) the tiled-cost reduction: row `lane` of sum_t dC_t, sum_t dc_t[lane]
+  float accC[NS], accc = 0.f;
+#pragma unroll
+  for (int j = 0; j < NS; ++j) accC[j] = 0.f;
   auto step = [&](int t, const Slot &s) {  // the step of costate_kernel
     const size_t tb = (size_t)t * B + b;
     const float tau = s.tau, dtau = s.dtau;
@@ -160,14 +164,21 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
       }
       if (a.df != nullptr && a.df_shift == 1 && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
     }
-    if (a.dC != nullptr) {                                                    // :128-129
+    if (a.dC != nullptr || summed) {                                          // :128-129
       float row[NS];
       Blk::outer2(row, tau, dtau, a.out_sign * wa * dtau, a.out_sign * wb * tau);
-      if (is_tau) {
+      if (summed) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) scrC[(r * NS + lane) * NS + j] = row[j];
+        for (int j = 0; j < NS; ++j) accC[j] += row[j];
+        accc += a.out_sign * dtau;
       }
-      store_chunks<NS * NS>(scrC, a.dC + ((size_t)t * B + b0) * (NS * NS), lane64);
+      if (a.dC != nullptr) {
+        if (is_tau) {
+#pragma unroll
+          for (int j = 0; j < NS; ++j) scrC[(r * NS + lane) * NS + j] = row[j];
+        }
+        store_chunks<NS * NS>(scrC, a.dC + ((size_t)t * B + b0) * (NS * NS), lane64);
+      }
     }
     if (a.dc != nullptr && is_tau) a.dc[tb * NS + lane] = a.out_sign * dtau;
     float nl = s.ci, ndl = a.r_sign * s.ri;                                   // :92,102 / :115,124
@@ -204,6 +215,22 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
   }
   wait_vmcnt<0>();
   if (a.dx0 != nullptr && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
+  if (summed) {
+    // the wave's four trajectories (the last wave of a ragged grid repeats trajectories of its neighbour: those rows are
+    // left out) -> lanes of row 0 -> one atomic per element
+    const bool mine = ((int)blockIdx.x * 4 + wave) * 4 + r == b;   // false for a repeated trajectory
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      float v = mine ? accC[j] : 0.f;
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane64 < NS) atomicAdd(&a.dC_sum[lane64 * NS + j], v);
+    }
+    float v = mine ? accc : 0.f;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane64 < NS && a.dc_sum != nullptr) atomicAdd(&a.dc_sum[lane64], v);
+  }
 }
 
 }  // namespace dmpc

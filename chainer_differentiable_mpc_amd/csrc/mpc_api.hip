@@ -597,10 +597,14 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
 int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
                            const float *F_hat, const float *x, const float *u, const float *u_lower,
                            const float *u_upper, const float *grad_x, const float *grad_u, float *d_x_init,
-                           float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes, int32_t *info,
-                           dmpc_stream_t stream_) {
+                           float *dC, float *dc, float *dF, float *df, float *dC_sum, float *dc_sum,
+                           const float *detach_norm, const int32_t *detach_flag, float detach_eps, void *ws,
+                           size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
   if (T <= 1 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
-  if (!C_hat || !c_hat || !F_hat || !x || !u || !u_lower || !u_upper || !d_x_init || !dc || !ws) return DMPC_E_BADARG;
+  if (!C_hat || !c_hat || !F_hat || !x || !u || !u_lower || !u_upper || !d_x_init || !ws) return DMPC_E_BADARG;
+  if ((dC_sum == nullptr) != (dc_sum == nullptr) || (dc == nullptr && dc_sum == nullptr)) return DMPC_E_BADARG;
+  // the sums are formed by the LDS-DMA co-state kernel only (whole wavefronts of four trajectories, 16-lane shapes)
+  if (dC_sum != nullptr && (B % 4 != 0 || nx + nu + 1 > 16 || dmpc_lqr_kernel_family(nx, nu) != 1)) return DMPC_E_UNSUPPORTED;
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(dC) || !aligned16(dF))
     return DMPC_E_BADARG;
   const MpcWs w = mpc_layout(T, B, nx, nu);
@@ -614,7 +618,8 @@ int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, con
   uint8_t *mask = reinterpret_cast<uint8_t *>(base + w.mask);
   const size_t rows = (size_t)T * B;
   DMPC_LAUNCH_GGL(active_mask_kernel, dim3(grid_for(rows * (nx + nu))), dim3(256), 0, stream, rows, nx, nu, u,
-                     u_lower, u_upper, grad_x, grad_u, mask, neg, x0, (size_t)B * nx);
+                     u_lower, u_upper, grad_x, grad_u, mask, neg, x0, (size_t)B * nx, dC_sum, dc_sum, B, detach_norm,
+                     detach_flag, detach_eps);
   // LQR_active(0, C, -d_tau, F, None, u_zero_Index=active)                               mpc_step.py:374-376
   int rc = dmpc_lqr_solve(T, B, nx, nu, C_hat, neg, F_hat, nullptr, x0, mask, nullptr, nullptr, dx, du,
                           base + w.lqr, w.total - w.lqr, info, stream_);
@@ -622,6 +627,8 @@ int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, con
   // d_lambda_t = C_xx dx + C_xu du - d_tau[:nx] + ...  ->  r = neg, r_sign = +1; outputs negated  :383-446
   CostateArgs a{T, B, C_hat, c_hat, F_hat, x, u, dx, du, neg, 1.0f, -1.0f, /*dC_mode=*/1, /*df_shift=*/1,
                 d_x_init, dC, dc, dF, df};
+  a.dC_sum = dC_sum;
+  a.dc_sum = dc_sum;
   return launch_costate(nx, nu, a, stream);
 }
 

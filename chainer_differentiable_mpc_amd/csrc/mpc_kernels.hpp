@@ -1380,16 +1380,27 @@ __global__ __launch_bounds__(256) void active_mask_kernel(size_t n_rows, int nx,
                                                           const float *__restrict__ lo, const float *__restrict__ hi,
                                                           const float *__restrict__ gx, const float *__restrict__ gu,
                                                           uint8_t *__restrict__ active, float *__restrict__ neg,
-                                                          float *__restrict__ x0, size_t n_x0) {
+                                                          float *__restrict__ x0, size_t n_x0, float *__restrict__ zero_a,
+                                                          float *__restrict__ zero_b, int n_batch,
+                                                          const float *__restrict__ detach_norm,
+                                                          const int32_t *__restrict__ detach_flag, float detach_eps) {
   const int ns = nx + nu;
+  // BoxDDP's detach mask (mpc/box_ddp.py:263-289) applied to the incoming gradient instead of to the solution: when the
+  // solve ended with some trajectory above eps (*detach_flag != 0), trajectories whose last step was not below eps
+  // (detach_norm[b] >= eps) receive no gradient.  All three live on the device: no read-back decides it.
+  const bool gated = detach_norm != nullptr && (detach_flag == nullptr || *detach_flag != 0);
   const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // the tiled-cost sums the co-state kernel adds into (CostateArgs::dC_sum / dc_sum): cleared by the chain's first launch
+  if (zero_a != nullptr && tid < (size_t)(ns * ns)) zero_a[tid] = 0.f;
+  if (zero_b != nullptr && tid < (size_t)ns) zero_b[tid] = 0.f;
   for (size_t e = tid; e < n_rows * nu; e += stride)
     active[e] = (fabsf(u[e] - lo[e]) <= bound_tol(lo[e])) || (fabsf(u[e] - hi[e]) <= bound_tol(hi[e]));
   for (size_t e = tid; e < n_rows * ns; e += stride) {
     const size_t row = e / ns;
     const int j = (int)(e % ns);
     const float v = j < nx ? (gx ? gx[row * nx + j] : 0.f) : (gu ? gu[row * nu + (j - nx)] : 0.f);
-    neg[e] = -v;
+    const bool keep = !gated || detach_norm[row % (size_t)n_batch] < detach_eps;
+    neg[e] = keep ? -v : 0.f;
   }
   for (size_t e = tid; e < n_x0; e += stride) x0[e] = 0.f;
 }

@@ -8,7 +8,7 @@ import torch
 
 from .box_ddp import BoxDDP
 from .pendulum import PendulumDx
-from .util import QuadCost
+from .util import TiledQuadCost
 
 
 class IL_Env:
@@ -26,6 +26,8 @@ class IL_Env:
     # the pickle of env_dx/make_dataset.py holds numpy arrays; keep that format (and no device handles) on disk
     def __getstate__(self):
         st = dict(self.__dict__)
+        st.pop("_solvers", None)
+        st.pop("last_solver", None)
         for k in ("train_data", "val_data", "test_data"):
             if isinstance(st[k], torch.Tensor):
                 st[k] = st[k].detach().cpu().numpy().astype(np.float64)
@@ -74,20 +76,28 @@ class IL_Env:
         n_batch = xinit.shape[0]
         Q = Q.to(device=self.device, dtype=self.dtype)
         p = p.to(device=self.device, dtype=self.dtype)
-        Qt = Q[None, None].expand(self.mpc_T, n_batch, -1, -1).contiguous()          # il_env.py:119-129
-        pt = p[None, None].expand(self.mpc_T, n_batch, -1).contiguous()
-        assert Qt.dim() == 4 and pt.dim() == 3
+        cost = TiledQuadCost(Q, p, self.mpc_T, n_batch)     # Q, p repeated to [T,B,ns,ns], [T,B,ns] (il_env.py:119-129)
+        assert cost.C.dim() == 4 and cost.c.dim() == 3
         if u_init is not None:
             u_init = torch.as_tensor(u_init, dtype=self.dtype, device=self.device)
-        solver = BoxDDP(T=self.mpc_T, u_lower=self.true_dx.lower, u_upper=self.true_dx.upper, n_batch=n_batch,
-                        n_state=self.true_dx.n_state, n_ctrl=self.true_dx.n_ctrl, u_init=u_init,
-                        eps=eps_override if eps_override else self.true_dx.mpc_eps,
-                        max_iter=lqr_iter_override if lqr_iter_override else self.lqr_iter, verbose=False,
-                        exit_unconverged=False, detach_unconverged=True,
-                        line_search_decay=self.true_dx.linesearch_decay,
-                        max_line_search_iter=self.true_dx.max_linesearch_iter, update_dynamics=update_dynamics,
-                        quiet=self.quiet)
-        x_mpc, u_mpc, _ = solver((xinit, QuadCost(Qt, pt), dx))
+        # the reference builds a BoxDDP per call (il_env.py:131-156); the solver object holds nothing of a solve but its
+        # status, so one per configuration is kept (a torch Module costs ~0.1 ms to construct - a seventh of a step)
+        key = (n_batch, eps_override if eps_override else self.true_dx.mpc_eps,
+               lqr_iter_override if lqr_iter_override else self.lqr_iter, bool(update_dynamics), self.quiet, str(self.device))
+        solver = self._solvers.get(key) if hasattr(self, "_solvers") else None
+        if solver is None:
+            solver = BoxDDP(T=self.mpc_T, u_lower=self.true_dx.lower, u_upper=self.true_dx.upper, n_batch=n_batch,
+                            n_state=self.true_dx.n_state, n_ctrl=self.true_dx.n_ctrl, u_init=None, eps=key[1],
+                            max_iter=key[2], verbose=False, exit_unconverged=False, detach_unconverged=True,
+                            line_search_decay=self.true_dx.linesearch_decay,
+                            max_line_search_iter=self.true_dx.max_linesearch_iter, update_dynamics=update_dynamics,
+                            quiet=self.quiet, lazy_status=self.quiet)   # (quiet: nothing to print, nothing to wait for)
+            if not hasattr(self, "_solvers"):
+                self._solvers = {}
+            self._solvers[key] = solver
+        solver.u_init = u_init
+        self.last_solver = solver
+        x_mpc, u_mpc, _ = solver((xinit, cost, dx))
         return x_mpc, u_mpc
 
     def mpc(self, dx, xinit, q, p, u_init=None, eps_override=None, lqr_iter_override=None, update_dynamics=False):

@@ -75,6 +75,64 @@ class _MPCstepFn(torch.autograd.Function):
         return tuple(out) + (None,)
 
 
+def tiled_cost_gradient(T, B, nx, nu, dev, r, lo, hi, gx, gu, detach=None):
+    """`MPCstep.backward` (mpc_step.py:330-460) for a cost that is one (Q, p) tiled over time and batch: -> (dx_init [B,nx],
+    sum_{t,b} dC [ns,ns], sum_{t,b} dc [ns]), the sums formed inside the co-state kernel; dF, df are not formed.
+    r: retained float32 device tensors C, c, F, x, u; detach = (du_norm_last [B], flag int32[1], eps) gates the incoming
+    gradient per trajectory on the device (BoxDDP's detach mask).  None where the C entry point does not serve the size."""
+    lib = _lib.load()
+    ns = nx + nu
+    out = torch.empty((B * nx + ns * ns + ns,), dtype=torch.float32, device=dev)      # one allocation
+    dx0, dQ, dp = out[:B * nx].view(B, nx), out[B * nx:B * nx + ns * ns].view(ns, ns), out[B * nx + ns * ns:]
+    need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
+    ws = _workspace(need, dev)
+    dn, dfl, de = (None, None, 0.0) if detach is None else (detach[0], detach[1], float(detach[2]))
+    with _lib.guard(dev):
+        rc = lib.dmpc_mpc_step_backward(T, B, nx, nu, _lib.ptr(r["C"]), _lib.ptr(r["c"]), _lib.ptr(r["F"]), _lib.ptr(r["x"]),
+                                        _lib.ptr(r["u"]), _lib.ptr(lo), _lib.ptr(hi), _lib.ptr(gx), _lib.ptr(gu),
+                                        _lib.ptr(dx0), None, None, None, None, _lib.ptr(dQ), _lib.ptr(dp), _lib.ptr(dn),
+                                        _lib.ptr(dfl), de, _lib.ptr(ws), need, None, _lib.stream_ptr(dev))
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    _lib.check(rc, "dmpc_mpc_step_backward")
+    return dx0, dQ, dp
+
+
+class _MPCstepTiledFn(torch.autograd.Function):
+    """The gradient node of `BoxDDP` for a `TiledQuadCost` (no-op forward, mpc/box_ddp.py:247-259): inputs are the
+    un-tiled (Q [ns,ns], p [ns]); backward returns the gradient summed over time and batch, as the backward of the tiling
+    would (`tiled_cost_gradient`); the linear model is a constant of this node (update_dynamics=False, :252-258).
+    `spec` = (T, B, nx, nu, device, lower, upper, detach)."""
+
+    @staticmethod
+    def forward(ctx, x_init, Q, p, spec, retained, x_best, u_best):
+        ctx.spec, ctx.retained = spec, retained
+        ctx.meta = (x_init.dtype, x_init.device, Q.dtype, Q.device)
+        ctx.need_x0 = x_init.requires_grad
+        return x_best.detach(), u_best.detach()
+
+    @staticmethod
+    def backward(ctx, dl_dx, dl_du):
+        T, B, nx, nu, dev, lo, hi, detach = ctx.spec
+        gx = None if dl_dx is None else _lib.f32c(dl_dx, dev)
+        gu = None if dl_du is None else _lib.f32c(dl_du, dev)
+        got = tiled_cost_gradient(T, B, nx, nu, dev, ctx.retained, lo, hi, gx, gu, detach)
+        if got is None:       # a ragged batch / a wide shape: the dense gradient, reduced here
+            node = MPCstep(controls=ctx.retained["u"], T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu,
+                           current_states=ctx.retained["x"], true_cost=None, true_dynamics=None, ls_decay=0.2, max_ls_iter=1,
+                           no_op_forward=True)
+            if detach is not None:
+                keep = ((detach[1] == 0) | (detach[0] < detach[2])).to(torch.float32)[None, :, None]
+                gx = None if gx is None else gx * keep
+                gu = None if gu is None else gu * keep
+            full = node.backward((0, 1, 2), (gx, gu), retained=dict(ctx.retained, f=None))
+            got = (full[0], full[1].sum(dim=(0, 1)), full[2].sum(dim=(0, 1)))
+        dx0, dQ, dp = got
+        xd, xdev, qd, qdev = ctx.meta
+        return (dx0.to(device=xdev, dtype=xd) if ctx.need_x0 else None, dQ.to(device=qdev, dtype=qd),
+                dp.to(device=qdev, dtype=qd), None, None, None, None)
+
+
 class MPCstep:
     """MPC forward backward calculation (mpc/mpc_step.py:33)."""
 
@@ -384,7 +442,7 @@ class MPCstep:
             rc = lib.dmpc_mpc_step_backward(T, B, nx, nu, _lib.ptr(r["C"]), _lib.ptr(r["c"]), _lib.ptr(r["F"]),
                                             _lib.ptr(r["x"]), _lib.ptr(r["u"]), _lib.ptr(self._lo), _lib.ptr(self._hi),
                                             _lib.ptr(gx), _lib.ptr(gu), _lib.ptr(dx0), _lib.ptr(dC), _lib.ptr(dc),
-                                            _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need, _lib.ptr(info),
-                                            _lib.stream_ptr(d))
+                                            _lib.ptr(dF), _lib.ptr(df), None, None, None, None, 0.0, _lib.ptr(ws), need,
+                                            _lib.ptr(info), _lib.stream_ptr(d))
         _lib.check(rc, "dmpc_mpc_step_backward")
         return tuple(None if g is None else self._out(g) for g in (dx0, dC, dc, dF, df))

@@ -16,6 +16,21 @@ QuadCost = namedtuple("QuadCost", "C c", defaults=(None, None))
 LinDx = namedtuple("LinDx", "F f", defaults=(None, None))
 
 
+class TiledQuadCost(QuadCost):
+    """A `QuadCost` that is ONE (Q [ns,ns], p [ns]) tiled over time and batch - the imitation loop's learnable cost
+    (env_dx/il_env.py:119-129 repeats Q and p to [T,B,ns,ns], [T,B,ns]).  `.C` / `.c` are those dense tensors (what the
+    kernels read; constants of the graph), `.Q` / `.p` the tensors a gradient flows to: `BoxDDP` then asks
+    `MPCstep.backward` for the gradient already summed over time and batch (formed in the co-state kernel) instead of
+    letting autograd reduce dC [T,B,ns,ns] and dc [T,B,ns] afterwards.  Everything that takes a `QuadCost` takes it."""
+
+    def __new__(cls, Q, p, T, n_batch):
+        C = Q.detach()[None, None].expand(T, n_batch, -1, -1).contiguous()
+        c = p.detach()[None, None].expand(T, n_batch, -1).contiguous()
+        self = super().__new__(cls, C, c)
+        self.Q, self.p = Q, p
+        return self
+
+
 def bmv(a, x):
     assert a.shape[0] == x.shape[0], "batch mismatch"
     assert a.shape[2] == x.shape[1], "mat mul dim mismatch"

@@ -250,12 +250,21 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
 
 /* backward(): active-set LQR on (-d_tau) + co-state sweeps + outer products (mpc_step.py:330-460).
  *   outputs carry the reference's signs: dC = -1/2(dtau'(x)tau + tau(x)dtau'), dc = -dtau',
- *   dF = -(dlam(x)tau + lam(x)dtau'), df = -dlam[1:] (NULL to skip), dx_init = -dlam[0].  */
+ *   dF = -(dlam(x)tau + lam(x)dtau'), df = -dlam[1:] (NULL to skip), dx_init = -dlam[0]; dC, dF may be NULL.
+ *   dC_sum [ns,ns], dc_sum [ns] (both or neither): sum over t and b of dC, dc - the gradient of a cost that is ONE (C, c)
+ *   tiled over time and batch (env_dx/il_env.py:119-129, the imitation loop's learnable cost), formed in the kernel
+ *   instead of by a reduction of [T,B,ns,ns] afterwards; dc may then be NULL too.  DMPC_E_UNSUPPORTED (nothing launched)
+ *   unless B % 4 == 0 and the shape has a 16-lane specialisation.
+ *   detach_norm [B] (or NULL), detach_flag (device int, or NULL = set), detach_eps: BoxDDP's detach mask for samples that
+ *   did not reach a fixed point (mpc/box_ddp.py:263-289), applied to the incoming gradient on the device: if *detach_flag
+ *   != 0, trajectories with detach_norm[b] >= detach_eps get grad_x = grad_u = 0 (dmpc_box_ddp's du_norm_last and
+ *   state[7] are these two arrays: no read-back between the solve and its gradient). */
 int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
                            const float *F_hat, const float *x, const float *u, const float *u_lower,
                            const float *u_upper, const float *grad_x, const float *grad_u, float *d_x_init,
-                           float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes,
-                           int32_t *info, dmpc_stream_t stream);
+                           float *dC, float *dc, float *dF, float *df, float *dC_sum, float *dc_sum,
+                           const float *detach_norm, const int32_t *detach_flag, float detach_eps, void *ws,
+                           size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
 
 #ifdef __cplusplus
 }

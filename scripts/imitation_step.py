@@ -5,14 +5,16 @@ controls of an expert that knows the true cost.  Prints the wall time of forward
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from chainer_differentiable_mpc_amd import BoxDDP, PendulumDx, QuadCost
+from chainer_differentiable_mpc_amd import BoxDDP, PendulumDx, QuadCost, TiledQuadCost
 from chainer_differentiable_mpc_amd.pendulum import sample_xinit
 
 
 def tile_cost(q, p, T, B):
-    Q = torch.diag(q)[None, None].expand(T, B, -1, -1).contiguous()
-    pv = p[None, None].expand(T, B, -1).contiguous()
-    return QuadCost(Q, pv)
+    if os.environ.get("DMPC_NO_TILED") == "1":      # A/B: the dense cost, autograd reduces dC [T,B,4,4] to the parameters
+        Q = torch.diag(q)[None, None].expand(T, B, -1, -1).contiguous()
+        pv = p[None, None].expand(T, B, -1).contiguous()
+        return QuadCost(Q, pv)
+    return TiledQuadCost(torch.diag(q), p, T, B)    # what IL_Env.mpc builds (il_env.py:119-129)
 
 
 def imitation_step(B=1024, T=20, max_iter=10, seed=0, quiet=True):

@@ -104,6 +104,117 @@ def test_clamp_derivative_flag_reaches_the_kernels():
     assert np.abs(outs[True] - outs[False]).max() > 1e-3      # the convention is live in the fused loop
 
 
+@pytest.mark.parametrize("B", [16, 1024, 6])
+def test_tiled_cost_gradient_is_the_reduced_dense_gradient(B):
+    """`TiledQuadCost` (one (Q, p) repeated over time and batch, env_dx/il_env.py:119-129): BoxDDP's gradient node returns
+    d Q, d p summed inside the co-state kernel (`dmpc_mpc_step_backward(..., dC_sum, dc_sum)`); the dense `QuadCost` of the
+    same numbers lets autograd reduce dC [T,B,4,4], dc [T,B,4] (MPCstep.backward, mpc_step.py:383-390) - same solution
+    bit for bit, same parameter gradients to summation rounding.  B = 6 is not a whole number of wavefronts: the C entry
+    point declines (DMPC_E_UNSUPPORTED) and the Python layer reduces the dense gradient itself."""
+    from chainer_differentiable_mpc_amd import TiledQuadCost
+    T = 20
+    dx = PendulumDx()
+    x0 = dev(sample_xinit_np(B, seed=5))
+    u_exp = dev(np.random.RandomState(6).uniform(-2, 2, size=(T, B, 1)))
+    kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter,
+              max_iter=6, exit_unconverged=False, quiet=True, update_dynamics=False)
+    res = {}
+    for tiled in (True, False):
+        logit = torch.tensor([0.3, -0.2, 0.1, -1.0], device="cuda", requires_grad=True)
+        learn_p = torch.tensor([-0.4, 0.1, 0.05, 0.02], device="cuda", requires_grad=True)
+        q = torch.sigmoid(logit)
+        p = torch.sqrt(q) * learn_p
+        if tiled:
+            cost = TiledQuadCost(torch.diag(q), p, T, B)
+        else:
+            cost = QuadCost(torch.diag(q)[None, None].expand(T, B, -1, -1).contiguous(),
+                            p[None, None].expand(T, B, -1).contiguous())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, _ = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, **kw)((x0, cost, dx))
+        loss = ((u - u_exp) ** 2).mean() + 0.1 * (x ** 2).mean()
+        loss.backward()
+        res[tiled] = (npy(u), npy(logit.grad), npy(learn_p.grad))
+    assert np.array_equal(res[True][0], res[False][0])
+    assert np.abs(res[False][1]).max() > 1e-6
+    assert_close(res[True][1], res[False][1], 2e-5, "d logit: summed in the kernel vs reduced by autograd")
+    assert_close(res[True][2], res[False][2], 2e-5, "d learn_p")
+
+
+def test_training_update_pipelined_and_graph_replayed_equal_the_synchronous_one():
+    """IL_Env(quiet=True) defers the device loop's read-back (`BoxDDP(lazy_status=True)`): the update needs no host
+    decision - solution, gradient node and its detach mask all read device flags - so it can run ahead of the GPU and be
+    captured in a hipGraph.  Three RMSprop updates (il_exp.py:213-302) run (a) synchronously with an eager status read
+    after every solve, (b) back to back without synchronisation, (c) as a captured graph replayed three times give the
+    same parameters; the deferred status / warning arrive with the first access."""
+    B, T = 64, 20
+    dx = PendulumDx()
+    np.random.seed(3)
+    xi = dev(IL_Env.sample_xinit(B))
+
+    def make():
+        env = IL_Env("pendulum", lqr_iter=6, mpc_T=T, device="cuda")
+        net = Pendulum_Net_cost_logit(4, device="cuda")
+        with torch.no_grad():
+            net.learn_q_logit.copy_(torch.tensor([0.2, -0.1, 0.0, -2.0], device="cuda"))
+            net.learn_p.copy_(torch.tensor([-0.5, 0.1, 0.02, 0.01], device="cuda"))
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-2, alpha=0.5, capturable=True)
+        return env, net, opt
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env0, _, _ = make()
+        with torch.no_grad():
+            q_true, p_true = dx.get_true_obj()
+            _, u_exp = env0.mpc(env0.true_dx, xi, q_true, p_true)
+
+        def update(env, net, opt):
+            opt.zero_grad(set_to_none=True)
+            _, u_pred = net(xi, env)
+            loss = ((u_pred - u_exp) ** 2).mean()
+            loss.backward()
+            opt.step()
+            return loss
+
+        results = {}
+        env, net, opt = make()
+        for _ in range(3):
+            update(env, net, opt)
+            assert env.last_solver.status in ("Converged", "Not improved lim", "Not Converged")    # reads back: a sync
+            torch.cuda.synchronize()
+        results["sync"] = [npy(p_) for p_ in net.parameters()]
+        env, net, opt = make()
+        for _ in range(3):
+            update(env, net, opt)
+        assert env.last_solver._pending is not None          # nothing has been read back yet ...
+        st = env.last_solver.status                          # ... until somebody asks
+        assert env.last_solver._pending is None and st in ("Converged", "Not improved lim", "Not Converged")
+        results["pipelined"] = [npy(p_) for p_ in net.parameters()]
+        env, net, opt = make()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm-up on a side stream (allocations, library load), then rewind the state
+            update(env, net, opt)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        env2, net2, opt2 = make()
+        with torch.no_grad():
+            for a_, b_ in zip(net.parameters(), net2.parameters()):
+                a_.copy_(b_)
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-2, alpha=0.5, capturable=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            update(env, net, opt)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        results["graph"] = [npy(p_) for p_ in net.parameters()]
+    for k in ("pipelined", "graph"):
+        for a_, b_ in zip(results["sync"], results[k]):
+            assert_close(b_, a_, 1e-5, "parameters after three updates, %s vs synchronous" % k)
+    assert np.abs(results["sync"][0] - np.array([0.2, -0.1, 0.0, -2.0])).max() > 1e-3        # the updates moved them
+
+
 def sample_xinit_np(B, seed=3):
     from chainer_differentiable_mpc_amd.pendulum import sample_xinit
     return sample_xinit(B, seed=seed).astype(np.float32)
