@@ -198,10 +198,13 @@ def test_training_update_pipelined_and_graph_replayed_equal_the_synchronous_one(
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         env2, net2, opt2 = make()
-        with torch.no_grad():
-            for a_, b_ in zip(net.parameters(), net2.parameters()):
+        with torch.no_grad():               # (the optimiser keeps its state tensors: created inside a capture they would be
+            for a_, b_ in zip(net.parameters(), net2.parameters()):      # re-initialised by every replay)
                 a_.copy_(b_)
-        opt = torch.optim.RMSprop(net.parameters(), lr=1e-2, alpha=0.5, capturable=True)
+            for st_ in opt.state.values():
+                for v_ in st_.values():
+                    if isinstance(v_, torch.Tensor):
+                        v_.zero_()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             update(env, net, opt)
