@@ -32,6 +32,33 @@ with warnings.catch_warnings():
         opt.step()
         return loss
 
+    # warm-up on a side stream first (what a later graph capture asks for: allocations, library load, optimiser state)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            train_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    replay = None
+    try:                           # (c) the update captured once in a hipGraph and replayed - first: a capture_end of this
+    # update after the phase-by-phase runs below (their last autograd graph still alive) has crashed inside the HIP runtime
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = train_step()
+        rp = []
+        for rep in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                graph.replay()
+            torch.cuda.synchronize()
+            rp.append((time.perf_counter() - t0) / 20)
+        replay = float(np.median(rp)) * 1e3
+    except Exception as e:  # pragma: no cover
+        replay = "capture failed: %r" % (e,)
     fw, bw = [], []
     for it in range(3 + 15):       # (a) phase by phase, each ended by a device synchronisation
         opt.zero_grad(set_to_none=True)
@@ -57,30 +84,6 @@ with warnings.catch_warnings():
             train_step()
         torch.cuda.synchronize()
         pipe.append((time.perf_counter() - t0) / 20)
-    replay = None
-    try:                           # (c) the same update captured once in a hipGraph and replayed
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                train_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            train_step()
-        rp = []
-        for rep in range(5):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                graph.replay()
-            torch.cuda.synchronize()
-            rp.append((time.perf_counter() - t0) / 20)
-        replay = float(np.median(rp)) * 1e3
-    except Exception as e:  # pragma: no cover
-        replay = "capture failed: %r" % (e,)
 out["config4_imitation_step"] = {
     "what": "one imitation-learning update at config 4 (B=1024, T=20, 10 iLQR iterations, env_dx/il_env.py:104-158, "
             "il_exp.py:213-302): forward with the gradient node, loss on the expert's controls, backward to d logit / "
