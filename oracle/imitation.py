@@ -58,3 +58,29 @@ def imitation_grads(logit, learn_p, xinit, expert_u, T, lqr_iter, u_init=None, b
     loss, dC, dc = gradient_node(x, u, Q, pv, expert_u, keep)
     g_logit, g_p = param_grads(dC, dc, logit, learn_p)
     return dict(nom_x=x, nom_u=u, loss=loss, g_logit=g_logit, g_p=g_p, status=status, dC=dC, dc=dc)
+
+
+def imitation_loop(logit, learn_p, xinit, expert_u, T, lqr_iter, K, lr=1e-2, alpha=0.5, eps=1e-8):
+    """K consecutive updates of config 4's loop (env_dx/il_exp.py:213-302) with the evaluation pass of :97-181 after each:
+    the training solve starts cold (the loop passes `train_warm_start`, :248, a buffer it never writes - it fills the
+    differently spelled `train_warmstart`, :257); only learn_p moves while `cost_update_q` is False (:227,268-281);
+    RMSprop(lr, alpha): ms <- alpha ms + (1 - alpha) g^2, p <- p - lr g / (sqrt(ms) + eps) (chainer.optimizers.RMSprop,
+    :213); the evaluation solve is warm-started from the previous pass's prediction (`warmstart[idxs] = pred_u`, :122-124)."""
+    B = xinit.shape[0]
+    learn_p = np.array(learn_p, dtype=np.float64)
+    ms = np.zeros_like(learn_p)
+    warm = np.zeros((T, B, 1))
+    hist = []
+    for _ in range(K):
+        r = imitation_grads(logit, learn_p, xinit, expert_u, T, lqr_iter, u_init=None)
+        ms = alpha * ms + (1.0 - alpha) * r["g_p"] ** 2
+        learn_p = learn_p - lr * r["g_p"] / (np.sqrt(ms) + eps)
+        q, p = cost_from_params(logit, learn_p)
+        Q, pv = tile_cost(q, p, T, B)
+        _, pred_u, *_ = obox.box_ddp(xinit, ompc.QuadCost(Q, pv), obox.pendulum_step, T, LOWER, UPPER, 3, 1, u_init=warm,
+                                     eps=MPC_EPS, line_search_decay=LS_DECAY, max_line_search_iter=MAX_LS_ITER,
+                                     max_iter=lqr_iter, linearize=obox.pendulum_linearize, batch_coupled=True)
+        warm = pred_u
+        hist.append(dict(loss=r["loss"], g_logit=r["g_logit"], g_p=r["g_p"], nom_u=r["nom_u"], learn_p=learn_p.copy(),
+                         eval_u=pred_u, eval_loss=float(np.mean((expert_u - pred_u) ** 2))))
+    return hist

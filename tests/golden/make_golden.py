@@ -24,6 +24,7 @@ Files written:
   pendulum_boxddp.npz                  BoxDDP around the non-linear PendulumDx (config 2 family): iterates after 1..4 steps
   imitation_16.npz                     config 4 chain, small: Pendulum_Net_cost_logit -> IL_Env.mpc -> loss -> d logit, d p
   imitation_step_1024.npz              config 4 at B=1024, T=20: one MPCstep from a common iterate + the no-op gradient node
+  imitation_loop_16.npz                config 4's loop: three RMSprop updates with the evaluation pass's warm-start carry-over
   pnqp_n8_b256.npz                     PNQP n=8, B=256: the batch whose rows fork under the batch-global termination
 """
 import io
@@ -464,6 +465,66 @@ def gen_imitation(ref):
         float(arr(loss)), float((np.abs(arr(u1)) == 2.0).mean()), arr(g_logit), arr(g_p), fo.mean_alphas))
 
 
+def gen_imitation_loop(ref):
+    """config 4's LOOP (env_dx/il_exp.py:213-302 and the evaluation pass :97-181), B=16, T=20, 10 iLQR iterations: K = 3
+    consecutive updates with the reference's own pieces - Pendulum_Net_cost_logit.forward -> IL_Env.mpc, the loss of
+    :254-255, chainer.grad - and what the loop does around them:
+      * the training call passes `train_warm_start[idxs]` (:248; zeros - the buffer the loop fills is the differently
+        spelled `train_warmstart`, :257), so every training solve starts cold;
+      * `cost_update_q` starts False (:227,268-281): only learn_p moves during the first ten epochs;
+      * opt = RMSprop(lr=1e-2, alpha=0.5) (:213): ms <- alpha ms + (1 - alpha) g^2, p <- p - lr g / (sqrt(ms) + 1e-8)
+        (chainer.optimizers.RMSprop's rule with its default eps; the optimiser class itself is not part of the stand-in);
+      * after each update an evaluation pass as dataset_loss (:97-181): the solve is warm-started from the controls the
+        PREVIOUS pass predicted (`warmstart[idxs] = pred_u`, :122-124), no gradient.
+    Stored per update k: loss, both gradients, learn_p after the update, the nominal controls; per evaluation pass: loss
+    and the predicted controls (the next pass's warm start)."""
+    import importlib
+    ch = ref.chainer
+    V, F = ch.Variable, ch.functions
+    pnet = importlib.import_module("pendulum_net")
+    B, T, K = 16, 20, 3
+    env = ref.il_env.IL_Env('pendulum', lqr_iter=10, mpc_T=T)
+    np.random.seed(11)
+    xinit = _f32(env.sample_xinit(B))
+    tq, tp = env.true_dx.get_true_obj()
+    out = dict(B=B, T=T, K=K, lqr_iter=10, xinit=xinit, lr=1e-2, alpha=0.5, eps=1e-8)
+    buf = io.StringIO()
+    with warnings.catch_warnings(), redirect_stdout(buf):
+        warnings.simplefilter("ignore")
+        ex, eu = env.mpc(env.true_dx, xinit, tq, tp, update_dynamics=True)
+        us = np.transpose(arr(eu), (1, 0, 2))                       # expert controls, [B,T,1] as the data set holds them
+        net = pnet.Pendulum_Net_cost_logit(4)
+        net.learn_q_logit.array[:] = np.array([0.5, -0.25, -1.0, -3.0])
+        net.learn_p.array[:] = np.array([-0.75, 0.125, 0.0625, 0.0])
+        out["q_logit0"], out["learn_p0"] = net.learn_q_logit.array.copy(), net.learn_p.array.copy()
+        ms = np.zeros(4)
+        train_warm_start = np.zeros((B, T, 1))                      # (:215; never written - see above)
+        eval_warmstart = np.zeros((B, T, 1))                        # (:224)
+        for k in range(K):
+            nom_x, nom_u = net(xinit, env, train_warm_start)
+            nu_ = F.transpose(nom_u, axes=(1, 0, 2))
+            loss = F.mean((us - nu_) * (us - nu_))                  # :254-255
+            g_logit, g_p = ch.grad([loss], [net.learn_q_logit, net.learn_p])
+            g = arr(g_p)
+            ms = 0.5 * ms + 0.5 * g * g
+            net.learn_p.array[:] = net.learn_p.array - 1e-2 * g / (np.sqrt(ms) + 1e-8)
+            out["loss_%d" % k], out["g_logit_%d" % k], out["g_p_%d" % k] = arr(loss), arr(g_logit), g
+            out["nom_u_%d" % k], out["learn_p_%d" % k] = arr(nom_u), net.learn_p.array.copy()
+            # evaluation pass (dataset_loss): warm start = the previous pass's prediction
+            q = F.sigmoid(net.learn_q_logit)
+            pp = F.sqrt(q) * net.learn_p
+            _, pred_u = env.mpc(env.true_dx, xinit, q, pp, u_init=np.transpose(eval_warmstart, (1, 0, 2)))
+            pred = np.transpose(arr(pred_u), (1, 0, 2))
+            eval_warmstart[:] = pred
+            out["eval_u_%d" % k] = arr(pred_u)
+            out["eval_loss_%d" % k] = np.mean((us - pred) * (us - pred))
+    out["expert_u"] = arr(eu)
+    np.savez_compressed(os.path.join(HERE, "imitation_loop_16.npz"), **out)
+    print("wrote imitation_loop_16.npz losses %s eval %s learn_p %s" % (
+        [float(out["loss_%d" % k]) for k in range(K)], [float(out["eval_loss_%d" % k]) for k in range(K)],
+        out["learn_p_%d" % (K - 1)]))
+
+
 def gen_pnqp_fork(ref):
     """PNQP n=8, B=256: batch-global convergence / Armijo tests make rows fork from their batch-of-one
     answers.  Batched run recorded in full; per-row answers for comparison."""
@@ -501,6 +562,7 @@ def main():
     gen_approx_cost(ref)
     gen_pendulum_boxddp(ref)
     gen_imitation(ref)
+    gen_imitation_loop(ref)
     gen_pnqp_fork(ref)
 
 

@@ -323,6 +323,25 @@ def test_oracle_imitation_chain_matches_the_reference():
     assert np.abs(g["g_logit"]).max() > 1e-4
 
 
+def test_oracle_imitation_loop_matches_the_reference():
+    """config 4's loop: three RMSprop updates of learn_p with the evaluation pass's warm-start carry-over after each
+    (env_dx/il_exp.py:213-302, :97-181), recorded from the reference's own pieces (tests/golden/make_golden.py)"""
+    from oracle import imitation as oim
+    g = load("imitation_loop_16.npz")
+    hist = oim.imitation_loop(g["q_logit0"], g["learn_p0"], g["xinit"], g["expert_u"], int(g["T"]), int(g["lqr_iter"]),
+                              int(g["K"]), float(g["lr"]), float(g["alpha"]), float(g["eps"]))
+    for k, h in enumerate(hist):
+        np.testing.assert_allclose(h["loss"], float(g["loss_%d" % k]), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(h["g_p"], g["g_p_%d" % k], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(h["g_logit"], g["g_logit_%d" % k], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(h["learn_p"], g["learn_p_%d" % k], rtol=0, atol=1e-10)
+        # (controls: the reference's float32-rounded box-QP solves, util.py:522-527, leave 1e-7 between two float64 runs
+        # whose parameters differ in the twelfth digit)
+        np.testing.assert_allclose(h["nom_u"], g["nom_u_%d" % k], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(h["eval_u"], g["eval_u_%d" % k], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(h["eval_loss"], float(g["eval_loss_%d" % k]), rtol=0, atol=1e-12)
+
+
 def test_oracle_imitation_step_b1024_matches_the_reference():
     """config 4 at full size (B=1024, T=20): one MPCstep from a common iterate + the gradient node"""
     from oracle import box_ddp as obox
