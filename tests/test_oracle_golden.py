@@ -331,7 +331,7 @@ def test_oracle_imitation_loop_matches_the_reference():
     hist = oim.imitation_loop(g["q_logit0"], g["learn_p0"], g["xinit"], g["expert_u"], int(g["T"]), int(g["lqr_iter"]),
                               int(g["K"]), float(g["lr"]), float(g["alpha"]), float(g["eps"]))
     for k, h in enumerate(hist):
-        tol = 1e-12 if k == 0 else 1e-8      # (later updates inherit the 1e-7 of the float32-rounded solves, below)
+        tol = 1e-12 if k == 0 else 1e-6      # (later updates inherit the 1e-7 of the float32-rounded solves, below)
         np.testing.assert_allclose(h["loss"], float(g["loss_%d" % k]), rtol=0, atol=tol)
         np.testing.assert_allclose(h["g_p"], g["g_p_%d" % k], rtol=0, atol=tol)
         np.testing.assert_allclose(h["g_logit"], g["g_logit_%d" % k], rtol=0, atol=tol)
