@@ -48,11 +48,16 @@ __device__ __forceinline__ f4v mfma_bcast(float a, float b, f4v c) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_rsrc(const void *base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);
 }
+// Cache policy knob of the sweep's loads of C and F (aux bit 1 = nt on gfx940+).  Measured (round 3, same box, B = 8192): nt
+// 2.34 ms against 1.88 ms - the row loads (164 B every 160 B) share cache lines that nt gives up.  Off.
+#ifndef DMPC_WAVE_NT
+#define DMPC_WAVE_NT 0
+#endif
 template <int BYTE_OFF>
 __device__ __forceinline__ float wave_load(__amdgpu_buffer_rsrc_t r, int voff) {
   // the immediate of a buffer load holds 12 bits: rows further down go through the scalar offset
   constexpr int kImm = BYTE_OFF % 4096, kS = BYTE_OFF - kImm;
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + kImm, kS, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + kImm, kS, DMPC_WAVE_NT ? 2 : 0));
 }
 
 constexpr int kOutOfRange = 0x40000000;
@@ -92,7 +97,7 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
     if (t < T - 1) {
       const __amdgpu_buffer_rsrc_t rF = wave_rsrc(a.F + tb * NX * NS, NX * NS * 4);
 #pragma unroll
-      for (int q = 0; q < TS; ++q) wf[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, voff_f + 16 * q, 0, 0);
+      for (int q = 0; q < TS; ++q) wf[q] = __builtin_amdgcn_raw_buffer_load_b128(rF, voff_f + 16 * q, 0, DMPC_WAVE_NT ? 2 : 0);
       if (has_f) aff |= __builtin_amdgcn_raw_buffer_load_b32(wave_rsrc(a.f + tb * NX, NX * 4), voff_f1, 0, 0);
     } else {
 #pragma unroll

@@ -12,7 +12,9 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 dev = torch.device("cuda")
-T, nx, nu = int(os.environ.get("T", "50")), 8, 2
+T, nx, nu = int(os.environ.get("T", "50")), int(os.environ.get("NX", "8")), int(os.environ.get("NU", "2"))
+ns = nx + nu
+BYTES_TS = 4 * (ns * ns + ns + nx * ns + 2 * nx + nu)      # algorithmic bytes per timestep-solve
 sizes = [int(v) for v in os.environ.get("SIZES", "4096 8192 32768").split()]
 vp = ctypes.c_void_p
 libs = []
@@ -26,9 +28,16 @@ for spec in sys.argv[1:]:
 stream = torch.cuda.current_stream().cuda_stream
 
 
+WS = {}
+
+
 def run(fn, d, x, u, B):
+    need = T * B * nu * (nx + 1) * 4          # dmpc_lqr_workspace_bytes: the wide shapes pass their gains through it
+    if B not in WS:
+        WS.clear()
+        WS[B] = torch.empty(need, dtype=torch.uint8, device=dev)
     rc = fn(T, B, nx, nu, d["C"].data_ptr(), d["c"].data_ptr(), d["F"].data_ptr(), d["f"].data_ptr(), d["x_init"].data_ptr(),
-            None, None, None, x.data_ptr(), u.data_ptr(), None, 0, None, stream)
+            None, None, None, x.data_ptr(), u.data_ptr(), WS[B].data_ptr(), need, None, stream)
     assert rc == 0, rc
 
 
@@ -47,7 +56,7 @@ def timeit(fn, sets, x, u, B, reps):
 
 
 for B in sizes:
-    in_bytes = 4 * B * T * (100 + 10 + 80 + 8)
+    in_bytes = 4 * B * T * (ns * ns + ns + nx * ns + nx)
     nset = max(2, -(-520 * 2 ** 20 // in_bytes)) if in_bytes < 300 * 2 ** 20 else 2   # rotation larger than 2 x the cache
     nset = int(os.environ.get("NSET", "0")) or nset
     sets = [bench.make_inputs(B, T, nx, nu, 10 + s, dev)[1] for s in range(nset)]
@@ -75,7 +84,7 @@ for B in sizes:
             res.append((tc, ts))
         tc = min(r[0] for r in res)
         ts = min(r[1] for r in res)
-        alg = 832 * B * T
+        alg = BYTES_TS * B * T
         print("B=%6d %-14s one set %7.2f us (%.3f)   %d sets in rotation %7.2f us (%.3f of 8 TB/s)   %s   [%s]"
               % (B, name, tc, alg / tc / 8e6, nset, ts, alg / ts / 8e6, same,
                  " ".join("%.1f/%.1f" % r for r in res)), flush=True)
