@@ -57,17 +57,6 @@ X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by 
 MFMA_USE = int(os.environ.get("GEN_MFMA_USE", "5"))     # wait states kept before a non-accumulating use of an MFMA result
 MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
 X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
-# A second form of the headline stream ((8,2), stash, no gains out): the backward sweep unrolled over the horizon (NSTASH
-# steps, one exit test each), so that the F block of a step goes to its accumulation registers by reads emitted in place -
-# the table of per-step stubs, called by s_setpc_b64 and left by s_branch, costs ~65 of a step's ~880 cycles.  75 KB of
-# straight-line code: 1-3 % faster than the loop when launched back to back, 4-5 us SLOWER per solve when other kernels
-# run in between (DiffLqr's forward + backward loop; scripts/unroll_ab.sh) - the launcher picks (api_util.hpp).
-# GEN_UNROLL_BWD=0: do not generate it.
-X_UNROLL_BWD = os.environ.get("GEN_UNROLL_BWD", "0") == "1"
-# Experiment: the prologue of the unrolled stream touches the stream's own code with 20 loads (64 lanes x one 64-byte
-# line each, clamped to the stream's end) so that the lines are in L2 before the fetcher asks for them.
-X_CODE_PREFETCH = os.environ.get("GEN_CODE_PREFETCH", "0") == "1"   # measured: makes both cases worse (+1.5 us); off
-N_CODE_PREFETCH = 20
 # Ring depth of the plain / saving / affine streams (the masked and MPC streams keep DB slots of whole 1 KB pieces: their
 # flags and bounds ride in the slot padding).  With more than DB slots the slot stride is the slot's own size (rounded up
 # to 64 B) and the last DMA of a group runs under an exec mask - whole pieces would not fit the 160 KB of a CU.
@@ -80,7 +69,7 @@ USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_
 
 
 class Layout:
-    def __init__(self, nx, nu, depth=DB):
+    def __init__(self, nx, nu, depth=DB, ghbm=False):
         self.nx, self.nu, self.ns = nx, nu, nx + nu
         self.depth = depth
         ns = self.ns
@@ -96,7 +85,11 @@ class Layout:
         # lanes of a group's last DMA that stay inside the slot (compact: the others would land in the next slot)
         self.last_lanes = (self.SLOT_B - (self.ndma_b - 1) * 1024) // 16
         self.FOFF_f = 16 * self.nF
-        self.nchunk_f = self.nF + self.nf
+        self.nG = nu * KROW // 4 * 1 if ghbm else 0      # ghbm: the wave's 4 trajectories x nu gain rows of KROW floats
+        assert (nu * KROW) % 4 == 0
+        self.nG = nu * KROW if ghbm else 0               # 16-byte chunks: 4 trajectories x nu x KROW floats / 4
+        self.FOFF_G = 16 * (self.nF + self.nf)
+        self.nchunk_f = self.nF + self.nf + self.nG
         self.ndma_f = (self.nchunk_f + 63) // 64
         self.SLOT_F = self.ndma_f * 1024
         # one ring size per shape, whatever the stream: RING_DEPTH compact slots or DB slots of whole pieces
@@ -246,7 +239,7 @@ def vrange(regs):
     return "v[%d:%d]" % (a, b)
 
 
-def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, unroll=False, save=False, affine=False, adj=False):
+def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, ghbm=False, save=False, affine=False, adj=False):
     """masked: LQR_active (mpc/active_constrained_lqr.py:110-137) - clamped controls get a zero right-hand side, Quu
     is zeroed outside free x free with 1e-8 on the clamped diagonal, so their gain rows come out exactly 0 (and the
     rollout needs no change); the value update keeps the unmasked blocks (:143-145).
@@ -267,6 +260,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     qu + Quu k = 0), then the same rollout.  The slot's C region carries [K_t | Qxu_t | Quu_t] instead of C_t (36
     chunks instead of 100 at (8,2); the other lanes of those groups fetch a resident zero chunk): 504 B per
     timestep-solve instead of 832 B, and ~60 instructions per step instead of ~165.
+    ghbm (ring form): the gain rows [K_m | 0 | k_m | pad] of every step go to a caller workspace in HBM ([T,B,nu,KROW] floats)
+    instead of LDS and come back to the rollout with F and f, through the forward ring - the horizon is then bounded by
+    nothing but the workspace (the LDS form holds T <= 74 at (8,2)).
     adj (affine only): DiffLqr.backward in ONE launch that never reads C (differentiable_lqr.py:78-142).  The reference's
     solve is exact block elimination of the KKT system, so its co-states are the value function's gradients:
     lambda_t = V_t x_t + v_t and d_lambda_t = V_t dx_t + v'_t (v' the affine value term of the second solve) for any, also
@@ -279,15 +275,14 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     takes x_t (4 nx more dwords) and every step starts with c_hat = C [x_t; u_t] + c in the affine column."""
     D = DB if (masked or mpc) else RING_DEPTH      # ring slots (the register sets stay three)
     kind = "mpc" if mpc else "masked" if masked else "save" if save else "adj" if adj else "affine" if affine else "plain"
-    L = Layout(nx, nu, D)
+    L = Layout(nx, nu, D, ghbm)
     ns, aff = L.ns, L.ns
     assert not stash or L.stash_ok
-    unroll_bwd = unroll
-    assert not unroll or (stash and not mpc)
+    assert not ghbm or not (stash or write_k or masked or mpc or save or affine)
     assert not mpc or (masked and write_k and not stash)
     assert not expand or (mpc and 12 * nu + 4 * nx <= 64)
-    assert not save or (write_k and not masked and not mpc and not unroll)
-    assert not affine or (stash and not write_k and not masked and not mpc and not unroll and not save and ns >= 4)
+    assert not save or (write_k and not masked and not mpc)
+    assert not affine or (stash and not write_k and not masked and not mpc and not save and ns >= 4)
     assert not adj or affine
     P = Prog()
     R = Regs(VBASE)
@@ -333,7 +328,6 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     NQP = R.take(1)[0] if mpc else None                       # sum over t of the QP passes run          (mpc_step.py:145)
     QINFO = R.take(1)[0] if mpc else None                     # 4 once a QP ran into the iteration cap
     TAU = R.take(3) if expand else None                       # expand: lane j < ns of set s holds [x_t; u_t][j]
-    PFD = R.take(1)[0] if unroll_bwd and X_CODE_PREFETCH else None   # destination of the code-prefetch loads (never read)
     Am = [R.take(nu) for _ in range(nu)] if masked else None   # masked Quu
     Rm = R.take(nu) if masked else None                        # masked right-hand side rows
     # forward sweep registers reuse the Q / F sets (the backward sweep is over by then)
@@ -360,6 +354,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     S_KM, S_SM, S_UM, S_XM, S_HI = "s[72:73]", "s[74:75]", "s[76:77]", "s[88:89]", "s[90:91]"
     S_RET, S_STUB, S_JMP, S_TMP = "s[78:79]", "s[80:81]", "s[82:83]", "s84"
     S_ROW0 = "s[98:99]"         # save: lane 0 of each 16-lane row
+    S_GM = "s[98:99]"           # ghbm: lanes 0..ns of each row (a whole gain row)
     S_AFF = "s[100:101]"        # mpc: the lanes `aff` (the stash pairs above are the QP's masks there - no stash in that mode)
 
     def mask64(lanes):
@@ -690,7 +685,12 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             for m in range(nu):
                 P.v("v_cndmask_b32_e64 %s, %s, %s, %s" % (Kt[m], Kt[m], XK[m], S_AFF), writes=(Kt[m],), reads=(Kt[m], XK[m]))
         # gain rows -> LDS (and HBM when the caller wants Ks/ks), still under the K mask
-        if not mpc:
+        if ghbm:     # ... -> the workspace, whole rows [K_m | 0 | k_m]: lanes nx..ns-1 of K~ are exactly 0, lane aff is column ns
+            P.uses(Kt)
+            P.raw("s_mov_b64 exec, " + S_GM)
+            for m in range(nu):
+                P.raw("global_store_dword %%[pgw], %s, off offset:%d" % (Kt[m], m * KROW * 4))
+        elif not mpc:
             for m in range(nu):
                 off = (" offset:%d" % (m * KROW * 4)) if m else ""
                 P.raw("ds_write_b32 %%[ak], %s%s" % (Kt[m], off))
@@ -719,7 +719,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         if write_k:
             for m in range(nu):
                 P.v("v_lshl_add_u64 %s, %s, 0, %%[dk]" % (pk[m], pk[m]))
-        if not mpc:
+        if ghbm:
+            P.v("v_lshl_add_u64 %[pgw], %[pgw], 0, %[dgw]")
+        elif not mpc:
             P.v("v_add_u32_e32 %%[ak], %d, %%[ak]" % ((-nu * KROW * 4) & 0xffffffff))
 
     def gains_affine(s, first):
@@ -817,7 +819,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 for i in range(nx):
                     P.fmac_dpp(Qs[i], Kt[m], Rr[m], i)
 
-    def bstep(step, first, extra_outstanding=0, stub_n=None):
+    def bstep(step, first, extra_outstanding=0):
         """step `step` of the sweep (0 is the peeled first step; the loop form passes its body position, the step modulo
         the loop length): register set step % 3, ring slot step % D"""
         s, slot, nslot = step % 3, step % D, (step + 1) % D
@@ -883,15 +885,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 st_allow = step * n_step_stores + min(n_extra, (D - 1 - step) * n_step_stores)
         vmwait((D - 1) * NDB_ALL + extra_outstanding + st_allow)
         read_set(n, nslot)
-        if stash and stub_n is not None:
-            # unrolled sweep: this step's stash registers are known here
-            for p_, (w, off) in enumerate(L.stash_pieces):
-                regs = stash_regs_of(p_, stub_n - 1)
-                if w == 2:
-                    P.raw("ds_read2_b32 a[%d:%d], %%[sr%d] offset0:%d offset1:%d" % (regs[0], regs[1], stub_n % D, off, off + 1))
-                else:
-                    P.raw("ds_read_b32 a%d, %%[sr%d] offset:%d" % (regs[0], stub_n % D, off * 4))
-        elif stash:
+        if stash:
             # F of the NEXT step goes from its ring slot into this step's stash registers: the register numbers
             # differ per step, so the two reads live in a table of stubs (one per step) that is called here
             lo = int(S_STUB[2:S_STUB.index(":")])
@@ -954,7 +948,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 P.v("v_lshl_add_u64 %%[pso%d], %%[pso%d], 0, %%[sso%d]" % (q, q, q))
 
     n_step_stores = 0      # global stores per backward step (not mpc)
-    if write_k:
+    if write_k or ghbm:
         n_step_stores += nu
     if save:
         n_step_stores += SV_NST
@@ -985,6 +979,10 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     for m in range(nu):
         P.v("v_mov_b32_e32 %s, 0" % Kt[m], writes=(Kt[m],))
     P.v("v_mov_b32_e32 %s, 0x7f7fffff" % MINPIV, writes=(MINPIV,))
+    if ghbm:
+        lo_g = int(S_GM[2:S_GM.index(":")])
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_g, mask64(range(ns + 1)) & 0xffffffff))
+        P.raw("s_mov_b32 s%d, 0x%x" % (lo_g + 1, mask64(range(ns + 1)) & 0xffffffff))
     if save:
         lo_r0 = int(S_ROW0[2:S_ROW0.index(":")])
         P.raw("s_mov_b32 s%d, 0x%x" % (lo_r0, mask64([0]) & 0xffffffff))
@@ -1033,23 +1031,9 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             P.raw("global_load_lds_dwordx4 %s, off" % fp[q])
     P.raw("global_load_dword %s, %%[pxi], off" % XV0)
     n_extra += 1
-    if PFD is not None:
-        P.raw("s_getpc_b64 " + S_JMP)            # (the forward sweep sets S_JMP up again for its own use)
-        P.label("Lpf_%=", reset=False)
-        P.v("v_mbcnt_lo_u32_b32 %s, -1, 0" % tP, writes=(tP,))
-        P.v("v_mbcnt_hi_u32_b32 %s, -1, %s" % (tP, tP), writes=(tP,), reads=(tP,))
-        P.v("v_lshlrev_b32_e32 %s, 6, %s" % (tP, tP), writes=(tP,), reads=(tP,))
-        for k in range(N_CODE_PREFETCH):
-            if k:
-                P.v("v_add_u32_e32 %s, 0x%x, %s" % (tPQ, k * 4096, tP), writes=(tPQ,), reads=(tP,))
-            else:
-                P.v("v_mov_b32_e32 %s, %s" % (tPQ, tP), writes=(tPQ,), reads=(tP,))
-            P.v("v_min_u32_e32 %s, Lcode_end_%%=-Lpf_%%=-4, %s" % (tPQ, tPQ), writes=(tPQ,), reads=(tPQ,))
-            P.raw("global_load_dword %s, %s, %s" % (PFD, tPQ, S_JMP))
-        n_extra += N_CODE_PREFETCH
     # zero this wave's gain rows while the first slots are in flight (columns nx..ns-1 and the pad of every row
     # are never written afterwards; the region is padded to whole 1 KB pieces by lqr_asm_kernel.hpp)
-    if not mpc:
+    if not mpc and not ghbm:
         for i in range(4):
             P.v("v_mov_b32_e32 %s, 0" % W[i], writes=(W[i],))
         P.raw("s_mov_b32 %s, %%[nz]" % S_TMP)
@@ -1077,17 +1061,11 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     P.raw("s_sub_i32 %s, %%[T], 2" % S_N)      # steps left after the first, minus one
     P.comment("---- t = T-1")
     stamp(1)
-    bstep(0, True, n_extra, stub_n=1 if unroll_bwd else None)
+    bstep(0, True, n_extra)
     if X_SKIP_BWD:
         P.raw("s_branch Lbwd_done_%=")
     in_loop[0] = True
-    if unroll_bwd:
-        for k in range(1, L.NSTASH):
-            P.comment("---- backward step %d, register set %d" % (k, k % 3))
-            bstep(k, False, stub_n=k + 1)
-            P.raw("s_sub_u32 %s, %s, 1" % (S_N, S_N))       # SCC = borrow: that was the last step
-            P.raw("s_cbranch_scc1 Lbwd_done_%=")
-    else:
+    if True:       # (one form of the sweep: the loop over lcm(register sets, ring slots) steps)
         P.label("Lbwd_%=")
         for k in range(1, LC + 1):       # steps k, k + LC, k + 2 LC, ... of the sweep
             P.comment("---- backward step, register set %d, ring slot %d" % (k % 3, k % D))
@@ -1166,10 +1144,29 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         P.raw("s_mov_b64 exec, -1")
         P.exec_written()
     if not stash:
-        P.raw("s_sub_i32 %s, %%[T], 2" % S_TF)
+        rare = []      # ghbm: out-of-line tails of the pointer steps
+
+        def advance_f():
+            """the forward DMA pointers go one timestep on.  ghbm: the gain rows have a slice T-1, F and f have not - the
+            last step moves the gain lanes alone (`fstrl`: their stride, 0 in the F / f lanes); it lives out of line, the
+            common path is the same four instructions"""
+            if not ghbm:
+                advance(fptr, fstr)
+                return
+            uniq[0] += 1
+            lab_r, lab_b = "Lfrare%d_%%=" % uniq[0], "Lfback%d_%%=" % uniq[0]
+            P.raw("s_cmp_gt_i32 %s, 1" % S_TF)
+            P.raw("s_cbranch_scc0 " + lab_r)
+            for p_, s_ in zip(fptr, fstr):
+                P.v("v_lshl_add_u64 %s, %s, 0, %s" % (p_, p_, s_))
+            P.raw("s_sub_i32 %s, %s, 1" % (S_TF, S_TF))
+            P.label(lab_b, reset=False)
+            rare.append((lab_r, lab_b))
+
+        P.raw("s_sub_i32 %s, %%[T], %d" % (S_TF, 1 if ghbm else 2))
         for j in range(DF):
             issue_group(fptr, j, L.SLOT_F)
-            advance(fptr, fstr)
+            advance_f()
         P.raw("s_waitcnt vmcnt(%d)" % ((DF - 1) * L.ndma_f))
         read_rows(0, 0)
         P.v("v_mov_b32_e32 %s, %s" % (ACC[2], XV0), writes=(ACC[2],))
@@ -1187,7 +1184,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             P.comment("---- forward step, slot %d" % j)
             P.raw("s_waitcnt lgkmcnt(0)")
             issue_group(fptr, j, L.SLOT_F)
-            advance(fptr, fstr)
+            advance_f()
             vmwait((DF - 1) * L.ndma_f)
             d = "2" if j == DF - 1 else ""
             P.v("v_add_u32_e32 %%[arow], %%[drow%s], %%[arow]" % d)
@@ -1212,6 +1209,14 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
             fcompute(c, a, ap, S_UM, True)
             P.v("v_mov_b32_e32 %%[xvout], %s" % ACC[a])
             P.raw("s_branch Ldone_%=")
+        for lab_r, lab_b in rare:       # (reached by their branches only)
+            P.label(lab_r, reset=False)
+            P.raw("s_cmp_eq_i32 %s, 1" % S_TF)
+            P.raw("s_cbranch_scc0 " + lab_b)
+            for q_, p_ in enumerate(fptr):
+                P.v("v_lshl_add_u64 %s, %s, 0, %%[fstrl%d]" % (p_, p_, q_))
+            P.raw("s_sub_i32 %s, %s, 1" % (S_TF, S_TF))
+            P.raw("s_branch " + lab_b)
     else:
         # F comes back from the stash registers through two staging buffers in the (now idle) ring: the code is
         # unrolled over n = T-1-t (the stash slot is a register NUMBER), entered at n = T-1 through a table of
@@ -1523,7 +1528,7 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
         # ---- backward stubs: F block of ring slot (n % 3) -> stash slot n-1
         P.lines.append(".p2align 5")
         P.label("Lbstub_%=")
-        for n in range(1, (0 if unroll_bwd else L.NSTASH) + 1):
+        for n in range(1, L.NSTASH + 1):
             P.lines.append(".p2align 5")
             for p, (w, off) in enumerate(L.stash_pieces):
                 regs = stash_regs_of(p, n - 1)
@@ -1541,8 +1546,6 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     stamp(3)
     for i in range(len(TS)):
         P.v("v_mov_b32_e32 %%[ts%d], %s" % (i, TS[i]))
-    if PFD is not None:
-        P.label("Lcode_end_%=", reset=False)
 
     # ---- operand lists
     outs = [("xvout", '"=&v"(xvout)'), ("minpiv", '"=&v"(minpiv)')]
@@ -1567,6 +1570,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if write_k:
         for m in range(nu):
             rw.append(("pk%d" % m, '"+v"(in.pk[%d])' % m))
+    if ghbm:
+        rw.append(("pgw", '"+v"(in.pgw)'))
     if masked:
         rw.append(("pm", '"+v"(in.pm)'))
     if save:
@@ -1604,6 +1609,10 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
                 ("dfshift", '"v"(in.dfshift)')]
     if write_k:
         ins.append(("dk", '"v"(in.dk)'))
+    if ghbm:
+        ins.append(("dgw", '"v"(in.dgw)'))
+        for q in range(L.ndma_f):
+            ins.append(("fstrl%d" % q, '"v"(in.fstrl[%d])' % q))
     if save:
         for q in range(SV_NST):
             ins.append(("sso%d" % q, '"v"(in.sso[%d])' % q))
@@ -1616,10 +1625,10 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     if expand:
         ins += [("atau", '"v"(in.atau)'), ("act", '"v"(in.act)')]
     clob = ['"v%d"' % i for i in range(VBASE, (255 if adj else last_vgpr) + 1)] + ['"a%d"' % i for i in range(n_agpr)] + \
-        ['"s%d"' % i for i in ([70] + list(range(72, 102 if (mpc or affine) else (100 if save else 98))))] + ['"vcc"', '"scc"', '"memory"']
+        ['"s%d"' % i for i in ([70] + list(range(72, 102 if (mpc or affine) else (100 if (save or ghbm) else 98))))] + ['"vcc"', '"scc"', '"memory"']
 
     tf = lambda b: "true" if b else "false"
-    name = "LqrAsm<%d, %d, %s, %s, %s, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(unroll), tf(save), tf(affine), tf(adj))
+    name = "LqrAsm<%d, %d, %s, %s, %s, %s, %s, %s, %s>" % (nx, nu, tf(write_k), tf(stash), tf(masked), tf(ghbm), tf(save), tf(affine), tf(adj))
     if mpc:
         name = "MpcAsm<%d, %d, %s>" % (nx, nu, tf(expand))
     o = []
@@ -1629,8 +1638,8 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, un
     o.append("  static constexpr bool kAvailable = true;\n")
     o.append("  static constexpr int NDB = %d, NDF = %d, SLOT_B = %d, SLOT_F = %d, RING_BYTES = %d, KROW = %d, DEPTH_F = %d, DEPTH_B = %d;\n"
              % (L.ndma_b, L.ndma_f, L.SLOT_B, L.SLOT_F, L.RING, KROW, DF, D))
-    o.append("  static constexpr int OFF_C = %d, OFF_c = %d, OFF_F = %d, OFF_f = %d, FOFF_f = %d;\n"
-             % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f))
+    o.append("  static constexpr int OFF_C = %d, OFF_c = %d, OFF_F = %d, OFF_f = %d, FOFF_f = %d, FOFF_G = %d;\n"
+             % (L.OFF_C, L.OFF_c, L.OFF_F, L.OFF_f, L.FOFF_f, L.FOFF_G))
     o.append("  static constexpr int NSTASH = %d, NFD = %d, FAREA_BYTES = %d, HROW = %d, SPD = %d, PADM = %d;\n"
              % (L.NSTASH, L.NFD, L.FAREA, L.H, L.SPD, 16 * L.nchunk_b))
     if adj:
@@ -1691,6 +1700,7 @@ struct LqrAsmIn {
   int bwd_only;                      // 1 = stop after the backward sweep (LqrRecursion.backward()); same in every lane
   float eaff;                        // 1 in lane `aff`, else 0
   uint64_t pk[NU], dk;               // Ks/ks store pointers (t = T-1) and their time stride (write_k)
+  uint64_t pgw, dgw;                 // ghbm: store pointer of column min(lane, ns) of gain row (T-1, 0) in the workspace, time stride
   // save: [Vv | Qxu | Quu] leave through a staging area (LDS byte addresses of: column min(lane, nx) of row 0 of this
   // trajectory's [V | v] - lane ns is column nx -, column lane - nx of row 0 of Qxu, Quu) as 16-byte chunks: pso / sso / ach
   unsigned asv, asq, asu;
@@ -1701,6 +1711,7 @@ struct LqrAsmIn {
   unsigned atau;                     // mpc, expand: LDS byte address (ring slot 0, without the padding offset) of [x_t; u_t][lane]
   // forward sweep
   uint64_t fptr[2], fstr[2];         // ring variant: DMA source of this lane's [F|f] chunk (t = 0) and time stride
+  uint64_t fstrl[2];                 // ghbm: stride of the LAST step (T-2 -> T-1): that of the gain lanes, 0 for F / f
   uint64_t fp[8];                    // stash variant: DMA sources of all of f (issued in the prologue)
   unsigned sr[6];                    // stash variant: LDS byte address of this lane's half row of F in ring slot q < DEPTH_B
   unsigned farea;                    // stash variant (wave-uniform): LDS byte address of this wave's f area
@@ -1722,12 +1733,12 @@ struct LqrAsmIn {
   int dfshift;                       // 0: df[t] = d_lambda[t] (the reference), 1: d_lambda[t+1]
 };
 
-// UNROLL: the backward sweep unrolled over the horizon (no per-step stash stubs), generated for the headline shape only
+// GHBM (ring form, no gains out): the gain rows pass through a caller workspace in HBM instead of LDS - any horizon
 // SAVE (with WRITE_K): Quu_t and Qxu_t of every step go to HBM as well (DiffLqr's training form)
 // AFFINE (STASH, no gains out): the re-solve with saved K_t, Quu_t, Qxu_t and another c (DiffLqr.backward's second solve)
 // ADJ (with AFFINE): DiffLqr.backward in one launch - the affine re-solve whose rollout writes dC, dc, dF, df, dx_init from
 // [V_t | v_t] of the saving solve instead of C (see gen_kernel)
-template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false, bool AFFINE = false,
+template <int NX, int NU, bool WRITE_K, bool STASH, bool MASKED = false, bool GHBM = false, bool SAVE = false, bool AFFINE = false,
           bool ADJ = false>
 struct LqrAsm {
   static constexpr bool kAvailable = false;
@@ -1761,8 +1772,8 @@ def main():
                 if stash and not write_k and nx + nu >= 4:
                     out.append(gen_kernel(nx, nu, write_k, stash, affine=True))
                     out.append(gen_kernel(nx, nu, write_k, stash, affine=True, adj=True))
-                if X_UNROLL_BWD and stash and not write_k and (nx, nu) == (8, 2):
-                    out.append(gen_kernel(nx, nu, write_k, stash, unroll=True))
+                if not stash and not write_k:
+                    out.append(gen_kernel(nx, nu, write_k, stash, ghbm=True))
                 if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding
                     out.append(gen_kernel(nx, nu, write_k, stash, masked=True))
                 if write_k and not stash and L0.SLOT_B - 16 * L0.nchunk_b >= 256:

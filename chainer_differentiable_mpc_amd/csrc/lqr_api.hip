@@ -42,7 +42,8 @@ static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch
   return off;
 }
 
-// 4 / 3: generated stream with / without the F stash; 2: LDS-DMA HIP kernel; 1: register-prefetch HIP kernel
+// 4 / 3: generated stream with / without the F stash; 6: generated stream, gain rows through the workspace (any horizon);
+// 2: LDS-DMA HIP kernel; 1: register-prefetch HIP kernel
 template <int NX, int NU, int L>
 static int solve_path(int T, int B) {
   if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
@@ -53,6 +54,9 @@ static int solve_path(int T, int B) {
           return 4;
       }
       if (lqr_asm_lds_bytes<NX, NU, false>(T) <= kAsmLdsBudget) return 3;
+      if constexpr (LqrAsm<NX, NU, false, false, false, true>::kAvailable) {
+        if (lqr_asm_lds_bytes<NX, NU, false, false, true>(T) <= kAsmLdsBudget) return 6;
+      }
     }
   }
   if constexpr (L == 16) {
@@ -85,7 +89,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
     // c in two arrays / x_init = 0: forms only the generated streams take (lqr_second_solve below)
     bool ok = false;
     if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable)
-      ok = mode == kSolve && !masked && a.Ks == nullptr && solve_path<NX, NU, L>(a.T, a.B) >= 3;
+      ok = mode == kSolve && !masked && a.Ks == nullptr && (solve_path<NX, NU, L>(a.T, a.B) == 3 || solve_path<NX, NU, L>(a.T, a.B) == 4);
     if (!ok) return DMPC_E_UNSUPPORTED;
   }
   if (a.Vv_in != nullptr) {
@@ -123,7 +127,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       const int mpath = (mode == kSolve && masked && a.Ks == nullptr && (a.B * NU) % 4 == 0 &&
                          (reinterpret_cast<uintptr_t>(a.mask) & 3u) == 0)
                             ? solve_path<NX, NU, L>(a.T, a.B) : 0;
-      if (mpath >= 3) {
+      if (mpath == 3 || mpath == 4) {
         const int waves = (a.B + 3) / 4;
         const dim3 g((waves + 3) / 4);
         const bool has_f = a.f != nullptr;
@@ -141,7 +145,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #undef DMPC_ASM_LAUNCH_M
       }
     }
-    if (mode == kBackwardOnly && !masked && solve_path<NX, NU, L>(a.T, a.B) >= 3 &&
+    if (mode == kBackwardOnly && !masked && solve_path<NX, NU, L>(a.T, a.B) >= 3 && solve_path<NX, NU, L>(a.T, a.B) != 6 &&
         lqr_asm_lds_bytes<NX, NU, false>(a.T) <= kAsmLdsBudget) {
       // LqrRecursion.backward(): the generated stream's backward sweep with the gains written to HBM (x == nullptr)
       const int waves = (a.B + 3) / 4;
@@ -153,7 +157,18 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       return (int)hipGetLastError();
     }
     const int path = (mode == kSolve && !masked) ? solve_path<NX, NU, L>(a.T, a.B) : 0;
-    if (path >= 3) {
+    if constexpr (LqrAsm<NX, NU, false, false, false, true>::kAvailable) {
+      // long horizons: the gain rows pass through the workspace instead of LDS (the caller's Ks / ks are another layout:
+      // a solve that wants them goes to the kernels below)
+      if (path == 6 && a.Ks == nullptr && a.wsK != nullptr && a.c_u == nullptr && a.x_init != nullptr) {
+        const int waves = (a.B + 3) / 4;
+        const size_t shmem = lqr_asm_lds_bytes<NX, NU, false, false, true>(a.T);
+        if (a.f != nullptr) DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, true, false, false, false, true>), dim3((waves + 3) / 4), block, shmem, stream, a);
+        else DMPC_LAUNCH_GGL((lqr_asm_kernel<NX, NU, false, false, false, false, true>), dim3((waves + 3) / 4), block, shmem, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
+    if (path >= 3 && path != 6) {
       const int waves = (a.B + 3) / 4;
       const dim3 g((waves + 3) / 4);
       const bool has_f = a.f != nullptr, write_k = a.Ks != nullptr;
@@ -332,9 +347,9 @@ int dmpc_lqr_saving_available(int T, int B, int nx, int nu) {
 
 size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
-  // gains [T,B,nu,nx] + [T,B,nu]; only touched when they do not fit in LDS (long horizons) or
-  // by the generic kernel
-  return (size_t)T * B * nu * (nx + 1) * sizeof(float);
+  // gains [T,B,nu,nx] + [T,B,nu], or - the generated stream at long horizons - rows of 12 floats [K_m | 0 | k_m | pad];
+  // only touched when they do not fit in LDS (long horizons) or by the generic kernel
+  return (size_t)T * B * nu * (nx + 1 > 12 ? nx + 1 : 12) * sizeof(float);
 }
 
 int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,

@@ -35,9 +35,10 @@ __device__ const float4 dmpc_zero_chunks[16] = {};
 
 // Bytes of a wave's gain rows + (saving solve) the staging area of the saved blocks behind them: the stream zero-fills
 // the gain rows in whole 1 KB pieces, and what that overshoots may be the staging area (scratch until the first step).
-template <int NX, int NU, bool STASH, bool SAVE = false>
+template <int NX, int NU, bool STASH, bool SAVE = false, bool GHBM = false>
 constexpr size_t lqr_asm_gain_bytes(int T) {
   using G = LqrAsm<NX, NU, false, STASH>;
+  if constexpr (GHBM) return 0;   // the gain rows live in the caller's workspace
   const size_t rows = (size_t)4 * T * NU * G::KROW * 4, filled = round_up(rows, 1024);
   if constexpr (SAVE) {
     const size_t both = round_up(rows, 16) + (size_t)LqrAsm<NX, NU, true, STASH, false, false, true>::SAVE_STAGE_BYTES;
@@ -47,10 +48,11 @@ constexpr size_t lqr_asm_gain_bytes(int T) {
   }
 }
 
-template <int NX, int NU, bool STASH, bool SAVE = false>
+template <int NX, int NU, bool STASH, bool SAVE = false, bool GHBM = false>
 constexpr size_t lqr_asm_lds_bytes(int T) {
   using G = LqrAsm<NX, NU, false, STASH>;
-  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) + 4 * lqr_asm_gain_bytes<NX, NU, STASH, SAVE>(T);
+  return (size_t)4 * G::RING_BYTES + (STASH ? (size_t)4 * G::FAREA_BYTES : 0) +
+         4 * lqr_asm_gain_bytes<NX, NU, STASH, SAVE, GHBM>(T);
 }
 
 // Per-lane LDS-DMA sources of the backward groups: chunk g = q*64 + lane64 of the slot [C | c | F | f | padding]
@@ -181,10 +183,13 @@ __device__ __forceinline__ void lqr_asm_row_addresses(LqrAsmIn<NX, NU> &in, unsi
 // AFFINE: the re-solve from saved gains (a.Ks_in, a.Quu_in, a.Qxu_in; a.c the new affine term, no f, a.C not read).
 // ADJ (with AFFINE): DiffLqr.backward in one launch - a.c / a.c_u are grad_x / grad_u, a.Vv_in the saving solve's value
 // functions, a.tau_x / a.tau_u its solution; dC, dc, dF, df, dx0 are written by the rollout (a.x, a.u are not).
-template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false, bool UNROLL = false, bool SAVE = false,
+// GHBM (ring form): the gain rows pass through a.wsK ([T,B,nu,KROW] floats, rows [K_m | 0 | k_m | pad]) instead of LDS and
+// come back to the rollout through its ring, with F and f: any horizon.
+template <int NX, int NU, bool HAS_F, bool WRITE_K, bool STASH, bool MASKED = false, bool GHBM = false, bool SAVE = false,
           bool AFFINE = false, bool ADJ = false>
 __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
-  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, UNROLL, SAVE, AFFINE, ADJ>;
+  using G = LqrAsm<NX, NU, WRITE_K, STASH, MASKED, GHBM, SAVE, AFFINE, ADJ>;
+  static_assert(!GHBM || !(STASH || WRITE_K || MASKED || SAVE || AFFINE), "gains through HBM: the plain ring form only");
   static_assert(!ADJ || AFFINE, "the one-pass gradient is a form of the affine re-solve");
   static_assert(!AFFINE || (!HAS_F && STASH), "the affine re-solve has no f and keeps F in the stash");
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   const unsigned lds0 = lds_byte_address(lds);
   const unsigned ring = lds0 + (unsigned)wave * G::RING_BYTES;
   const unsigned farea = lds0 + 4u * G::RING_BYTES + (unsigned)wave * (STASH ? G::FAREA_BYTES : 0);
-  const unsigned gain_wave_bytes = (unsigned)lqr_asm_gain_bytes<NX, NU, STASH, SAVE>(T);
+  const unsigned gain_wave_bytes = (unsigned)lqr_asm_gain_bytes<NX, NU, STASH, SAVE, GHBM>(T);
   const unsigned gain_wave = lds0 + 4u * G::RING_BYTES + (STASH ? 4u * G::FAREA_BYTES : 0u) + (unsigned)wave * gain_wave_bytes;
   const unsigned gain_traj = gain_wave + (unsigned)r * (unsigned)(T * NU * KROW * 4);
 
@@ -239,7 +244,14 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   // is loaded and x_0 stored by the stream itself.
   G::issue_first(in);
   in.gz = gain_wave + (unsigned)lane64 * 16u;  // the stream zero-fills the gain rows behind its first DMAs
-  in.nz = (int)(round_up((size_t)4 * T * NU * KROW * 4, 1024) / 1024u);
+  in.nz = GHBM ? 0 : (int)(round_up((size_t)4 * T * NU * KROW * 4, 1024) / 1024u);
+  if constexpr (GHBM) {   // a whole gain row per trajectory and control: lane j <= ns stores column j (lane ns = the affine column)
+    const size_t tb = (size_t)(T - 1) * B + (size_t)b;
+    in.pgw = reinterpret_cast<uint64_t>(a.wsK + tb * NU * KROW + (lane <= NS ? lane : NS));
+    in.dgw = (uint64_t)0 - (uint64_t)(B * NU * KROW * 4);
+  } else {
+    in.pgw = in.dgw = 0;
+  }
   const int lane_c = lane < NS ? lane : NS - 1;  // lanes past the affine column duplicate column ns-1
   const bool col_aff = lane == AFF;
   if constexpr (AFFINE) lqr_asm_affine_addresses<NX, NU, G>(in, ring, r, lane, a.c_u != nullptr);
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
   const int m_own = row_x ? 0 : (lane < NS ? lane - NX : NU - 1);
   const unsigned arow_u = gain_traj + (unsigned)(m_own * KROW * 4);
 #pragma unroll
-  for (int q = 0; q < 2; ++q) in.fptr[q] = in.fstr[q] = 0;
+  for (int q = 0; q < 2; ++q) in.fptr[q] = in.fstr[q] = in.fstrl[q] = 0;
 #pragma unroll
   for (int q = 0; q < 8; ++q) in.fp[q] = 0;
   {  // stash: lane i < 8 of a row parks columns [0, H) of row i of F_t, lane 8 + i columns [H, ns)
@@ -327,14 +339,18 @@ __global__ __launch_bounds__(256) void lqr_asm_kernel(const LqrArgs a) {
         off = (size_t)g * 16;
       } else if (g < nF + nf) {
         base = fb; per = per_f; off = (size_t)(g - nF) * 16;
+      } else if (GHBM && g < nF + nf + NU * KROW) {   // the wave's gain rows of the step: 4 trajectories x nu x KROW floats
+        base = reinterpret_cast<const char *>(a.wsK); per = (size_t)NU * KROW * 4; off = (size_t)(g - nF - nf) * 16;
       }
       in.fptr[q] = reinterpret_cast<uint64_t>(base) + (size_t)b0 * per + off - (uint64_t)q * 1024u;
       in.fstr[q] = (uint64_t)(B * per);
+      in.fstrl[q] = (GHBM && g >= nF + nf && g < nF + nf + NU * KROW) ? (uint64_t)(B * per) : 0;
     }
-    in.arow = row_x ? ring + (unsigned)((r * NX + lane) * NS * 4) : arow_u;
-    in.aaff = row_x ? ring + (unsigned)(G::FOFF_f + (r * NX + lane) * 4) : arow_u + (unsigned)(NS * 4);
-    in.drow = row_x ? (unsigned)G::SLOT_F : (unsigned)(NU * KROW * 4);
-    in.drow2 = row_x ? (unsigned)G::SLOT_F - (unsigned)(G::DEPTH_F * G::SLOT_F) : (unsigned)(NU * KROW * 4);
+    const unsigned arow_g = GHBM ? ring + (unsigned)(G::FOFF_G + (r * NU + m_own) * KROW * 4) : arow_u;   // GHBM: in the slot
+    in.arow = row_x ? ring + (unsigned)((r * NX + lane) * NS * 4) : arow_g;
+    in.aaff = row_x ? ring + (unsigned)(G::FOFF_f + (r * NX + lane) * 4) : arow_g + (unsigned)(NS * 4);
+    in.drow = (row_x || GHBM) ? (unsigned)G::SLOT_F : (unsigned)(NU * KROW * 4);
+    in.drow2 = (row_x || GHBM) ? (unsigned)G::SLOT_F - (unsigned)(G::DEPTH_F * G::SLOT_F) : (unsigned)(NU * KROW * 4);
     in.daff = in.drow;
     in.daff2 = in.drow2;
   }

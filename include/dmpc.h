@@ -58,7 +58,9 @@ int dmpc_lqr_kernel_family(int nx, int nu);
  *   2 lqr_dma_kernel (HIP, LDS-DMA ring)          3 lqr_asm_kernel, ring (generated stream, F fetched twice)
  *   4 lqr_asm_kernel, stash (generated stream, F kept in accumulation registers)
  *   5 lqr_wave_mfma_backward (one wavefront per trajectory, e.g. (32,8): MFMA backward sweep, then the same wavefront
- *     rolls its trajectory out)   <0 unsupported */
+ *     rolls its trajectory out)
+ *   6 lqr_asm_kernel, ring, gain rows through the workspace (horizons whose gain rows do not fit in LDS: T > 74 at
+ *     (8,2); needs `ws`)   <0 unsupported */
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
 
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active

@@ -48,7 +48,7 @@ def test_dispatch_table_and_workspace_queries():
     assert lib.dmpc_lqr_kernel_family(32, 8) == 2       # wave kernel
     assert lib.dmpc_lqr_kernel_family(5, 3) == 3        # runtime-dimension kernel
     assert lib.dmpc_lqr_kernel_family(60, 10) == _lib.E_UNSUPPORTED
-    assert lib.dmpc_lqr_workspace_bytes(50, 4096, 8, 2) == 50 * 4096 * 2 * 9 * 4
+    assert lib.dmpc_lqr_workspace_bytes(50, 4096, 8, 2) == 50 * 4096 * 2 * 12 * 4     # gain rows of 12 floats (path 6)
     assert lib.dmpc_lqr_workspace_bytes(0, 1, 1, 1) == 0
 
 
@@ -60,8 +60,8 @@ def test_solve_path_selection_is_host_logic():
     assert lib.dmpc_lqr_solve_path(51, 4096, 8, 2) == 4
     assert lib.dmpc_lqr_solve_path(52, 4096, 8, 2) == 3
     assert lib.dmpc_lqr_solve_path(74, 4096, 8, 2) == 3   # the last horizon whose gain rows fit in LDS beside the rings
-    assert lib.dmpc_lqr_solve_path(75, 4096, 8, 2) == 2
-    assert lib.dmpc_lqr_solve_path(80, 4096, 8, 2) == 1
+    assert lib.dmpc_lqr_solve_path(75, 4096, 8, 2) == 6   # beyond: the gain rows pass through the workspace, any horizon
+    assert lib.dmpc_lqr_solve_path(400, 4096, 8, 2) == 6
     assert lib.dmpc_lqr_solve_path(50, 3, 8, 2) == 1      # less than one wavefront of trajectories
     assert lib.dmpc_lqr_solve_path(20, 1024, 3, 1) == 3   # nx = 3 does not tile the f area: ring variant
     assert lib.dmpc_lqr_solve_path(50, 65536, 32, 8) == 5   # one wavefront per trajectory, MFMA backward sweep

@@ -12,7 +12,7 @@ from tests.helpers import TOL_PRIMAL, assert_close, npy, to_dev
 
 pytestmark = pytest.mark.gpu
 
-STASH, RING, DMA = 4, 3, 2
+STASH, RING, DMA, GHBM = 4, 3, 2, 6
 
 
 def run_case(B, T, nx, nu, with_f, want_gains, seed=5):
@@ -36,7 +36,7 @@ def run_case(B, T, nx, nu, with_f, want_gains, seed=5):
     ((64, 10, 8, 2), STASH), ((4, 2, 8, 2), STASH), ((5, 3, 8, 2), STASH), ((9, 5, 8, 2), STASH),
     ((131, 50, 8, 2), STASH), ((6, 51, 8, 2), STASH),      # 51 = the last horizon that fits the stash registers
     ((6, 52, 8, 2), RING), ((5, 74, 8, 2), RING),          # 74 = the last horizon whose gains fit in LDS
-    ((5, 75, 8, 2), DMA),
+    ((5, 75, 8, 2), GHBM), ((37, 100, 8, 2), GHBM), ((8, 200, 8, 2), GHBM), ((12, 300, 3, 1), GHBM),   # gain rows through HBM
     ((16, 20, 3, 1), RING), ((7, 9, 4, 2), STASH), ((11, 13, 6, 2), RING), ((8, 6, 2, 2), STASH),
     ((8, 6, 1, 1), STASH), ((8, 7, 2, 1), STASH), ((8, 6, 3, 2), RING)])
 @pytest.mark.parametrize("with_f", [True, False])
@@ -45,6 +45,9 @@ def test_generated_stream_against_oracle(shape, path, with_f, want_gains):
     B, T, nx, nu = shape
     assert _lib.load().dmpc_lqr_solve_path(T, B, nx, nu) == path
     run_case(B, T, nx, nu, with_f, want_gains)
+    if path == GHBM and not want_gains:      # <nx, nu, has_f, write_k, stash, masked, GHBM, save, affine, adj>
+        assert _lib.last_kernel_name().endswith("false, false, false, true, false, false, false>(dmpc::LqrArgs)"), \
+            _lib.last_kernel_name()
 
 
 def test_batch_below_one_wave_takes_the_hip_kernel():
