@@ -165,8 +165,11 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
 // DMPC_WAVE_PREFETCH 1: one wavefront per SIMD (512 registers), inputs of the next step in a second register bank;
 //                    0: two wavefronts per SIMD (256 registers each), each hides the other's latencies
 // ROLLOUT: the wavefront goes on with the forward sweep of its trajectory (solve_recursion in ONE launch)
+#ifndef DMPC_WAVE_OCC
+#define DMPC_WAVE_OCC 2    // wavefronts per SIMD the register budget is set for (experiments: 3 -> 168 registers)
+#endif
 template <int NX, int NU, bool MASKED, bool ROLLOUT>
-__global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : 2) void lqr_wave_mfma_backward(const LqrArgs a) {
+__global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void lqr_wave_mfma_backward(const LqrArgs a) {
   constexpr int NS = NX + NU, AFF = NS;
   static_assert(NX % 4 == 0 && NU % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
   constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4, TU = NU / 4;

@@ -57,7 +57,7 @@ def imitation_grads(logit, learn_p, xinit, expert_u, T, lqr_iter, u_init=None, b
     keep = (last_norm < MPC_EPS).astype(float) if best_norm.max() > MPC_EPS else None
     loss, dC, dc = gradient_node(x, u, Q, pv, expert_u, keep)
     g_logit, g_p = param_grads(dC, dc, logit, learn_p)
-    return dict(nom_x=x, nom_u=u, loss=loss, g_logit=g_logit, g_p=g_p, status=status, dC=dC, dc=dc)
+    return dict(nom_x=x, nom_u=u, loss=loss, g_logit=g_logit, g_p=g_p, status=status, dC=dC, dc=dc, keep=keep)
 
 
 def imitation_loop(logit, learn_p, xinit, expert_u, T, lqr_iter, K, lr=1e-2, alpha=0.5, eps=1e-8):

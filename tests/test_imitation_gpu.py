@@ -388,6 +388,27 @@ def test_imitation_chain_small_against_the_reference():
     assert abs(float(loss) - float(g["loss"])) < 5e-3 * float(g["loss"])
     for got, ref in ((net.learn_q_logit.grad, g["g_logit"]), (net.learn_p.grad, g["g_p"])):
         assert np.abs(npy(got) - ref).max() <= 5e-2 * np.abs(ref).max(), (npy(got), ref)
+    # The bound above absorbs five iterations of line-search forks.  The gradient ITSELF is held at the reference's own
+    # final iterate, where both sides differentiate the same point: MPCstep.backward there (mpc/box_ddp.py:234-259) with
+    # the detach mask of :263-289 (from the oracle's run, pinned to this fixture at 1e-12), summed over time and batch
+    # in the kernel, chained to (d logit, d learn_p) - 1e-3 of the largest entry.
+    from chainer_differentiable_mpc_amd.mpc_step import tiled_cost_gradient
+    from oracle import imitation as oim
+    r = oim.imitation_grads(g["q_logit"], g["learn_p"], g["xinit"], g["expert_u"], T, int(g["lqr_iter"]))
+    xr_, ur_ = dev(g["nom_x"]), dev(g["nom_u"])
+    _, Fm, _ = env.true_dx.rollout_linearize(xr_[0], ur_)
+    q64, p64 = oim.cost_from_params(g["q_logit"], g["learn_p"])
+    Qt, pt = oim.tile_cost(q64, p64, T, B)
+    keep = np.ones(B) if r["keep"] is None else r["keep"]
+    dl_du = -2.0 * (g["expert_u"] - g["nom_u"]) / g["expert_u"].size * keep[None, :, None]
+    lo, hi = torch.full((T, B, 1), -2.0, device="cuda"), torch.full((T, B, 1), 2.0, device="cuda")
+    got = tiled_cost_gradient(T, B, 3, 1, torch.device("cuda", 0), dict(C=dev(Qt), c=dev(pt), F=Fm, x=xr_, u=ur_), lo, hi,
+                              None, dev(dl_du))
+    assert got is not None
+    dQ, dp = npy(got[1]).astype(np.float64), npy(got[2]).astype(np.float64)
+    dq = np.diag(dQ) + dp * g["learn_p"] / (2.0 * np.sqrt(q64))           # oracle/imitation.py: param_grads
+    for mine, ref, name in ((dq * q64 * (1.0 - q64), g["g_logit"], "d logit"), (dp * np.sqrt(q64), g["g_p"], "d learn_p")):
+        assert np.abs(mine - ref).max() <= 1e-3 * np.abs(ref).max(), (name, mine, ref)
 
 
 def test_imitation_loop_three_updates_against_the_reference():
