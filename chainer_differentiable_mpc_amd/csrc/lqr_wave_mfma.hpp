@@ -31,6 +31,7 @@
 // forward-only lqr_kernel, which is bandwidth bound.
 #pragma once
 #include "colwise.hpp"
+#include "dma_gather.hpp"
 #include "lqr_kernels.hpp"
 
 namespace dmpc {
@@ -61,6 +62,64 @@ __device__ __forceinline__ float wave_load(__amdgpu_buffer_rsrc_t r, int voff) {
 }
 
 constexpr int kOutOfRange = 0x40000000;
+
+// DMPC_WAVE_DMA 1 (default): the inputs of step t-1 travel HBM -> LDS by LDS-DMA while step t computes, and the register
+// bank is filled from LDS at the top of the step - a prefetch that costs no registers (the two-bank form above needs the
+// whole file of a SIMD for one wavefront) and turns the sweep's 164-byte row loads into whole kilobytes.
+//                0: buffer loads straight into the bank at the top of the step (rounds 1-2)
+#ifndef DMPC_WAVE_DMA
+#define DMPC_WAVE_DMA 1
+#endif
+#ifndef DMPC_WAVE_DMA_NT
+#define DMPC_WAVE_DMA_NT 0
+#endif
+#ifndef DMPC_WAVE_COUNTED_WAIT
+#define DMPC_WAVE_COUNTED_WAIT 1
+#endif
+// ROLLOUT only: wavefronts in an odd slot of their SIMD start DMPC_WAVE_STAGGER_TICKS (100 MHz ticks) late when the grid
+// takes several rounds, so that the two wavefronts of a SIMD are not in the same phase: the rollout (waits on memory)
+// of one then runs under the sweep (issue bound) of the other instead of both rolling out at once.
+// Measured (round 3, B = 8192, same box): 0 -> 1.852 ms, 5,000 -> 1.85, 10,000 -> 1.79, 20,000 -> 1.81, 40,000 -> 1.88.
+#ifndef DMPC_WAVE_STAGGER_TICKS
+#define DMPC_WAVE_STAGGER_TICKS 10000
+#endif
+#if DMPC_WAVE_DMA_NT
+#define DMPC_WAVE_DMA_POLICY " nt"
+#else
+#define DMPC_WAVE_DMA_POLICY ""
+#endif
+// one LDS-DMA instruction, uniform base + per-lane byte offset: lane l copies 16 bytes from base + voff + OFF to LDS at
+// M0 + OFF + 16 l (the instruction offset moves both addresses; 12 bits + sign)
+template <int OFF>
+__device__ __forceinline__ void wave_dma16(unsigned voff, unsigned long long base) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" DMPC_WAVE_DMA_POLICY ::"v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+// the same for the first LANES lanes only (the tail of a region); every lane is active around it
+template <int OFF, int LANES>
+__device__ __forceinline__ void wave_dma16_tail(unsigned voff, unsigned long long base) {
+  static_assert(LANES >= 1 && LANES <= 32, "the mask is a 32-bit literal");
+  asm volatile("s_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" DMPC_WAVE_DMA_POLICY "\n\ts_mov_b64 exec, -1"
+               ::"v"(voff), "s"(base), "n"(OFF), "n"((1ll << LANES) - 1) : "memory");
+}
+// a contiguous region of BYTES bytes (a multiple of 16) at `src` (wave-uniform) -> LDS byte address `dst`
+template <int BYTES>
+__device__ __forceinline__ void wave_dma_region(const void *src, unsigned dst, unsigned voff16) {
+  static_assert(BYTES % 16 == 0, "whole 16-byte chunks");
+  constexpr int kChunks = BYTES / 16, kSeg = (kChunks + 255) / 256;     // a segment = 4 instructions = 4 KB
+  static_for<0, kSeg>([&](auto sg) {
+    constexpr int c0 = sg.value * 256;
+    set_m0(dst + sg.value * 4096);
+    const unsigned long long base = reinterpret_cast<unsigned long long>(src) + sg.value * 4096;
+    static_for<0, 4>([&](auto q) {
+      constexpr int first = c0 + q.value * 64, left = kChunks - first;
+      if constexpr (left >= 64) wave_dma16<q.value * 1024>(voff16, base);
+      else if constexpr (left > 32) {   // 33..63 lanes: two halves (the mask literal holds 32 bits)
+        wave_dma16_tail<q.value * 1024, 32>(voff16, base);
+        wave_dma16_tail<q.value * 1024 + 512, left - 32>(voff16, base);
+      } else if constexpr (left > 0) wave_dma16_tail<q.value * 1024, left>(voff16, base);
+    });
+  });
+}
 
 // Closed-loop rollout (LqrRecursion.forward, lqr/lqr_recursion.py:160-200) by the wavefront that has just finished the
 // backward sweep of the same trajectory: while it waits on memory here, the other wavefront of its SIMD is in the
@@ -191,6 +250,15 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
   float *ks = a.Ks != nullptr ? a.ks : a.wsk;
   int info_bits = 0;
 
+  if constexpr (ROLLOUT && DMPC_WAVE_STAGGER_TICKS > 0) {
+    // HW_ID (hwreg 4) bits 3:0 = the wavefront's slot in its SIMD; first round only (later rounds inherit the offset)
+    const unsigned slot_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
+    constexpr unsigned kResident = 2 * 256;   // workgroups the chip holds at once: two per CU (LDS, registers)
+    if ((slot_id & 1u) && gridDim.x > kResident && blockIdx.x < kResident) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)DMPC_WAVE_STAGGER_TICKS) __builtin_amdgcn_s_sleep(64);
+    }
+  }
   struct Bank {
     f4v Q4[TS];    // rows of [C_t | c_t], column-per-lane
     float Fc[NX];  // rows of [F_t | f_t]
@@ -234,6 +302,51 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
 
   __shared__ float xu_all[4][NX * NU];   // per wavefront: Qxu of the current step, [i][m]
   float *xu_lds = xu_all[threadIdx.x >> 6];
+#if DMPC_WAVE_DMA && !DMPC_WAVE_PREFETCH
+  // ---- the input slot of this wavefront: [C_t | c_t | F_t | f_t] as they lie in HBM, filled by LDS-DMA a step ahead
+  constexpr int kSlotC = 0, kSlotc = NS * NS, kSlotF = kSlotc + NS, kSlotf = kSlotF + NX * NS, kSlotFloats = kSlotf + NX;
+  static_assert((NS * NS) % 4 == 0 && NS % 4 == 0 && (NX * NS) % 4 == 0 && NX % 4 == 0, "16-byte regions");
+  __shared__ __attribute__((aligned(16))) float slot_all[4][kSlotFloats];
+  float *slot = slot_all[threadIdx.x >> 6];
+  const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot);   // LDS byte address (low 32 bits of the pointer)
+  const unsigned voff16 = lane * 16;
+  auto dma_issue = [&](int t) {   // the slot's reads are in (the caller has waited for them)
+    const size_t tb = (size_t)t * B + b;
+    wave_dma_region<NS * NS * 4>(a.C + tb * NS * NS, slot_addr + kSlotC * 4, voff16);
+    wave_dma_region<NS * 4>(a.c + tb * NS, slot_addr + kSlotc * 4, voff16);
+    if (t < T - 1) {   // uniform; there is no F_{T-1}
+      wave_dma_region<NX * NS * 4>(a.F + tb * NX * NS, slot_addr + kSlotF * 4, voff16);
+      if (has_f) wave_dma_region<NX * 4>(a.f + tb * NX, slot_addr + kSlotf * 4, voff16);
+    }
+  };
+  // slot -> bank.  Lanes beyond the affine column are never written: they hold the zeros the bank starts with (their
+  // columns of Q~ only ever add products with those zeros), as the out-of-range buffer loads of the other form give.
+  auto read_bank = [&](int t, Bank &k) {
+    if (lane < NS) {
+      static_for<0, NS>([&](auto i) { k.Q4[i.value / 4][i.value % 4] = slot[kSlotC + i.value * NS + lane]; });
+      if (t < T - 1) static_for<0, NX>([&](auto r) { k.Fc[r.value] = slot[kSlotF + r.value * NS + lane]; });
+    } else if (col_aff) {
+      const f4v *cp = reinterpret_cast<const f4v *>(slot + kSlotc);
+#pragma unroll
+      for (int I = 0; I < TS; ++I) k.Q4[I] = cp[I];
+      if (has_f && t < T - 1) {
+        const f4v *fp = reinterpret_cast<const f4v *>(slot + kSlotf);
+#pragma unroll
+        for (int I = 0; I < TX; ++I) {
+          const f4v v = fp[I];
+          k.Fc[4 * I] = v[0]; k.Fc[4 * I + 1] = v[1]; k.Fc[4 * I + 2] = v[2]; k.Fc[4 * I + 3] = v[3];
+        }
+      }
+    }
+    if constexpr (MASKED) {
+      const size_t tb = (size_t)t * B + b;
+      unsigned bits = 0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) bits |= (a.mask[tb * NU + m] != 0 ? 1u : 0u) << m;
+      k.act = __builtin_amdgcn_readfirstlane(bits);
+    }
+  };
+#endif
   f4v V4[TX];  // rows of [V | v]
 #pragma unroll
   for (int I = 0; I < TX; ++I) V4[I] = f4v{0.f, 0.f, 0.f, 0.f};
@@ -371,7 +484,32 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
     }
   };
 
-#if !DMPC_WAVE_PREFETCH
+#if DMPC_WAVE_DMA && !DMPC_WAVE_PREFETCH
+  Bank ka;
+#pragma unroll
+  for (int I = 0; I < TS; ++I) ka.Q4[I] = f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int r = 0; r < NX; ++r) ka.Fc[r] = 0.f;
+  ka.act = 0;
+  dma_issue(T - 1);
+  for (int t = T - 1; t >= 0; --t) {
+    // The slot has landed (requested a whole step ago).  The vector-memory counter retires in order and the only operations
+    // behind the slot's DMA are the NU gain stores of the step in between: waiting for all but NU leaves their
+    // acknowledgements (a trip to HBM each, right before this point) out of the critical path.
+    if (DMPC_WAVE_COUNTED_WAIT && !MASKED && t < T - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NU) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DMPC_STAMP(0);
+    read_bank(t, ka);
+    if (t > 0) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and has been read: it can take the next step's inputs
+#ifndef DMPC_WAVE_KNOB_NO_FETCH   // timing knob: the sweep on whatever the slot holds (wrong results)
+      dma_issue(t - 1);
+#endif
+    }
+    DMPC_STAMP(1);
+    step(t, ka, ka);
+  }
+#elif !DMPC_WAVE_PREFETCH
   Bank ka;
   for (int t = T - 1; t >= 0; --t) {
     fetch_cost(t, ka);
@@ -409,7 +547,11 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
     out[6] = tot;
   }
 #endif
+#ifdef DMPC_WAVE_KNOB_NO_ROLLOUT
+  if constexpr (false) {
+#else
   if constexpr (ROLLOUT) {
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gain stores of this wavefront have reached L2
 #ifdef DMPC_DBG_FENCE
     __threadfence();
