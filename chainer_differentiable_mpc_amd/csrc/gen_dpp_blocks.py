@@ -27,8 +27,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "dpp_blocks_gen.hpp")
 
-# (nx, nu) with nx + nu + 1 <= 16 that get asm blocks (must be a subset of DMPC_LQR_SHAPES, L = 16)
-SHAPES = [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (4, 2), (6, 2), (8, 2), (4, 4), (8, 4), (12, 3)]
+# (nx, nu) with nx + nu + 1 <= 16 that get asm blocks (DMPC_LQR_SHAPES with L = 16 and DMPC_LQR_CONTAINERS of lqr_api.hip)
+SHAPES = [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (4, 2), (6, 2), (8, 2), (4, 4), (8, 4), (12, 3),
+          (14, 1), (13, 2), (11, 4)]      # the last three: containers only (lqr_api.hip DMPC_LQR_CONTAINERS)
 MAX_OPERANDS = 30
 
 

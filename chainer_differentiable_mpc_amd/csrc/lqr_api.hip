@@ -37,13 +37,18 @@ static bool wave_mfma_disabled() {  // DMPC_NO_WAVE_MFMA=1: large shapes on the 
   static const bool off = [] { const char *e = getenv("DMPC_NO_WAVE_MFMA"); return e && e[0] == '1'; }();
   return off;
 }
+static bool container_disabled() {  // DMPC_NO_CONTAINER=1: shapes without a specialisation on the runtime-dimension kernel
+  static const bool off = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
+  return off;
+}
 static bool dma_path_disabled() {  // DMPC_NO_DMA=1 forces the register-prefetch kernel (A/B timing, debugging)
   static const bool off = [] { const char *e = getenv("DMPC_NO_DMA"); return e && e[0] == '1'; }();
   return off;
 }
 
 // 4 / 3: generated stream with / without the F stash; 6: generated stream, gain rows through the workspace (any horizon);
-// 2: LDS-DMA HIP kernel; 1: register-prefetch HIP kernel
+// 2: LDS-DMA HIP kernel; 1: register-prefetch HIP kernel; 7: a container (the register-prefetch kernel of a larger shape);
+// 0: runtime-dimension kernel
 template <int NX, int NU, int L>
 static int solve_path(int T, int B) {
   if constexpr (L == 16 && LqrAsm<NX, NU, false, false>::kAvailable) {
@@ -255,13 +260,64 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
 #endif
 
+// Containers: register-resident kernels that also take any SMALLER problem (lqr_kernel<..., PAD>; the loads pad it in
+// place), in the order they are tried - fewest columns first, fewest controls among equals.  Every shape with
+// nx + nu <= 15 and nu <= 4 has one.
+#if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2)
+#define DMPC_LQR_CONTAINERS(X)
+#else
+#define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
+#endif
+
+static bool has_container(int nx, int nu) {
+#define X(NX_, NU_) \
+  if (nx <= NX_ && nu <= NU_) return true;
+  DMPC_LQR_CONTAINERS(X)
+#undef X
+  return false;
+}
+
 static int lqr_family(int nx, int nu) {
 #define X(NX_, NU_, L_) \
   if (nx == NX_ && nu == NU_) return L_ == 16 ? 1 : 2;
   DMPC_LQR_SHAPES(X)
 #undef X
+  if (nx >= 1 && nu >= 1 && has_container(nx, nu)) return 4;
   if (nx >= 1 && nu >= 1 && nx + nu + 1 <= kGenericMaxCols) return 3;
   return DMPC_E_UNSUPPORTED;
+}
+
+// a problem without a specialisation of its own, in the smallest container that holds it
+template <int NX, int NU>
+static int launch_lqr_container(int mode, int nx, int nu, const LqrArgs &a0, hipStream_t stream) {
+  constexpr int GPB = 16;
+  LqrArgs a = a0;
+  a.nx_log = nx;
+  a.nu_log = nu;
+  const dim3 grid((a.B + GPB - 1) / GPB), block(256);
+  const bool masked = a.mask != nullptr;
+  const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);
+#define DMPC_LAUNCH(MASKED, MODE, KLDS, SHMEM) \
+  DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, 16, MASKED, MODE, KLDS, true>), grid, block, SHMEM, stream, a)
+  if (mode == kSolve) {
+    if (lds_gain <= kGainLdsBudget) {
+      if (masked) DMPC_LAUNCH(true, kSolve, true, lds_gain);
+      else DMPC_LAUNCH(false, kSolve, true, lds_gain);
+    } else {
+      if (a.Ks == nullptr) { a.Ks = a.wsK; a.ks = a.wsk; }
+      if (a.Ks == nullptr) return DMPC_E_WORKSPACE;
+      if (masked) DMPC_LAUNCH(true, kSolve, false, 0);
+      else DMPC_LAUNCH(false, kSolve, false, 0);
+    }
+  } else if (mode == kBackwardOnly) {
+    if (masked) DMPC_LAUNCH(true, kBackwardOnly, false, 0);
+    else DMPC_LAUNCH(false, kBackwardOnly, false, 0);
+  } else {
+    if (masked) DMPC_LAUNCH(true, kForwardOnly, false, 0);
+    else DMPC_LAUNCH(false, kForwardOnly, false, 0);
+  }
+#undef DMPC_LAUNCH
+  return (int)hipGetLastError();
 }
 
 static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t stream) {
@@ -273,7 +329,13 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
   if (a.c_u != nullptr || a.Ks_in != nullptr || a.Vv_in != nullptr || a.Quu_out != nullptr ||
       (a.x_init == nullptr && a.x != nullptr))
     return DMPC_E_UNSUPPORTED;
-  if (lqr_family(nx, nu) == 3) return launch_lqr_generic(mode, nx, nu, a, stream);
+  if (lqr_family(nx, nu) == 4 && !container_disabled()) {
+#define X(NX_, NU_) \
+  if (nx <= NX_ && nu <= NU_) return launch_lqr_container<NX_, NU_>(mode, nx, nu, a, stream);
+    DMPC_LQR_CONTAINERS(X)
+#undef X
+  }
+  if (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) return launch_lqr_generic(mode, nx, nu, a, stream);
   return DMPC_E_UNSUPPORTED;
 }
 
@@ -333,7 +395,8 @@ int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   if (nx == NX_ && nu == NU_) return solve_path<NX_, NU_, L_>(T, B);
   DMPC_LQR_SHAPES(X)
 #undef X
-  return lqr_family(nx, nu) == 3 ? 0 : DMPC_E_UNSUPPORTED;
+  if (lqr_family(nx, nu) == 4 && !container_disabled()) return 7;   // a container kernel (lqr_kernel<..., PAD>)
+  return (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) ? 0 : DMPC_E_UNSUPPORTED;
 }
 
 int dmpc_lqr_saving_available(int T, int B, int nx, int nu) {

@@ -48,6 +48,8 @@ struct LqrArgs {
   float *dC = nullptr, *dc = nullptr, *dF = nullptr, *df = nullptr, *dx0 = nullptr;
   float w_a = 0.5f, w_b = 1.0f;
   int df_shift = 0;
+  // container launches (lqr_kernel<..., PAD>): the problem's own dimensions, nx_log <= NX and nu_log <= NU of the kernel
+  int nx_log = 0, nu_log = 0;
 };
 
 enum LqrMode { kSolve = 0, kBackwardOnly = 1, kForwardOnly = 2 };
@@ -84,7 +86,12 @@ constexpr int ring_depth(int regs_per_slot, int budget, int max_depth) {
 // NX, NU: state / control dims.  L: lanes per trajectory (16 or 64).  MASKED: LQR_active.
 // MODE: fused solve, gains only, or rollout only.  K_LDS: gains handed to the forward sweep
 // through LDS (else through args.Ks/args.ks in HBM).
-template <int NX, int NU, int L, bool MASKED, int MODE, bool K_LDS>
+// PAD: the kernel is a CONTAINER for a smaller problem (a.nx_log <= NX states, a.nu_log <= NU controls - the shapes without a
+// specialisation of their own): the loads place the problem's rows and columns at the container's positions (state i at i,
+// control m at NX + m), everything else of [C|c] and [F|f] is 0 and the unused controls get a unit diagonal in Quu - their
+// gain rows come out exactly 0, the pivot search never picks their rows for a real column (LAPACK's choice is unchanged),
+// and every added term of a dot product is an exact 0.  Arrays in HBM keep the problem's own strides.
+template <int NX, int NU, int L, bool MASKED, int MODE, bool K_LDS, bool PAD = false>
 __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
   constexpr int NS = NX + NU;
   static_assert(NS + 1 <= L, "a trajectory's augmented columns must fit its lane group");
@@ -101,6 +108,11 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
   const int T = a.T;
   const size_t B = (size_t)a.B;
   const bool has_f = a.f != nullptr;
+  // the problem's dimensions and where container index i lies in its arrays (-1: padding)
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int i) -> int { return i < NX ? (i < nx ? i : -1) : (i - NX < nu ? nx + (i - NX) : -1); };
+  const int lcol = lane < NS ? logical(lane) : -1;   // this lane's column of C / F
+  const int lcol_c = lcol >= 0 ? lcol : 0;
 
   extern __shared__ float lds[];
   float *kl = lds + (size_t)grp * T * NU * KROW;  // this trajectory's gains [T][NU][KROW]
@@ -133,11 +145,27 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
     // replaced by F_{T-2}, and a missing f reads c instead (both discarded by the merge in step()).
     const float *Fsafe = T > 1 ? a.F : a.C;
     const float *fsafe = has_f ? a.f : a.c;
-    auto issue_loads = [&](int t, float (&Qn)[NS], float (&Fn)[NX], float (&cn)[NS], float (&fn)[NX]) {
+    auto issue_loads = [&](int t, float (&Qn)[NS], float (&Fn)[NX], float (&cn)[NS], float (&fn)[NX]) __attribute__((always_inline)) {
       t = t < 0 ? 0 : t;
       const size_t tb = (size_t)t * B + b;
       const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
       const size_t tbF = (size_t)tF * B + b;
+      if constexpr (PAD) {   // clamped addresses, the same loads on every path as below; step() discards the padding
+        const float *Cp = a.C + tb * ns * ns + lcol_c;
+        const float *cp = a.c + tb * ns;
+        static_for<0, NS>([&](auto i) {
+          const int li = logical(i.value);   // uniform
+          Qn[i.value] = Cp[(li >= 0 ? li : 0) * ns];
+          cn[i.value] = cp[li >= 0 ? li : 0];
+        });
+        const float *Fp = Fsafe + tbF * nx * ns + lcol_c;
+        const float *fp = fsafe + tbF * nx;
+        static_for<0, NX>([&](auto k) {
+          Fn[k.value] = Fp[(k.value < nx ? k.value : 0) * ns];
+          fn[k.value] = fp[k.value < nx ? k.value : 0];
+        });
+        return;
+      }
       const float *Cp = a.C + tb * NS * NS + lane_c;
 #pragma unroll
       for (int i = 0; i < NS; ++i) Qn[i] = Cp[i * NS];
@@ -153,15 +181,26 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
     for (int i = 0; i < NX; ++i) V[i] = 0.f;
 
     auto step = [&](int t, const float (&Qn)[NS], const float (&Fn)[NX], const float (&cn)[NS],
-                    const float (&fn)[NX]) {
+                    const float (&fn)[NX]) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
       float Q[NS];
 #pragma unroll
       for (int i = 0; i < NS; ++i) Q[i] = col_aff ? cn[i] : Qn[i];
+      if constexpr (PAD) {   // rows / columns outside the problem: 0, and 1 on the diagonal of the unused controls
+        const bool col_ok = col_aff || lcol >= 0;
+        static_for<0, NS>([&](auto i) {
+          const bool row = logical(i.value) >= 0;
+          Q[i.value] = (row && col_ok) ? Q[i.value] : ((i.value >= NX && lane == i.value) ? 1.f : 0.f);
+        });
+      }
       if (t < T - 1) {
         float Fc[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) Fc[k] = col_aff ? (has_f ? fn[k] : 0.f) : Fn[k];
+        if constexpr (PAD) {
+          const bool col_ok = col_aff || lcol >= 0;
+          static_for<0, NX>([&](auto k) { Fc[k.value] = (k.value < nx && col_ok) ? Fc[k.value] : 0.f; });
+        }
         // W~ = V F~ (+ v in the affine column)     lqr_recursion.py:89,96: (F^T V) F, (F^T V) f + F^T v
         float W[NX];
 #pragma unroll
@@ -184,8 +223,7 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
         // active_constrained_lqr.py:110-137: zero q_u / Qux rows of clamped controls, zero Quu
         // outside free x free, 1e-8 on the clamped diagonal.
         bool act[NU];
-#pragma unroll
-        for (int m = 0; m < NU; ++m) act[m] = a.mask[tb * NU + m] != 0;
+        static_for<0, NU>([&](auto m) { act[m.value] = (!PAD || m.value < nu) && a.mask[tb * nu + (m.value < nu ? m.value : 0)] != 0; });
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
           Kt[m] = act[m] ? 0.f : Kt[m];
@@ -218,11 +256,12 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
 #pragma unroll
           for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + kidx] = Kt[m];
         }
-        if (live && a.Ks != nullptr) {
+        if (live && a.Ks != nullptr && (!PAD || col_aff || lane < nx)) {
 #pragma unroll
           for (int m = 0; m < NU; ++m) {
-            if (col_aff) a.ks[tb * NU + m] = Kt[m];
-            else a.Ks[(tb * NU + m) * NX + lane] = Kt[m];
+            if (PAD && m >= nu) break;   // uniform
+            if (col_aff) a.ks[tb * nu + m] = Kt[m];
+            else a.Ks[(tb * nu + m) * nx + lane] = Kt[m];
           }
         }
       }
@@ -273,19 +312,28 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
 #define DMPC_FWD_MAXG 4
 #endif
     constexpr int G = ring_depth(NS + 1 + NU, DMPC_FWD_BUDGET, DMPC_FWD_MAXG);  // ping-pong banks as in the backward sweep
-    const bool row_x = lane < NX;
-    const int lane_x = row_x ? lane : NX - 1;  // other lanes re-read the last row (never used)
+    const bool row_x = lane < nx;
+    const int lane_x = row_x ? lane : nx - 1;  // other lanes re-read the last row (never used)
     float Fr[2][G][NS], fr[2][G], Kr[2][G][NU];
     bool cl[2][G][NU];
     const float *Fsafe = T > 1 ? a.F : a.x_init;  // T == 1: nothing is read through it that is used
     const float *fsafe = has_f ? a.f : a.x_init;
-    auto issue_row = [&](int t, float (&Fn)[NS], float &fn, float (&Kn)[NU], bool (&cn)[NU]) {
+    auto issue_row = [&](int t, float (&Fn)[NS], float &fn, float (&Kn)[NU], bool (&cn)[NU]) __attribute__((always_inline)) {
       t = t < T ? t : T - 1;  // branch-free, see the backward sweep
       const size_t tb = (size_t)t * B + b;
       const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
       const size_t tbF = (size_t)tF * B + b;
-      if (T > 1) load_contig<NS>(Fsafe + (tbF * NX + lane_x) * NS, Fn);
-      fn = fsafe[has_f ? tbF * NX + lane_x : 0];
+      if constexpr (PAD) {
+        const float *Fp = Fsafe + (tbF * nx + lane_x) * ns;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const int lj = logical(j);   // uniform
+          if (T > 1) Fn[j] = Fp[lj >= 0 ? lj : 0];
+        }
+      } else {
+        if (T > 1) load_contig<NS>(Fsafe + (tbF * NX + lane_x) * NS, Fn);
+      }
+      fn = fsafe[has_f ? tbF * nx + lane_x : 0];
       if constexpr (MODE == kSolve && K_LDS) {
 #pragma unroll
         for (int m = 0; m < NU; ++m) Kn[m] = kl[(t * NU + m) * KROW + kidx];
@@ -293,34 +341,36 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
         // gains from HBM: lanes < NX read Ks[t][b][m][lane], lane NS reads ks[t][b][m]
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
-          const float *p = col_aff ? (a.ks + tb * NU + m) : (a.Ks + (tb * NU + m) * NX + kidx % NX);
-          Kn[m] = *p;
+          const int mc = (!PAD || m < nu) ? m : 0;
+          const float *p = col_aff ? (a.ks + tb * nu + mc) : (a.Ks + (tb * nu + mc) * nx + (kidx < nx ? kidx : 0));
+          Kn[m] = *p;   // (PAD: fstep() discards what lies outside the problem)
         }
       }
       if constexpr (MASKED) {
 #pragma unroll
-        for (int m = 0; m < NU; ++m) cn[m] = a.mask[tb * NU + m] != 0;
+        for (int m = 0; m < NU; ++m) cn[m] = (!PAD || m < nu) && a.mask[tb * nu + (m < nu ? m : 0)] != 0;
       }
     };
-    float xv = row_x ? a.x_init[(size_t)b * NX + lane] : (col_aff ? 1.f : 0.f);
+    float xv = row_x ? a.x_init[(size_t)b * nx + lane] : (col_aff ? 1.f : 0.f);
     bool bad = false;
-    auto fstep = [&](int t, const float (&Fn)[NS], const float fn, const float (&Kn)[NU], const bool (&cn)[NU]) {
+    auto fstep = [&](int t, const float (&Fn)[NS], const float fn, const float (&Kn)[NU], const bool (&cn)[NU]) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
       float u[NU];
 #pragma unroll
       for (int m = 0; m < NU; ++m) {
-        u[m] = group_sum<L>(k_lane ? Kn[m] * xv : 0.f);  // lqr_recursion.py:177
+        const bool kv = PAD ? (m < nu && (col_aff || lane < nx)) : k_lane;
+        u[m] = group_sum<L>(kv ? Kn[m] * xv : 0.f);  // lqr_recursion.py:177
         if constexpr (MASKED) u[m] = cn[m] ? 0.f : u[m];   // :179-183
         bad = bad || !is_finite(u[m]);
       }
       bad = bad || !is_finite(xv);
       if (live) {
-        if (row_x) a.x[tb * NX + lane] = xv;
-        if (lane < NU) {
+        if (row_x) a.x[tb * nx + lane] = xv;
+        if (lane < nu) {
           float uo = u[0];
 #pragma unroll
           for (int m = 1; m < NU; ++m) uo = (lane == m) ? u[m] : uo;
-          a.u[tb * NU + lane] = uo;
+          a.u[tb * nu + lane] = uo;
         }
       }
       if (t < T - 1) {
@@ -328,12 +378,12 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
         {
           float M[NS + 1];
 #pragma unroll
-          for (int j = 0; j < NS; ++j) M[j] = Fn[j];
+          for (int j = 0; j < NS; ++j) M[j] = (!PAD || logical(j) >= 0) ? Fn[j] : 0.f;
           M[NS] = 0.f;
           Blk::dot_x(acc, xv, M);  // :189, state part
         }
 #pragma unroll
-        for (int m = 0; m < NU; ++m) acc = fmaf(Fn[NX + m], u[m], acc);  // control part (u is in every lane)
+        for (int m = 0; m < NU; ++m) acc = fmaf((!PAD || m < nu) ? Fn[NX + m] : 0.f, u[m], acc);  // control part (u is in every lane)
         if (row_x) xv = acc;
       }
     };

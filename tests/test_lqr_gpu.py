@@ -99,6 +99,65 @@ def test_other_shapes_against_oracle(shape, with_f):
     assert_close(npy(x2), xr, TOL_PRIMAL, "x fwd")
 
 
+CONTAINER_SHAPES = [(5, 1), (13, 1), (14, 1), (1, 2), (5, 2), (7, 2), (9, 2), (13, 2), (2, 3), (6, 3), (10, 3), (1, 4), (3, 4),
+                    (6, 4), (9, 4), (11, 4)]
+
+
+@pytest.mark.parametrize("dims", CONTAINER_SHAPES, ids=["%dx%d" % d for d in CONTAINER_SHAPES])
+def test_container_shapes_against_oracle(dims):
+    """shapes without a specialisation of their own run padded inside a larger register-resident kernel (solve path 7):
+    solve, gains, rollout from given gains and the clamped variant against the oracle, ragged batch"""
+    nx, nu = dims
+    B, T = 19, 7
+    lib = _lib.load()
+    assert lib.dmpc_lqr_kernel_family(nx, nu) == 4 and lib.dmpc_lqr_solve_path(T, B, nx, nu) == 7
+    for with_f in (True, False):
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=100 + nx, with_f=with_f)
+        xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        Ksr, ksr = olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        d = to_dev(p)
+        rec = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu)
+        x, u = rec.solve_recursion()
+        assert_close(npy(x), xr, TOL_PRIMAL, "x")
+        assert_close(npy(u), ur, TOL_PRIMAL, "u")
+        Ks, ks = rec.backward()
+        assert_close(npy(torch.stack(Ks)), Ksr, TOL_PRIMAL, "Ks")
+        assert_close(npy(torch.stack(ks)), ksr, TOL_PRIMAL, "ks")
+        x2, u2 = rec.forward(Ks, ks)
+        assert_close(npy(x2), xr, TOL_PRIMAL, "x fwd")
+        assert_close(npy(u2), ur, TOL_PRIMAL, "u fwd")
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7, with_f=False)
+    act = np.random.RandomState(nx * 16 + nu).rand(T, B, nu) < 0.4
+    xr, ur = ompc.lqr_active_solve(np.zeros((B, nx)), p["C"], p["c"], p["F"], None, act, T, nx, nu)
+    d = to_dev(p)
+    x, u = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
+                        u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
+    assert_close(npy(x), xr, 2e-4, "x active")
+    assert_close(npy(u), ur, 2e-4, "u active")
+    assert np.all(npy(u)[act] == 0)
+
+
+@pytest.mark.parametrize("dims", [(6, 3), (13, 2)])
+def test_container_long_horizon_and_full_batch(dims):
+    """gains through HBM (the horizon does not fit in LDS) and a batch that fills the chip, sampled against the oracle"""
+    nx, nu = dims
+    B, T = 2, 320
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=8)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    d = to_dev(p)
+    x, u = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu).solve_recursion()
+    assert_close(npy(x), xr, 5e-4, "x")
+    assert_close(npy(u), ur, 5e-4, "u")
+    B, T = 4096, 20
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=9)
+    d = to_dev(p)
+    x, u, _, _ = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)
+    idx = np.arange(0, B, 311)
+    xr, ur = olqr.lqr_solve(p["x_init"][idx], p["C"][:, idx], p["c"][:, idx], p["F"][:, idx], p["f"][:, idx], T, nx, nu)
+    assert_close(npy(x)[:, idx], xr, TOL_PRIMAL, "x")
+    assert_close(npy(u)[:, idx], ur, TOL_PRIMAL, "u")
+
+
 def test_ragged_batch_and_T_slices_of_F():
     """B not a multiple of the 16 trajectories per workgroup; F given with T slices (Boyd_lqr.py:29-32)"""
     B, T, nx, nu = 37, 6, 8, 2
