@@ -22,6 +22,7 @@ struct CostateArgs {
   // of the tiling would reduce dC, dc to (326 K floats at config 4).  Accumulated per wavefront over its trajectories and
   // timesteps, one atomic add per element and wavefront; the caller zeroes them.  dC / dc may then be nullptr.
   float *dC_sum = nullptr, *dc_sum = nullptr;
+  int nx_log = 0, nu_log = 0;   // container launches (costate_kernel<..., PAD>): the problem's own dimensions
 };
 
 // Shape dispatch (defined in kkt_api.hip).

@@ -35,7 +35,10 @@ __device__ __forceinline__ void store_contig(float *__restrict__ p, const float 
   }
 }
 
-template <int NX, int NU, int L>
+// PAD: container for a smaller problem (a.nx_log <= NX, a.nu_log <= NU; see lqr_kernel<..., PAD>): element i of tau lives in
+// lane i (state) or NX + m (control), everything outside the problem is 0, rows are stored element by element at the
+// problem's own strides.
+template <int NX, int NU, int L, bool PAD = false>
 __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   constexpr int NS = NX + NU;
   static_assert(NS <= L, "tau must fit the lane group");
@@ -51,10 +54,13 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
   const int T = a.T;
   const size_t B = (size_t)a.B;
 
-  const bool is_x = lane < NX;
-  const bool is_tau = lane < NS;
-  const int lane_x = is_x ? lane : NX - 1;    // clamped: rows/columns re-read by the idle lanes, never used
-  const int lane_t = is_tau ? lane : NS - 1;
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int i) -> int { return i < NX ? (i < nx ? i : -1) : (i - NX < nu ? nx + (i - NX) : -1); };
+  const int lrow = lane < NS ? logical(lane) : -1;
+  const bool is_x = lane < nx;
+  const bool is_tau = PAD ? lrow >= 0 : lane < NS;
+  const int lane_x = is_x ? lane : nx - 1;    // clamped: rows/columns re-read by the idle lanes, never used
+  const int lane_t = PAD ? (lrow >= 0 ? lrow : ns - 1) : (is_tau ? lane : NS - 1);   // index into [x; u]
   const float wa = 0.5f, wb = a.dC_mode == 0 ? 1.0f : 0.5f;
 
   float lam = 0.f, dlam = 0.f;  // lambda_{t+1}[lane], d_lambda_{t+1}[lane]  (lanes < NX)
@@ -66,14 +72,27 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
     float tau, dtau, ci, ri;
     float Crow[NS], Fcol[NX];
   };
-  auto load = [&](int t, Slot &s) {
+  auto load = [&](int t, Slot &s) __attribute__((always_inline)) {
     t = t < 0 ? 0 : t;  // the prefetch past t = 0 re-reads step 0 (never consumed)
     const size_t tb = (size_t)t * B + b;
     // (pointer selects, then ONE load each: `cond ? x[i] : u[j]` makes hipcc emit an exec-masked branch per load)
-    const float *tp = lane_t < NX ? a.x + tb * NX + lane_t : a.u + tb * NU + (lane_t - NX);
-    const float *dp = lane_t < NX ? a.dx + tb * NX + lane_t : a.du + tb * NU + (lane_t - NX);
+    const float *tp = lane_t < nx ? a.x + tb * nx + lane_t : a.u + tb * nu + (lane_t - nx);
+    const float *dp = lane_t < nx ? a.dx + tb * nx + lane_t : a.du + tb * nu + (lane_t - nx);
     s.tau = *tp;
     s.dtau = *dp;
+    if constexpr (PAD) {   // clamped addresses; step() discards what lies outside the problem
+      const float *Cp = a.C + (tb * ns + lane_x) * ns;
+      static_for<0, NS>([&](auto j) {
+        const int lj = logical(j.value);
+        s.Crow[j.value] = Cp[lj >= 0 ? lj : 0];
+      });
+      s.ci = a.c[tb * ns + lane_x];
+      s.ri = a.r[tb * (a.r_cols ? a.r_cols : ns) + lane_x];
+      const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+      const float *Fp = (T > 1 ? a.F : a.C) + ((size_t)tF * B + b) * nx * ns + lane_x;
+      static_for<0, NX>([&](auto k) { s.Fcol[k.value] = Fp[(k.value < nx ? k.value : 0) * ns]; });
+      return;
+    }
     load_contig<NS>(a.C + (tb * NS + lane_x) * NS, s.Crow);
     s.ci = a.c[tb * NS + lane_x];
     s.ri = a.r[tb * (a.r_cols ? a.r_cols : NS) + lane_x];
@@ -82,33 +101,50 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
 #pragma unroll
     for (int k = 0; k < NX; ++k) s.Fcol[k] = Fp[k * NS];
   };
-  auto step = [&](int t, const Slot &s) {
+  auto step = [&](int t, const Slot &s_in) __attribute__((always_inline)) {
     const size_t tb = (size_t)t * B + b;
+    Slot sp;
+    if constexpr (PAD) {
+      sp = s_in;
+      sp.tau = is_tau ? sp.tau : 0.f;
+      sp.dtau = is_tau ? sp.dtau : 0.f;
+      static_for<0, NS>([&](auto j) { sp.Crow[j.value] = logical(j.value) >= 0 ? sp.Crow[j.value] : 0.f; });
+      static_for<0, NX>([&](auto k) { sp.Fcol[k.value] = k.value < nx ? sp.Fcol[k.value] : 0.f; });
+    }
+    const Slot &s = PAD ? sp : s_in;
     const float tau = s.tau, dtau = s.dtau;
+    auto store_row = [&](float *row_base, const float (&row)[NS]) __attribute__((always_inline)) {   // PAD: the problem's columns of a row
+      static_for<0, NS>([&](auto j) {
+        const int lj = logical(j.value);
+        if (lj >= 0) row_base[lj] = row[j.value];
+      });
+    };
     // ---- dF_t and df (they use lambda_{t+1}, d_lambda_{t+1})             differentiable_lqr.py:130-133
     if (t < T - 1) {
       if (a.dF != nullptr) {
         float row[NS];  // out_sign * (dlam (x) tau + lam (x) dtau), row `lane`
         Blk::outer2(row, tau, dtau, a.out_sign * dlam, a.out_sign * lam);
-        if (live && is_x) store_contig<NS>(a.dF + (tb * NX + lane) * NS, row);
+        if constexpr (PAD) { if (live && is_x) store_row(a.dF + (tb * nx + lane) * ns, row); }
+        else if (live && is_x) store_contig<NS>(a.dF + (tb * NX + lane) * NS, row);
       }
-      if (a.df != nullptr && a.df_shift == 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+      if (a.df != nullptr && a.df_shift == 1 && live && is_x) a.df[tb * nx + lane] = a.out_sign * dlam;
     }
     // ---- dC_t, dc_t                                                          :128-129
     if (a.dC != nullptr) {
       float row[NS];  // out_sign * (wa dtau (x) tau + wb tau (x) dtau), row `lane`
       Blk::outer2(row, tau, dtau, a.out_sign * wa * dtau, a.out_sign * wb * tau);
-      if (live && is_tau) store_contig<NS>(a.dC + (tb * NS + lane) * NS, row);
+      if constexpr (PAD) { if (live && is_tau) store_row(a.dC + (tb * ns + lane_t) * ns, row); }
+      else if (live && is_tau) store_contig<NS>(a.dC + (tb * NS + lane) * NS, row);
     }
-    if (a.dc != nullptr && live && is_tau) a.dc[tb * NS + lane] = a.out_sign * dtau;
+    if (a.dc != nullptr && live && is_tau) a.dc[tb * ns + lane_t] = a.out_sign * dtau;
 
     // ---- lambda_t, d_lambda_t                                                 :92,102 / :115,124
     float nl = s.ci, ndl = a.r_sign * s.ri;
     Blk::dots2_ns(nl, ndl, s.Crow, tau, dtau);
     if (t < T - 1) Blk::dots2_nx(nl, ndl, s.Fcol, lam, dlam);
-    lam = nl;
-    dlam = ndl;
-    if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && live && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+    lam = (!PAD || is_x) ? nl : 0.f;
+    dlam = (!PAD || is_x) ? ndl : 0.f;
+    if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && live && is_x) a.df[tb * nx + lane] = a.out_sign * dlam;
   };
 
   Slot sa, sb, sc;  // two steps of loads in flight
@@ -126,7 +162,7 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
       step(t - 2, sc);
     }
   }
-  if (a.dx0 != nullptr && live && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
+  if (a.dx0 != nullptr && live && is_x) a.dx0[(size_t)b * nx + lane] = a.out_sign * dlam;
 }
 
 // Runtime-dimension version: one wavefront per trajectory, vectors in LDS (completeness path).

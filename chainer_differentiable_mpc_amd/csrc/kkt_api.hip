@@ -36,6 +36,12 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16) X(32, 8, 64)
 #endif
 
+#ifdef DMPC_EXPERIMENT_ONLY_8_2
+#define DMPC_COSTATE_CONTAINERS(X)
+#else
+#define DMPC_COSTATE_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
+#endif
+
 static bool costate_dma_disabled() {  // DMPC_NO_COSTATE_DMA=1: register-prefetch co-state kernel (A/B timing, debugging)
   static const bool off = [] { const char *e = getenv("DMPC_NO_COSTATE_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -60,6 +66,21 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
   DMPC_COSTATE_SHAPES(X)
 #undef X
+  {   // a smaller problem (nu <= 4, nx + nu <= 15) padded inside the first container that holds it (the list of lqr_api.hip)
+    static const bool off = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
+    if (!off && a.dC_sum == nullptr) {
+      CostateArgs p = a;
+      p.nx_log = nx;
+      p.nu_log = nu;
+#define X(NX_, NU_)                                                                                          \
+  if (nx <= NX_ && nu <= NU_) {                                                                              \
+    DMPC_LAUNCH_GGL((costate_kernel<NX_, NU_, 16, true>), dim3((p.B + 15) / 16), dim3(256), 0, stream, p);  \
+    return (int)hipGetLastError();                                                                           \
+  }
+      DMPC_COSTATE_CONTAINERS(X)
+#undef X
+    }
+  }
   if (nx + nu + 1 > 64) return DMPC_E_UNSUPPORTED;
   const size_t shmem = (size_t)(2 * (nx + nu) + 4 * nx) * sizeof(float);
   DMPC_LAUNCH_GGL(costate_generic_kernel, dim3(a.B), dim3(64), shmem, stream, a, CostateDims{nx, nu});

@@ -86,6 +86,18 @@ static size_t coupled_bytes(int T, int n_qp_iter) { return round_up((size_t)T * 
   X(4, 4, 16) X(8, 4, 16) X(12, 3, 16)
 #endif
 
+// Containers (mpc_backward_rec_kernel / mpc_forward_rec_kernel <..., PAD>): any smaller problem runs padded inside them
+// instead of on the runtime-dimension kernels of mpc_generic.hpp; tried in this order (same list as lqr_api.hip)
+#ifdef DMPC_EXPERIMENT_ONLY_8_2
+#define DMPC_MPC_CONTAINERS(X)
+#else
+#define DMPC_MPC_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
+#endif
+static bool mpc_container_disabled() {   // DMPC_NO_CONTAINER=1: the runtime-dimension kernels (A/B timing)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
+  return off;
+}
+
 static bool mpc_dma_disabled() {
   static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -172,6 +184,20 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   if (sel != nullptr && !(dma_ok && sel_sync != nullptr)) return DMPC_E_BADARG;   // callers ask mpc_back_dma_ok first
   DMPC_MPC_SHAPES(X)
 #undef X
+  if (!mpc_container_disabled()) {   // a smaller problem inside the first container that holds it
+    a.nx_log = nx;
+    a.nu_log = nu;
+#define X(NX_, NU_)                                                                                           \
+  if (nx <= NX_ && nu <= NU_) {                                                                               \
+    if (a.sync != nullptr)                                                                                    \
+      return launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, 16, true>), \
+                                dim3((a.B + 15) / 16), dim3(256), args1, 0, stream);                          \
+    DMPC_LAUNCH_GGL((mpc_backward_rec_kernel<NX_, NU_, 16, true>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a); \
+    return (int)hipGetLastError();                                                                            \
+  }
+    DMPC_MPC_CONTAINERS(X)
+#undef X
+  }
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
   if (nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
     void *args2[] = {&a, &nx};
@@ -263,6 +289,17 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   }
   DMPC_MPC_SHAPES(X)
 #undef X
+  if (a.dyn_kind == 0 && !mpc_container_disabled()) {
+    a.nx_log = nx;
+    a.nu_log = nu;
+#define X(NX_, NU_)                                                                                              \
+  if (nx <= NX_ && nu <= NU_) {                                                                                  \
+    DMPC_LAUNCH_GGL((mpc_forward_rec_kernel<NX_, NU_, 16, false, true>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a); \
+    return (int)hipGetLastError();                                                                               \
+  }
+    DMPC_MPC_CONTAINERS(X)
+#undef X
+  }
   if (a.dyn_kind == 0 && nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
     DMPC_LAUNCH_GGL(mpc_generic_forward_kernel, dim3(a.B), dim3(64), mpc_generic_fwd_lds_bytes(nx, nu), stream, a,
                        nx, nu);

@@ -43,10 +43,15 @@ struct MpcBackArgs {
   // and the kernel forms c_hat_t = C_t [x_t; u_t] + c_t from the C rows it holds anyway (nullptr: c is used as given)
   const float *states;
   int info_store;                       // != 0: info[b] = this sweep's flags (plain store) instead of an atomic OR
+  // container launches (PAD kernels, see lqr_kernel): the problem's own dimensions, nx_log <= NX and nu_log <= NU
+  int nx_log = 0, nu_log = 0;
 };
 
 // `block` = the workgroup's index among the 256-thread workgroups that share the batch (blockIdx.x for the kernel below)
-template <int NX, int NU, int L>
+// PAD: container for a smaller problem, as lqr_kernel<..., PAD> (lqr_kernels.hpp): rows and columns outside the problem are
+// 0, the unused controls get a unit diagonal in Quu, qu = 0 and the box [-1, 1] - their QP solution is exactly 0 and never
+// clamped, their gain rows are 0, and they add exact zeros to every sum the QP's tests are made of.
+template <int NX, int NU, int L, bool PAD = false>
 __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, const int block, const unsigned n_blocks) {
   constexpr int NS = NX + NU;
   static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
@@ -65,6 +70,11 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
   const bool has_f = a.f != nullptr;
   const bool col_aff = lane == NS;
   const int lane_c = lane < NS ? lane : NS - 1;
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int i) -> int { return i < NX ? (i < nx ? i : -1) : (i - NX < nu ? nx + (i - NX) : -1); };
+  const int lcol = lane < NS ? logical(lane) : -1;
+  const int lcol_c = lcol >= 0 ? lcol : 0;
+  const bool col_ok = col_aff || lcol >= 0;
 
   float V[NX];
 #pragma unroll
@@ -93,9 +103,32 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
     float tau;                // lane j < ns: [x_t; u_t][j] (need_expand), else 0
   };
   const bool expand = a.states != nullptr;
-  auto load = [&](int t, Slot &sl) {
+  auto load = [&](int t, Slot &sl) __attribute__((always_inline)) {
     t = t < 0 ? 0 : t;  // prefetch past t = 0: step 0 again (never consumed)
     const size_t tb = (size_t)t * B + b;
+    if constexpr (PAD) {   // clamped addresses, the same loads on every path; step() discards what lies outside the problem
+      const char *qp = reinterpret_cast<const char *>(col_aff ? a.c + tb * ns : a.C + tb * ns * ns + lcol_c);
+      const size_t qs = col_aff ? 4 : (size_t)ns * 4;
+      static_for<0, NS>([&](auto i) {
+        const int li = logical(i.value);
+        sl.Q[i.value] = *reinterpret_cast<const float *>(qp + (li >= 0 ? li : 0) * qs);
+      });
+      const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+      const size_t tbF = (size_t)tF * B + b;
+      const bool f_lane = col_aff && has_f;
+      const char *fp = reinterpret_cast<const char *>(f_lane ? a.f + tbF * nx : (T > 1 ? a.F : a.C) + tbF * nx * ns + lcol_c);
+      const size_t fs = f_lane ? 4 : (size_t)ns * 4;
+      static_for<0, NX>([&](auto k) { sl.Fc[k.value] = *reinterpret_cast<const float *>(fp + (k.value < nx ? k.value : 0) * fs); });
+      static_for<0, NU>([&](auto m) {
+        const int mc = m.value < nu ? m.value : 0;
+        sl.uc[m.value] = a.controls[tb * nu + mc];
+        sl.lb[m.value] = a.lower[tb * nu + mc];
+        sl.ub[m.value] = a.upper[tb * nu + mc];
+      });
+      sl.tau = 0.f;
+      if (expand && lcol >= 0) sl.tau = lane < NX ? a.states[tb * nx + lane] : a.controls[tb * nu + (lane - NX)];
+      return;
+    }
     // per-lane base and stride: lane ns walks c / f, the others a column of C / F (one load per element, no branches)
     const char *qp = reinterpret_cast<const char *>(col_aff ? a.c + tb * NS : a.C + tb * NS * NS + lane_c);
     const size_t qs = col_aff ? 4 : NS * 4;
@@ -124,12 +157,18 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
     if (expand && lane < NS) sl.tau = lane < NX ? a.states[tb * NX + lane] : a.controls[tb * NU + (lane - NX)];
   };
 
-  auto step = [&](int t, const Slot &sl) {
+  auto step = [&](int t, const Slot &sl) __attribute__((always_inline)) {
     const size_t tb = (size_t)t * B + b;
     DMPC_MSTAMP(6);
     float Q[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) Q[i] = sl.Q[i];
+    if constexpr (PAD) {
+      static_for<0, NS>([&](auto i) {
+        const bool row = logical(i.value) >= 0;
+        Q[i.value] = (row && col_ok) ? Q[i.value] : ((i.value >= NX && lane == i.value) ? 1.f : 0.f);
+      });
+    }
 #ifdef DMPC_MPC_TIMING
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMPC_MPC_TIMING_VMCNT) : "memory");
     DMPC_MSTAMP(0);
@@ -145,6 +184,7 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
       float Fc[NX];
 #pragma unroll
       for (int k = 0; k < NX; ++k) Fc[k] = (col_aff && !has_f) ? 0.f : sl.Fc[k];
+      if constexpr (PAD) static_for<0, NX>([&](auto k) { Fc[k.value] = (k.value < nx && col_ok) ? Fc[k.value] : 0.f; });
       float W[NX];
 #pragma unroll
       for (int i = 0; i < NX; ++i) W[i] = col_aff ? V[i] : 0.f;
@@ -164,6 +204,10 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
       lo[m] = sl.lb[m] - sl.uc[m];  // :136-138
       hi[m] = sl.ub[m] - sl.uc[m];
     }
+    if constexpr (PAD) static_for<0, NU>([&](auto m) {
+      lo[m.value] = m.value < nu ? lo[m.value] : -1.f;
+      hi[m.value] = m.value < nu ? hi[m.value] : 1.f;
+    });
     // k_t: box QP, warm-started from the later timestep                        :141-146
     PnqpResult<NU> qp;
     float kt[NU];
@@ -192,8 +236,9 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
     if (live) {
 #pragma unroll
       for (int m = 0; m < NU; ++m) {
-        if (col_aff) a.ks[tb * NU + m] = Kt[m];
-        else if (lane < NX) a.Ks[(tb * NU + m) * NX + lane] = Kt[m];
+        if (PAD && m >= nu) break;   // uniform
+        if (col_aff) a.ks[tb * nu + m] = Kt[m];
+        else if (lane < nx) a.Ks[(tb * nu + m) * nx + lane] = Kt[m];
       }
     }
     DMPC_MSTAMP(4);
@@ -239,9 +284,9 @@ __device__ __forceinline__ void mpc_backward_rec_body(const MpcBackArgs &a, cons
 #endif
 }
 
-template <int NX, int NU, int L>
+template <int NX, int NU, int L, bool PAD = false>
 __global__ __launch_bounds__(256) void mpc_backward_rec_kernel(const MpcBackArgs a) {
-  mpc_backward_rec_body<NX, NU, L>(a, blockIdx.x, gridDim.x);
+  mpc_backward_rec_body<NX, NU, L, PAD>(a, blockIdx.x, gridDim.x);
 }
 
 // The pendulum of env_dx/pendulum.py:84-98 (simple model), state (cos th, sin th, dth), one torque.  One definition
@@ -356,6 +401,7 @@ struct MpcFwdArgs {
   // and the accepted one is copied out instead of being rolled out a second time; 0 = no such buffer was given
   int traj_in_lds;
   const int32_t *info_in;                // [B] flags to merge into info (the backward sweep's, when it ran ahead of `done`)
+  int nx_log = 0, nu_log = 0;            // container launches (PAD): the problem's own dimensions
 };
 
 // chunks of one wave-step of the forward kernel's LDS-DMA ring (DMA variant):
@@ -376,11 +422,14 @@ struct MpcFwdDmaLayout {
 // per-lane gather LDS-DMA, DB - 1 steps ahead (the scheme of mpc_dma_kernels.hpp) instead of three compiler-managed
 // register banks.  Both variants run the line search as a WAVE-UNIFORM loop: a pass is executed by every lane while
 // any trajectory of the wavefront still searches, and the trajectories that are done neither store nor commit.
-template <int NX, int NU, int L, bool DMA = false>
+// PAD (register-bank variant, LinDx): container for a smaller problem - element i of tau lives in lane i (state) or NX + m
+// (control), rows and columns outside the problem are 0, the unused controls stay 0 inside the box [-1, 1].
+template <int NX, int NU, int L, bool DMA = false, bool PAD = false>
 __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a) {
   constexpr int NS = NX + NU;
   static_assert(NS + 1 <= L, "augmented columns must fit the lane group");
   static_assert(!DMA || L == 16, "the ring is laid out for four trajectories per wavefront");
+  static_assert(!(DMA && PAD), "containers take their inputs through the register banks");
   constexpr int GPB = 256 / L;
   using G = Group<L>;
   using Lay = MpcFwdDmaLayout<NX, NU>;
@@ -394,12 +443,16 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   const int T = a.T;
   const size_t B = (size_t)a.B;
   const bool has_f = a.f != nullptr;
-  const bool is_x = lane < NX;
-  const bool is_tau = lane < NS;
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int i) -> int { return i < NX ? (i < nx ? i : -1) : (i - NX < nu ? nx + (i - NX) : -1); };
+  const int lrow = lane < NS ? logical(lane) : -1;   // this lane's element of tau / row of C
+  const bool is_x = lane < nx;
+  const bool is_tau = PAD ? lrow >= 0 : lane < NS;
+  const bool is_u = lane >= NX && lane - NX < nu;
   const bool col_aff = lane == NS;
   const bool k_lane = is_x || col_aff;
-  const int lane_x = is_x ? lane : NX - 1;
-  const int lane_t = is_tau ? lane : NS - 1;
+  const int lane_x = is_x ? lane : nx - 1;
+  const int lane_t = PAD ? (lrow >= 0 ? lrow : ns - 1) : (is_tau ? lane : NS - 1);
 
   // OLD_COST of (states, controls) (mpc_step.py:191) is accumulated during the first pass from the same rows of C.
   // The test `current_cost > OLD_COST` (:196,266) is NOT taken on the two rounded totals: near a fixed point their
@@ -417,9 +470,34 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   };
   using Blk = RiccatiBlocks<NX, NU, L>;
   const bool lin = a.dyn_kind == 0;
-  auto load = [&](int t, Slot &sl) {
+  auto load = [&](int t, Slot &sl) __attribute__((always_inline)) {
     t = t < T ? t : T - 1;  // prefetch past the horizon: the last step again (never consumed)
     const size_t tb = (size_t)t * B + b;
+    if constexpr (PAD) {   // clamped addresses; step() discards what lies outside the problem
+      sl.xt = a.states[tb * nx + lane_x];
+      static_for<0, NU>([&](auto m) {
+        const int mc = m.value < nu ? m.value : 0;
+        const float *kp = col_aff ? (a.ks + tb * nu + mc) : (a.Ks + (tb * nu + mc) * nx + lane_x);
+        sl.kv[m.value] = *kp;
+        sl.uc[m.value] = a.controls[tb * nu + mc];
+        sl.lb[m.value] = a.lower[tb * nu + mc];
+        sl.ub[m.value] = a.upper[tb * nu + mc];
+      });
+      const float *Cp = a.C + (tb * ns + lane_t) * ns;
+      const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
+      const size_t tbF = (size_t)tF * B + b;
+      const float *Fp = (T > 1 ? a.F : a.C) + (tbF * nx + lane_x) * ns;
+      static_for<0, NS>([&](auto j) {
+        const int lj = logical(j.value);
+        sl.Crow[j.value] = Cp[lj >= 0 ? lj : 0];
+        sl.Frow[j.value] = Fp[lj >= 0 ? lj : 0];
+      });
+      sl.Crow[NS] = 0.f;
+      sl.Frow[NS] = 0.f;
+      sl.ci = a.c[tb * ns + lane_t];
+      sl.fi = has_f ? a.f[tbF * nx + lane_x] : 0.f;
+      return;
+    }
     sl.xt = a.states[tb * NX + lane_x];
 #pragma unroll
     for (int m = 0; m < NU; ++m) {
@@ -528,11 +606,29 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
   bool searching = a.ls_cap > 0;   // this trajectory's search goes on                      :196
   for (int pass_idx = 0; __any(searching); ++pass_idx) {
     float xh = 0.f;                                            // new_x[0] = states[0]     :198
-    if constexpr (!DMA) xh = is_x ? a.states[(size_t)b * NX + lane] : 0.f;   // (DMA: from the ring's first slot, below)
+    if constexpr (!DMA) xh = is_x ? a.states[(size_t)b * nx + lane] : 0.f;   // (DMA: from the ring's first slot, below)
     float cost_p = 0.f, old_p = 0.f;
     float delta = 0.f;                  // current_cost - OLD_COST, summed per timestep
-    auto step = [&](int t, const Slot &sl) {
+    auto step = [&](int t, const Slot &sl_in) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
+      Slot slp;
+      if constexpr (PAD) {   // the slot with everything outside the problem replaced: zeros, and the box [-1, 1] around 0
+        slp = sl_in;
+        static_for<0, NU>([&](auto m) {
+          const bool ok = m.value < nu;
+          slp.kv[m.value] = ok ? slp.kv[m.value] : 0.f;
+          slp.uc[m.value] = ok ? slp.uc[m.value] : 0.f;
+          slp.lb[m.value] = ok ? slp.lb[m.value] : -1.f;
+          slp.ub[m.value] = ok ? slp.ub[m.value] : 1.f;
+        });
+        static_for<0, NS>([&](auto j) {
+          const bool ok = logical(j.value) >= 0;
+          slp.Crow[j.value] = ok ? slp.Crow[j.value] : 0.f;
+          slp.Frow[j.value] = ok ? slp.Frow[j.value] : 0.f;
+        });
+        slp.xt = is_x ? slp.xt : 0.f;
+      }
+      const Slot &sl = PAD ? slp : sl_in;
       const float xt = is_x ? sl.xt : 0.f;
       const float z = is_x ? (xh - xt) : (col_aff ? alpha : 0.f);  // [dx ; alpha] against [K_t | k_t]
       float un[NU];
@@ -562,10 +658,10 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       float obj = 0.f;
       if (a.objs != nullptr) obj = group_sum<L>(obj_l);
       if (live && searching) {  // outputs are overwritten by later passes; the last one is the accepted one
-        if (is_x) a.x[tb * NX + lane] = xh;
-        else if (lane < NS) a.u[tb * NU + (lane - NX)] = tau;
+        if (is_x) a.x[tb * nx + lane] = xh;
+        else if (is_u) a.u[tb * nu + (lane - NX)] = tau;
         if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
-        if (a.u_first != nullptr && pass_idx == 0 && lane >= NX && lane < NS) a.u_first[tb * NU + (lane - NX)] = tau;
+        if (a.u_first != nullptr && pass_idx == 0 && is_u) a.u_first[tb * nu + (lane - NX)] = tau;
       }
       if (t < T - 1 && !lin) {  // built-in pendulum (cos th, sin th, dth), torque -> next   pendulum.py:84-98
         if constexpr (NX == 3 && NU == 1) {

@@ -57,6 +57,26 @@ def test_strict_math_variant_against_oracle(shape):
     assert np.abs(dC - np.swapaxes(dC, 2, 3)).max() <= 1e-6 * max(1.0, np.abs(dC).max())
 
 
+@pytest.mark.parametrize("dims", [(3, 3), (6, 3), (5, 1), (13, 2), (9, 4), (14, 1), (2, 4), (10, 3)], ids=lambda d: "%dx%d" % d)
+@pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
+def test_container_shapes_against_oracle(dims, strict):
+    """shapes without a specialisation: the second solve and the co-state sweep run padded inside a container kernel"""
+    nx, nu = dims
+    B, T = 21, 6
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=40 + nx)
+    rng = np.random.RandomState(nx * 17 + nu)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu, strict_math=strict)
+    d = to_dev(p)
+    node = DiffLqr(T, B, nx, nu, strict_math=strict)
+    node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for got, want, key in zip(out, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)
+
+
 def test_autograd_through_lqrnet_reproduces_the_notebook_anchor():
     """examples/LQRnet.ipynb:184 - loss 0.661925 at iteration 0, dynamics mse 4.774785 after the first
     RMSprop step - with forward AND backward on the HIP path, driven by torch.autograd."""
