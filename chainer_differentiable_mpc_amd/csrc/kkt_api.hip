@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
 
 #ifdef DMPC_EXPERIMENT_ONLY_8_2
 #define DMPC_COSTATE_CONTAINERS(X)
+#define DMPC_COSTATE_WAVE_CONTAINERS(X)
 #else
+#define DMPC_COSTATE_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)
 #define DMPC_COSTATE_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
 #endif
 
@@ -66,7 +68,7 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
   DMPC_COSTATE_SHAPES(X)
 #undef X
-  {   // a smaller problem (nu <= 4, nx + nu <= 15) padded inside the first container that holds it (the list of lqr_api.hip)
+  {   // a problem without a specialisation padded inside the first container that holds it (the lists of lqr_api.hip)
     static const bool off = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
     if (!off && a.dC_sum == nullptr) {
       CostateArgs p = a;
@@ -78,6 +80,13 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
     return (int)hipGetLastError();                                                                           \
   }
       DMPC_COSTATE_CONTAINERS(X)
+#undef X
+#define X(NX_, NU_)                                                                                          \
+  if (nx <= NX_ && nu <= NU_) {   /* wider: a wavefront per trajectory */                                     \
+    DMPC_LAUNCH_GGL((costate_kernel<NX_, NU_, 64, true>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p);     \
+    return (int)hipGetLastError();                                                                           \
+  }
+      DMPC_COSTATE_WAVE_CONTAINERS(X)
 #undef X
     }
   }

@@ -269,12 +269,40 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
 #endif
 
+// ... and the wavefront-per-trajectory kernels take what is larger, up to 32 states and 8 controls
+#if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2)
+#define DMPC_LQR_WAVE_CONTAINERS(X)
+#else
+#define DMPC_LQR_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)
+#endif
+
 static bool has_container(int nx, int nu) {
 #define X(NX_, NU_) \
   if (nx <= NX_ && nu <= NU_) return true;
   DMPC_LQR_CONTAINERS(X)
+  DMPC_LQR_WAVE_CONTAINERS(X)
 #undef X
   return false;
+}
+
+// a wider problem (up to 32 states, 8 controls) inside a wavefront-per-trajectory instance: sweep on the matrix cores
+// (lqr_wave_mfma_backward<..., PAD>), gains through HBM, then the forward-only container kernel
+template <int NX, int NU>
+static int launch_lqr_wave_container(int mode, int nx, int nu, const LqrArgs &a0, hipStream_t stream) {
+  LqrArgs a = a0;
+  a.nx_log = nx;
+  a.nu_log = nu;
+  const bool masked = a.mask != nullptr;
+  if (mode != kForwardOnly) {
+    if (a.Ks == nullptr) { a.Ks = a.wsK; a.ks = a.wsk; }
+    if (a.Ks == nullptr) return DMPC_E_WORKSPACE;
+    const int rc = launch_lqr_wave_container_sweep(NX, NU, masked, a, stream);
+    if (rc != 0 || mode == kBackwardOnly) return rc;
+  }
+  const dim3 grid((a.B + 3) / 4), block(256);
+  if (masked) DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, 64, true, kForwardOnly, false, true>), grid, block, 0, stream, a);
+  else DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, 64, false, kForwardOnly, false, true>), grid, block, 0, stream, a);
+  return (int)hipGetLastError();
 }
 
 static int lqr_family(int nx, int nu) {
@@ -333,6 +361,10 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
 #define X(NX_, NU_) \
   if (nx <= NX_ && nu <= NU_) return launch_lqr_container<NX_, NU_>(mode, nx, nu, a, stream);
     DMPC_LQR_CONTAINERS(X)
+#undef X
+#define X(NX_, NU_) \
+  if (nx <= NX_ && nu <= NU_) return launch_lqr_wave_container<NX_, NU_>(mode, nx, nu, a, stream);
+    DMPC_LQR_WAVE_CONTAINERS(X)
 #undef X
   }
   if (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) return launch_lqr_generic(mode, nx, nu, a, stream);

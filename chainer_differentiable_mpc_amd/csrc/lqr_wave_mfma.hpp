@@ -227,8 +227,12 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
 #ifndef DMPC_WAVE_OCC
 #define DMPC_WAVE_OCC 2    // wavefronts per SIMD the register budget is set for (experiments: 3 -> 168 registers)
 #endif
-template <int NX, int NU, bool MASKED, bool ROLLOUT>
+// PAD: container for a smaller problem (a.nx_log <= NX, a.nu_log <= NU; lqr_kernel<..., PAD> of lqr_kernels.hpp has the
+// argument): rows by buffer loads at the problem's own strides, columns outside it out of range (= 0), a unit diagonal for
+// the unused controls; sweep only (the rollout is the forward-only container kernel).
+template <int NX, int NU, bool MASKED, bool ROLLOUT, bool PAD = false>
 __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void lqr_wave_mfma_backward(const LqrArgs a) {
+  static_assert(!(PAD && ROLLOUT), "containers roll out in a launch of their own");
   constexpr int NS = NX + NU, AFF = NS;
   static_assert(NX % 4 == 0 && NU % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
   constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4, TU = NU / 4;
@@ -245,7 +249,10 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
   const bool col_aff = lane == AFF;
   const bool k_lane = lane < NX || col_aff;
   const float eaff = col_aff ? 1.f : 0.f;
-  const int voff_col = lane < NS ? lane * 4 : kOutOfRange;                  // column `lane` of a row of C / F
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int i) -> int { return i < NX ? (i < nx ? i : -1) : (i - NX < nu ? nx + (i - NX) : -1); };
+  const int lcol = lane < NS ? logical(lane) : -1;
+  const int voff_col = (PAD ? lcol >= 0 : lane < NS) ? (PAD ? lcol : lane) * 4 : kOutOfRange;   // this lane's column of a row of C / F
   float *Ks = a.Ks != nullptr ? a.Ks : a.wsK;
   float *ks = a.Ks != nullptr ? a.ks : a.wsk;
   int info_bits = 0;
@@ -271,6 +278,25 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
   auto fetch_cost = [&](int t, Bank &k) {
     if (t < 0) return;   // uniform
     const size_t tb = (size_t)t * B + b;
+    if constexpr (PAD) {
+      const __amdgpu_buffer_rsrc_t rc = wave_rsrc(a.C + tb * ns * ns, ns * ns * 4);
+      static_for<0, NS>([&](auto i) {
+        const int li = logical(i.value);   // uniform
+        float v = (i.value >= NX && lane == i.value) ? 1.f : 0.f;   // (row of an unused control: the unit diagonal)
+        if (li >= 0) {
+          v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, voff_col, li * ns * 4, 0));
+          if (col_aff) v = a.c[tb * ns + li];
+        }
+        k.Q4[i.value / 4][i.value % 4] = v;
+      });
+      if constexpr (MASKED) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int m = 0; m < NU; ++m) bits |= (m < nu && a.mask[tb * nu + (m < nu ? m : 0)] != 0 ? 1u : 0u) << m;
+        k.act = __builtin_amdgcn_readfirstlane(bits);
+      }
+      return;
+    }
     const __amdgpu_buffer_rsrc_t rc = wave_rsrc(a.C + tb * NS * NS, NS * NS * 4);
     static_for<0, NS>([&](auto i) { k.Q4[i.value / 4][i.value % 4] = wave_load<i.value * NS * 4>(rc, voff_col); });
     if (col_aff) {   // the affine column: c_t is a contiguous run, fetched by lane ns alone
@@ -288,6 +314,18 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
   auto fetch_dyn = [&](int t, Bank &k) {
     if (t < 0 || t >= T - 1) return;   // uniform; there is no F_{T-1}
     const size_t tb = (size_t)t * B + b;
+    if constexpr (PAD) {
+      const __amdgpu_buffer_rsrc_t rf = wave_rsrc(a.F + tb * nx * ns, nx * ns * 4);
+      static_for<0, NX>([&](auto r) {
+        float v = 0.f;
+        if (r.value < nx) {   // uniform
+          v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, voff_col, r.value * ns * 4, 0));
+          if (col_aff) v = has_f ? a.f[tb * nx + r.value] : 0.f;
+        }
+        k.Fc[r.value] = v;
+      });
+      return;
+    }
     const __amdgpu_buffer_rsrc_t rf = wave_rsrc(a.F + tb * NX * NS, NX * NS * 4);
     static_for<0, NX>([&](auto r) { k.Fc[r.value] = wave_load<r.value * NS * 4>(rf, voff_col); });
     if (col_aff && has_f) {
@@ -451,11 +489,14 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
     float Kt[NU];
 #pragma unroll
     for (int m = 0; m < NU; ++m) Kt[m] = -Kr[m];
-    if (k_lane && live) {
-      float *kp = col_aff ? ks + tb * NU : Ks + tb * NU * NX + lane;
-      const int kstride = col_aff ? 1 : NX;
+    if (k_lane && live && (!PAD || col_aff || lane < nx)) {
+      float *kp = col_aff ? ks + tb * nu : Ks + tb * nu * nx + lane;
+      const int kstride = col_aff ? 1 : nx;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) kp[m * kstride] = Kt[m];
+      for (int m = 0; m < NU; ++m) {
+        if (PAD && m >= nu) break;   // uniform
+        kp[m * kstride] = Kt[m];
+      }
     }
     DMPC_STAMP(4);
     if (t > 0) {
@@ -484,6 +525,18 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
     }
   };
 
+#if !DMPC_WAVE_PREFETCH
+  if constexpr (PAD) {
+    Bank kp;
+    for (int t = T - 1; t >= 0; --t) {
+      fetch_cost(t, kp);
+      fetch_dyn(t, kp);
+      step(t, kp, kp);
+    }
+    if (a.info != nullptr && live && info_bits != 0) atomicOr(&a.info[b], info_bits);
+    return;
+  }
+#endif
 #if DMPC_WAVE_DMA && !DMPC_WAVE_PREFETCH
   Bank ka;
 #pragma unroll

@@ -48,8 +48,9 @@ def test_dispatch_table_and_workspace_queries():
     assert lib.dmpc_lqr_kernel_family(32, 8) == 2       # wave kernel
     assert lib.dmpc_lqr_kernel_family(5, 3) == 4        # padded into a container (the (8,4) kernel)
     assert lib.dmpc_lqr_kernel_family(13, 2) == 4 and lib.dmpc_lqr_kernel_family(11, 4) == 4
-    assert lib.dmpc_lqr_kernel_family(5, 5) == 3        # runtime-dimension kernel
-    assert lib.dmpc_lqr_kernel_family(20, 6) == 3
+    assert lib.dmpc_lqr_kernel_family(5, 5) == 4 and lib.dmpc_lqr_kernel_family(20, 6) == 4   # inside the (16,8) / (32,8) wave kernels
+    assert lib.dmpc_lqr_kernel_family(40, 4) == 3       # runtime-dimension kernel
+    assert lib.dmpc_lqr_kernel_family(10, 9) == 3
     assert lib.dmpc_lqr_kernel_family(60, 10) == _lib.E_UNSUPPORTED
     assert lib.dmpc_lqr_workspace_bytes(50, 4096, 8, 2) == 50 * 4096 * 2 * 12 * 4     # gain rows of 12 floats (path 6)
     assert lib.dmpc_lqr_workspace_bytes(0, 1, 1, 1) == 0
@@ -69,7 +70,8 @@ def test_solve_path_selection_is_host_logic():
     assert lib.dmpc_lqr_solve_path(20, 1024, 3, 1) == 3   # nx = 3 does not tile the f area: ring variant
     assert lib.dmpc_lqr_solve_path(50, 65536, 32, 8) == 5   # one wavefront per trajectory, MFMA backward sweep
     assert lib.dmpc_lqr_solve_path(10, 16, 5, 3) == 7       # a container: the (8,4) kernel, padded by its loads
-    assert lib.dmpc_lqr_solve_path(10, 16, 20, 6) == 0      # the runtime-dimension kernel
+    assert lib.dmpc_lqr_solve_path(10, 16, 20, 6) == 7      # ... the (32,8) wavefront-per-trajectory kernels
+    assert lib.dmpc_lqr_solve_path(10, 16, 40, 4) == 0      # the runtime-dimension kernel
     assert lib.dmpc_lqr_solve_path(10, 16, 60, 10) == _lib.E_UNSUPPORTED
 
 

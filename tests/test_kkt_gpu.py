@@ -57,7 +57,8 @@ def test_strict_math_variant_against_oracle(shape):
     assert np.abs(dC - np.swapaxes(dC, 2, 3)).max() <= 1e-6 * max(1.0, np.abs(dC).max())
 
 
-@pytest.mark.parametrize("dims", [(3, 3), (6, 3), (5, 1), (13, 2), (9, 4), (14, 1), (2, 4), (10, 3)], ids=lambda d: "%dx%d" % d)
+@pytest.mark.parametrize("dims", [(3, 3), (6, 3), (5, 1), (13, 2), (9, 4), (14, 1), (2, 4), (10, 3), (5, 5), (16, 4), (20, 6), (31, 7)],
+                         ids=lambda d: "%dx%d" % d)
 @pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
 def test_container_shapes_against_oracle(dims, strict):
     """shapes without a specialisation: the second solve and the co-state sweep run padded inside a container kernel"""

@@ -137,6 +137,42 @@ def test_container_shapes_against_oracle(dims):
     assert np.all(npy(u)[act] == 0)
 
 
+WAVE_CONTAINER_SHAPES = [(5, 5), (3, 8), (12, 4), (16, 4), (10, 6), (16, 8), (15, 7), (20, 6), (24, 8), (31, 7), (17, 1), (32, 3)]
+
+
+@pytest.mark.parametrize("dims", WAVE_CONTAINER_SHAPES, ids=["%dx%d" % d for d in WAVE_CONTAINER_SHAPES])
+def test_wide_container_shapes_against_oracle(dims):
+    """up to 32 states and 8 controls: padded inside the wavefront-per-trajectory kernels ((16,8) or (32,8) instance; sweep
+    on the matrix cores, then the forward-only container kernel) - solve, gains, rollout, the clamped variant"""
+    nx, nu = dims
+    B, T = 7, 6
+    lib = _lib.load()
+    assert lib.dmpc_lqr_kernel_family(nx, nu) == 4 and lib.dmpc_lqr_solve_path(T, B, nx, nu) == 7
+    for with_f in (True, False):
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=200 + nx, with_f=with_f)
+        xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        Ksr, ksr = olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        d = to_dev(p)
+        rec = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu)
+        x, u = rec.solve_recursion()
+        assert_close(npy(x), xr, TOL_PRIMAL, "x")
+        assert_close(npy(u), ur, TOL_PRIMAL, "u")
+        Ks, ks = rec.backward()
+        assert_close(npy(torch.stack(Ks)), Ksr, TOL_PRIMAL, "Ks")
+        assert_close(npy(torch.stack(ks)), ksr, TOL_PRIMAL, "ks")
+        x2, u2 = rec.forward(Ks, ks)
+        assert_close(npy(x2), xr, TOL_PRIMAL, "x fwd")
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7, with_f=False)
+    act = np.random.RandomState(nx * 16 + nu).rand(T, B, nu) < 0.4
+    xr, ur = ompc.lqr_active_solve(np.zeros((B, nx)), p["C"], p["c"], p["F"], None, act, T, nx, nu)
+    d = to_dev(p)
+    x, u = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
+                        u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
+    assert_close(npy(x), xr, 2e-4, "x active")
+    assert_close(npy(u), ur, 2e-4, "u active")
+    assert np.all(npy(u)[act] == 0)
+
+
 @pytest.mark.parametrize("dims", [(6, 3), (13, 2)])
 def test_container_long_horizon_and_full_batch(dims):
     """gains through HBM (the horizon does not fit in LDS) and a batch that fills the chip, sampled against the oracle"""
