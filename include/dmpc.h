@@ -50,7 +50,9 @@ const char *dmpc_source_hash(void);
 int dmpc_last_kernel_name(char *buf, size_t buf_bytes);
 
 /* Which kernel family a shape dispatches to: 1 = DPP row kernel (16 lanes / trajectory),
- * 2 = wave kernel (64 lanes / trajectory), 3 = generic LDS kernel, <0 unsupported. */
+ * 2 = wave kernel (64 lanes / trajectory), 3 = generic LDS kernel (runtime dimensions),
+ * 4 = a container: the shape has no specialisation of its own and runs padded by the loads inside a larger kernel of
+ *     family 1 (nu <= 4, nx + nu <= 15) or 2 (up to 32 states, 8 controls),  <0 unsupported. */
 int dmpc_lqr_kernel_family(int nx, int nu);
 
 /* Which kernel a plain (unmasked) dmpc_lqr_solve of this size runs (diagnostics, benchmark labelling):
@@ -60,7 +62,9 @@ int dmpc_lqr_kernel_family(int nx, int nu);
  *   5 lqr_wave_mfma_backward (one wavefront per trajectory, e.g. (32,8): MFMA backward sweep, then the same wavefront
  *     rolls its trajectory out)
  *   6 lqr_asm_kernel, ring, gain rows through the workspace (horizons whose gain rows do not fit in LDS: T > 74 at
- *     (8,2); needs `ws`)   <0 unsupported */
+ *     (8,2); needs `ws`)
+ *   7 a container: lqr_kernel<..., PAD> of a larger shape, or lqr_wave_mfma_backward<..., PAD> + the forward-only
+ *     container kernel (needs `ws` unless the caller takes the gains)        <0 unsupported */
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
 
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active
