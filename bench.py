@@ -271,10 +271,16 @@ def secondary_metrics(device, d_headline):
     sweep_b = 4 * (ns * ns + ns + nx * ns + 3 * nu + nx) + 4 * (nu * nx + nu)
     pass_b = 4 * (ns * ns + ns + nx * ns + nx + nu * nx + 4 * nu + nx) + 4 * ns
     mpc_bytes = B * T * (sweep_b + passes * pass_b + 4 * (1 + nu))
+    # read-once: every input array once (C, c, F, f, u, lower, upper, x) + the outputs (K, k, x, u, objs, u_first) - what a
+    # step that kept everything on chip between its sweep and its line-search passes would move
+    once_b = 4 * (ns * ns + ns + nx * ns + nx + 3 * nu + nx) + 4 * (nu * nx + nu) + 4 * ns + 4 * (1 + nu)
     out["mpc_step_forward_cfg3"] = {"what": "MPCstep.forward (Taylor re-centring, backward_rec with one PNQP per timestep, "
                                             "line search) B=4096 T=50 (8,2), bounds +-0.5", "us": t * 1e6,
                                     "timestep_solves_per_s": B * T / t, "line_search_passes_mean": passes,
-                                    "algorithmic_bytes": int(mpc_bytes), "frac_hbm": mpc_bytes / t / 1e9 / HBM_PEAK_GBS}
+                                    "qp_passes_per_timestep_mean": float(nqp.float().mean()) / T,
+                                    "algorithmic_bytes": int(mpc_bytes), "frac_hbm": mpc_bytes / t / 1e9 / HBM_PEAK_GBS,
+                                    "read_once_bytes": int(B * T * once_b),
+                                    "frac_hbm_read_once": B * T * once_b / t / 1e9 / HBM_PEAK_GBS}
     del ws, Ks, ks, xo, uo, u1, objs
     # (iv) config 2: pendulum box-DDP, B=128, T=20, 10 iLQR iterations; (v) config 4: imitation step at B=1024
     dx = PendulumDx()

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .lqr_recursion import (_as_tensor, _device_of, _workspace, saving_solve_available, solve_device,
+from .lqr_recursion import (_as_tensor, _device_of, _workspace, saving_solve_available, solve_device, solve_device_f64,
                             solve_saving_device)
 from .util import expand_time_batch
 
@@ -97,10 +97,36 @@ class _DiffLqrFn(torch.autograd.Function):
         return tuple(out) + (None,)
 
 
+def kkt_grad_device_f64(C, c, F, x, u, grad_x, grad_u, T, n_state, n_ctrl, strict_math=False, info=None):
+    """The KKT gradient in float64 on float64 device tensors (`dmpc_lqr_kkt_grad_f64`) -> (d_x_init, dC, dc, dF, df)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = C.device
+    B = C.shape[1]
+    nx, nu = n_state, n_ctrl
+    ns = nx + nu
+    f64 = dict(dtype=torch.float64, device=dev)
+    dx0, dC, dc = torch.empty((B, nx), **f64), torch.empty((T, B, ns, ns), **f64), torch.empty((T, B, ns), **f64)
+    dF, df = torch.empty((T - 1, B, nx, ns), **f64), torch.empty((T - 1, B, nx), **f64)
+    need = lib.dmpc_lqr_f64_workspace_bytes(T, B, nx, nu)
+    ws = _workspace(need, dev)
+    with _lib.guard(dev):
+        rc = lib.dmpc_lqr_kkt_grad_f64(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(x), _lib.ptr(u),
+                                       _lib.ptr(grad_x), _lib.ptr(grad_u), 1 if strict_math else 0, _lib.ptr(dx0), _lib.ptr(dC),
+                                       _lib.ptr(dc), _lib.ptr(dF), _lib.ptr(df), _lib.ptr(ws), need, _lib.ptr(info),
+                                       _lib.stream_ptr(dev))
+    _lib.check(rc, "dmpc_lqr_kkt_grad_f64")
+    return dx0, dC, dc, dF, df
+
+
 class DiffLqr:
     """Differentiable LQR (module 1 of Amos et al. 2018).  lqr/differentiable_lqr.py:21-142."""
 
-    def __init__(self, T, n_batch, n_state, n_ctrl, strict_math=False, save_gains=True):
+    def __init__(self, T, n_batch, n_state, n_ctrl, strict_math=False, save_gains=True, precision="float32"):
+        # precision="float64" (not in the reference's signature): forward and backward on the float64 kernels - the
+        # reference's own precision, an order of magnitude slower
+        assert precision in ("float32", "float64")
+        self.precision = precision
         self.T = int(T)
         self.n_batch = int(n_batch)
         self.n_state = int(n_state)
@@ -130,6 +156,13 @@ class DiffLqr:
         if f is not None:
             assert list(f.shape) == [T - 1, B, nx], " f dim mismatch"
         dev = _device_of(C, c, F, x_init)
+        if self.precision == "float64":
+            d = [None if t is None else t.detach().to(device=dev, dtype=torch.float64).contiguous() for t in (x_init, C, c, F, f)]
+            self.info = torch.zeros(B, dtype=torch.int32, device=dev)
+            x, u, _, _ = solve_device_f64(d[1], d[2], d[3], d[4], d[0], None, T, nx, nu, info=self.info)
+            self._retained = dict(x_init=d[0], C=d[1], c=d[2], F=d[3], x=x, u=u, saved=None, out_dtype=C.dtype,
+                                  out_device=C.device, versions=tuple(t._version for t in d[:4]))
+            return x.to(device=C.device, dtype=C.dtype), u.to(device=C.device, dtype=C.dtype)
         d = [_lib.f32c(t.detach() if t is not None else None, dev) for t in (x_init, C, c, F, f)]
         saved = None
         got = None
@@ -178,6 +211,12 @@ class DiffLqr:
         T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
         grad_x, grad_u = grad_outputs
         dev = r["C"].device
+        if self.precision == "float64":
+            g64 = lambda g, n: (_as_tensor(g).to(device=dev, dtype=torch.float64).contiguous() if g is not None
+                                else torch.zeros((T, B, n), dtype=torch.float64, device=dev))
+            out = kkt_grad_device_f64(r["C"], r["c"], r["F"], r["x"], r["u"], g64(grad_x, nx), g64(grad_u, nu), T, nx, nu,
+                                      strict_math=self.strict_math)
+            return tuple(g.to(device=r["out_device"], dtype=r["out_dtype"]) for g in out)
         gx = _lib.f32c(_as_tensor(grad_x), dev) if grad_x is not None else torch.zeros((T, B, nx), device=dev)
         gu = _lib.f32c(_as_tensor(grad_u), dev) if grad_u is not None else torch.zeros((T, B, nu), device=dev)
         assert list(gx.shape) == [T, B, nx] and list(gu.shape) == [T, B, nu]

@@ -41,7 +41,11 @@ def raise_info(info, what):
 class LqrRecursion:
     """LQR Recursion solver (time-varying, batched).  lqr/lqr_recursion.py:18."""
 
-    def __init__(self, x_init, C, c, large_f, f, T, n_state, n_ctrl, u_zero_Index=None):
+    def __init__(self, x_init, C, c, large_f, f, T, n_state, n_ctrl, u_zero_Index=None, precision="float32"):
+        # precision="float64" (not in the reference's signature): solve_recursion() on the float64 kernels - the reference's
+        # own precision, an order of magnitude slower (include/dmpc.h, `_f64`)
+        assert precision in ("float32", "float64")
+        self.precision = precision
         self.x_init = _as_tensor(x_init)
         self.C = _as_tensor(C)
         self.c = _as_tensor(c)
@@ -129,6 +133,13 @@ class LqrRecursion:
 
     def solve_recursion(self):
         """backward + forward in ONE fused launch -> (x, u) (lqr_recursion.py:202-209)"""
+        if self.precision == "float64":
+            d = self._dev
+            f64 = lambda t: None if t is None else t.to(device=d, dtype=torch.float64).contiguous()
+            mask = None if self.u_zero_Index is None else self.u_zero_Index.to(device=d).to(torch.uint8).contiguous()
+            x, u, _, _ = solve_device_f64(f64(self.C), f64(self.c), f64(self.F), f64(self.f), f64(self.x_init), mask,
+                                          self.T, self.n_state, self.n_ctrl, info=self._new_info())
+            return self._out(x), self._out(u)
         x, u, _, _ = solve_device(*self._dev_inputs(), self.T, self.n_state, self.n_ctrl,
                                   info=self._new_info())
         return self._out(x), self._out(u)
@@ -239,4 +250,29 @@ def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False,
                                 _lib.ptr(x_init), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(x),
                                 _lib.ptr(u), _lib.ptr(ws), ws_bytes, _lib.ptr(info), _lib.stream_ptr(dev))
     _lib.check(rc, "dmpc_lqr_solve")
+    return x, u, Ks, ks
+
+
+def solve_device_f64(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False, info=None):
+    """The fused solve in float64 on float64 device tensors (`dmpc_lqr_solve_f64`: the reference's precision; one lane per
+    trajectory, any shape with nx + nu + 1 <= 64).  Returns (x, u, Ks|None, ks|None)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = C.device
+    B = C.shape[1]
+    nx, nu = n_state, n_ctrl
+    for t in (C, c, F, f, x_init):
+        assert t is None or (t.dtype == torch.float64 and t.is_contiguous())
+    f64 = dict(dtype=torch.float64, device=dev)
+    x, u = torch.empty((T, B, nx), **f64), torch.empty((T, B, nu), **f64)
+    Ks = ks = None
+    if want_gains:
+        Ks, ks = torch.empty((T, B, nu, nx), **f64), torch.empty((T, B, nu), **f64)
+    need = lib.dmpc_lqr_f64_workspace_bytes(T, B, nx, nu)
+    ws = _workspace(need, dev)
+    with _lib.guard(dev):
+        rc = lib.dmpc_lqr_solve_f64(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(x_init),
+                                    _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks), _lib.ptr(x), _lib.ptr(u), _lib.ptr(ws), need,
+                                    _lib.ptr(info), _lib.stream_ptr(dev))
+    _lib.check(rc, "dmpc_lqr_solve_f64")
     return x, u, Ks, ks

@@ -142,6 +142,20 @@ int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const 
                             float *d_x_init, float *dC, float *dc, float *dF, float *df, void *ws, size_t ws_bytes,
                             int32_t *info, dmpc_stream_t stream);
 
+/* ---- A / B in float64 (optional `_f64` variants of SURVEY.md 8b): the reference computes in float64
+ *      (lqr/differentiable_lqr.py:169-172, numpy's default), these return outputs at its precision.  The completeness path
+ *      for precision, not a fast path: one lane per trajectory, runtime dimensions (any nx + nu + 1 <= 64), every matrix of
+ *      a trajectory in `ws` (dmpc_lqr_f64_workspace_bytes, required).  Arrays are the float64 twins of dmpc_lqr_solve's /
+ *      dmpc_lqr_kkt_grad's, same shapes; Ks_out / ks_out may be NULL (both). */
+size_t dmpc_lqr_f64_workspace_bytes(int T, int B, int nx, int nu);
+int dmpc_lqr_solve_f64(int T, int B, int nx, int nu, const double *C, const double *c, const double *F, const double *f,
+                       const double *x_init, const uint8_t *u_zero_mask, double *Ks_out, double *ks_out, double *x_out,
+                       double *u_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
+int dmpc_lqr_kkt_grad_f64(int T, int B, int nx, int nu, const double *C, const double *c, const double *F, const double *x,
+                          const double *u, const double *grad_x, const double *grad_u, int strict_math, double *d_x_init,
+                          double *dC, double *dc, double *dF, double *df, void *ws, size_t ws_bytes, int32_t *info,
+                          dmpc_stream_t stream);
+
 /* ---- D. batched LU (util.py:462-482 torch.lu, util.py:505-528 torch.lu_solve in float32) */
 /* A [B,n,n] -> LU [B,n,n], piv [B,n] int32 1-based (LAPACK getrf). */
 int dmpc_batch_lu_factor(int B, int n, const float *A, float *LU, int32_t *piv, int32_t *info,
