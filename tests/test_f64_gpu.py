@@ -80,3 +80,39 @@ def test_reference_golden_vectors_at_reference_precision(path):
     out = node.backward((0, 1, 2, 3, 4), (dev64(g["grad_x"]), dev64(g["grad_u"])))
     for got, key in zip(out, ("d_x_init", "dC", "dc", "dF", "df")):
         close64(got.cpu().numpy(), g[key], key)
+
+
+def test_headline_batch_every_trajectory_against_the_float64_kernels():
+    """BASELINE.json configs[2] at FULL size (B=4096, T=50, (8,2)): the float32 fast path against the float64 kernels
+    (themselves held to the oracle above) on EVERY trajectory - solution at the north star's 1e-4, gradient at 5e-4 - not
+    on a sample as the oracle tests have to"""
+    from chainer_differentiable_mpc_amd.differentiable_lqr import kkt_grad_device, kkt_grad_device_f64
+    from chainer_differentiable_mpc_amd.lqr_recursion import solve_device, solve_device_f64
+    from tests.helpers import TOL_COSTATE, TOL_PRIMAL, assert_close
+    B, T, nx, nu = 4096, 50, 8, 2
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=0)
+    d32 = {k: torch.as_tensor(v, dtype=torch.float32).cuda() for k, v in p.items() if isinstance(v, np.ndarray)}
+    d64 = {k: v.double() for k, v in d32.items()}      # identical inputs: the float32 values up-cast
+    x, u, _, _ = solve_device(d32["C"], d32["c"], d32["F"], d32["f"], d32["x_init"], None, T, nx, nu)
+    x64, u64, _, _ = solve_device_f64(d64["C"], d64["c"], d64["F"], d64["f"], d64["x_init"], None, T, nx, nu)
+    assert_close(x.cpu().numpy(), x64.cpu().numpy(), TOL_PRIMAL, "x")
+    assert_close(u.cpu().numpy(), u64.cpu().numpy(), TOL_PRIMAL, "u")
+    gx, gu = torch.ones((T, B, nx), device="cuda"), torch.ones((T, B, nu), device="cuda")
+    out = kkt_grad_device(d32["C"], d32["c"], d32["F"], x, u, gx, gu, T, nx, nu)
+    ref = kkt_grad_device_f64(d64["C"], d64["c"], d64["F"], x64, u64, gx.double(), gu.double(), T, nx, nu)
+    for got, want, key in zip(out, ref, ("d_x_init", "dC", "dc", "dF", "df")):
+        assert_close(got.cpu().numpy(), want.cpu().numpy(), TOL_COSTATE if key in ("d_x_init", "dF", "df") else TOL_PRIMAL, key)
+
+
+def test_config5_shard_sampled_against_the_float64_kernels():
+    """(32,8): 512 trajectories of a config-5 shard, float32 matrix-core path against float64"""
+    from chainer_differentiable_mpc_amd.lqr_recursion import solve_device, solve_device_f64
+    from tests.helpers import assert_close
+    B, T, nx, nu = 512, 50, 32, 8
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=1)
+    d32 = {k: torch.as_tensor(v, dtype=torch.float32).cuda() for k, v in p.items() if isinstance(v, np.ndarray)}
+    d64 = {k: v.double() for k, v in d32.items()}
+    x, u, _, _ = solve_device(d32["C"], d32["c"], d32["F"], d32["f"], d32["x_init"], None, T, nx, nu)
+    x64, u64, _, _ = solve_device_f64(d64["C"], d64["c"], d64["F"], d64["f"], d64["x_init"], None, T, nx, nu)
+    assert_close(x.cpu().numpy(), x64.cpu().numpy(), 5e-4, "x")
+    assert_close(u.cpu().numpy(), u64.cpu().numpy(), 5e-4, "u")
