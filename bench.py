@@ -169,8 +169,42 @@ def usable_cores():
         return os.cpu_count() or 1
 
 
-def event_time(fn, reps, warm=3):
-    """average duration of fn() in seconds: HIP events on the current stream around `reps` back-to-back calls"""
+SETTLE_MS = 60.0       # how long the device is kept busy before a measurement (scripts/clock_ramp.py: from a cold start a
+                       # launch takes 36 us in the first millisecond, 40-45 us from the 4th to the 10th, and its
+                       # steady 33 us from ~30 ms on, for as many seconds as the load lasts)
+
+
+def settle(fn, min_ms=SETTLE_MS, max_ms=600.0, block=25):
+    """Bring the GPU to the power state of a running job before timing anything: fn() back to back in blocks of `block`
+    for at least `min_ms`, until two consecutive blocks take the same time within 3 % (at most `max_ms`).  A freshly
+    woken MI355X ramps its clocks over tens of milliseconds (and dips on the way); a measurement window that starts one
+    millisecond after the first launch times that transient, not the kernel.  Returns (calls made, milliseconds spent,
+    [first block's, last block's] seconds per call)."""
+    fn()                               # (first-call costs - lazy initialisation, workspace allocation - are not the ramp)
+    torch.cuda.synchronize()
+    t_begin = time.perf_counter()
+    calls, prev, first, last = 1, None, None, None
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(block):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        calls += block
+        last = e0.elapsed_time(e1) * 1e-3 / block
+        first = last if first is None else first
+        spent = (time.perf_counter() - t_begin) * 1e3
+        if spent >= max_ms or (spent >= min_ms and prev is not None and abs(last - prev) <= 0.03 * prev):
+            return calls, spent, [first, last]
+        prev = last
+
+
+def event_time(fn, reps, warm=3, settled=True):
+    """average duration of fn() in seconds: HIP events on the current stream around `reps` back-to-back calls, the
+    device in its steady power state (`settle`)"""
+    if settled:
+        settle(fn, min_ms=SETTLE_MS / 2)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -347,6 +381,8 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the sharded CPU baseline "
                     "(default: the cores this process may use, at most 16 - a one-GPU box's CPU share)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-settle", action="store_true", help="time from a cold start: no run-up to the steady power state "
+                    "before the warm-up steps (the first milliseconds of a job instead of its steady rate)")
     ap.add_argument("--allow-secondary-failure", action="store_true",
                     help="exit 0 even when a secondary measurement raised (its error string is in the JSON line either way)")
     args = ap.parse_args()
@@ -405,6 +441,8 @@ def main():
             dist.all_gather_into_tensor(gx, x)
             dist.all_gather_into_tensor(gu, u)
 
+    # the device in the power state of a running job (every rank its own GPU), then the contract's W warm-up steps
+    pre_calls, pre_ms, pre_times = (0, 0.0, [None, None]) if args.no_settle else settle(step)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -477,6 +515,15 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kern_name,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3},
+            # what ran on the device before the W warm-up steps and the K timed ones: the same step, untimed, until its
+            # time had settled (the steady power state of a running job; scripts/clock_ramp.py has the ramp)
+            "device_run_up": {"untimed_steps": pre_calls, "ms": pre_ms,
+                              "ms_per_step_first_block_cold": None if pre_times[0] is None else pre_times[0] * 1e3,
+                              "ms_per_step_last_block": None if pre_times[1] is None else pre_times[1] * 1e3,
+                              "what": "none (--no-settle)" if args.no_settle else
+                                      "the timed step itself, back to back in blocks of 25 for >= %.0f ms until two blocks agree "
+                                      "within 3 %%: a freshly woken MI355X takes 36 us for this launch in its first millisecond, "
+                                      "40-45 us from the 4th to the 10th, 33 us from ~30 ms on (profiles/r03/clock_ramp.txt)" % SETTLE_MS},
         }
         out["roofline"].update({
             "input_sets_in_rotation": n_sets,
