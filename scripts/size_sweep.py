@@ -1,5 +1,6 @@
-"""Fused-solve time over batch sizes and horizons at (8,2) (HIP events around 100 back-to-back launches; sizes whose
-kernel is shorter than the host's launch rate are launch bound and marked)."""
+"""Fused-solve time over batch sizes and horizons at (8,2) (HIP events around 100 back-to-back launches of ONE input set after
+the device has been run up to its steady clocks, bench.settle; sizes whose kernel is shorter than the host's launch rate
+are launch bound and marked)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
@@ -15,7 +16,7 @@ for B, T, nx, nu in cases:
     p, d = bench.make_inputs(B, T, nx, nu, 0, torch.device("cuda"))
     x = torch.empty((T, B, nx), device="cuda"); u = torch.empty((T, B, nu), device="cuda")
     ws = None
-    for _ in range(5): solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u))
+    bench.settle(lambda: solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u)))   # steady clocks
     torch.cuda.synchronize()
     n = 100 if B <= 16384 else 10
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
