@@ -441,6 +441,20 @@ def main():
             dist.all_gather_into_tensor(gx, x)
             dist.all_gather_into_tensor(gu, u)
 
+    # For the record, the contract's protocol from a cold device first (W warm-up steps, K timed ones - a window of a
+    # millisecond at the driver's K = 20): reported as `cold_start`, never as `value`
+    cold = None
+    if not args.no_settle:
+        step()
+        torch.cuda.synchronize()       # (first-call costs are not part of either figure)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        cold = (time.perf_counter() - c0) / args.steps
     # the device in the power state of a running job (every rank its own GPU), then the contract's W warm-up steps
     pre_calls, pre_ms, pre_times = (0, 0.0, [None, None]) if args.no_settle else settle(step)
     for _ in range(args.warmup):
@@ -517,6 +531,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3},
             # what ran on the device before the W warm-up steps and the K timed ones: the same step, untimed, until its
             # time had settled (the steady power state of a running job; scripts/clock_ramp.py has the ramp)
+            "cold_start": None if cold is None else {
+                "ms_per_step": cold * 1e3, "value": B * T / cold,
+                "what": "rank 0's own W warm-up + K timed steps BEFORE the run-up, i.e. in the first milliseconds after the "
+                        "device wakes (its clocks still ramping): what `value` would be without `device_run_up`"},
             "device_run_up": {"untimed_steps": pre_calls, "ms": pre_ms,
                               "ms_per_step_first_block_cold": None if pre_times[0] is None else pre_times[0] * 1e3,
                               "ms_per_step_last_block": None if pre_times[1] is None else pre_times[1] * 1e3,
