@@ -116,3 +116,78 @@ def test_config5_shard_sampled_against_the_float64_kernels():
     x64, u64, _, _ = solve_device_f64(d64["C"], d64["c"], d64["F"], d64["f"], d64["x_init"], None, T, nx, nu)
     assert_close(x.cpu().numpy(), x64.cpu().numpy(), 5e-4, "x")
     assert_close(u.cpu().numpy(), u64.cpu().numpy(), 5e-4, "u")
+
+
+def _fuzz_cases():
+    rng = np.random.RandomState(2026)
+    cases = []
+    for _ in range(40):
+        nx = int(rng.randint(1, 33))
+        nu = int(rng.randint(1, min(8, 40 - nx) + 1))
+        T = int(rng.choice([1, 2, 3, 7, 20, 51, 52, 75, 90]))
+        B = int(rng.choice([1, 3, 4, 17, 64, 130]))
+        if nx * T > 900:          # (keep the float64 path's share of the suite small)
+            T = max(1, 900 // nx)
+        cases.append((B, T, nx, nu, bool(rng.randint(2)), bool(rng.randint(2))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(), ids=lambda c: "B%d_T%d_%dx%d_%s%s" % (c[0], c[1], c[2], c[3], "f" if c[4] else "nof", "_masked" if c[5] else ""))
+def test_float32_paths_against_the_float64_kernels_over_the_shape_space(case):
+    """forty random (B, T, nx, nu) up to 32 states / 8 controls - specialised shapes, containers, wide containers, ragged
+    batches, horizons on either side of the stash / ring / workspace limits, with and without f, plain and clamped: whichever
+    float32 kernel the dispatch picks against the float64 kernel on identical inputs"""
+    from chainer_differentiable_mpc_amd.lqr_recursion import solve_device, solve_device_f64
+    from tests.helpers import assert_close
+    B, T, nx, nu, with_f, masked = case
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=B * 1000 + T * 10 + nx, with_f=with_f)
+    d32 = {k: torch.as_tensor(v, dtype=torch.float32).cuda() for k, v in p.items() if isinstance(v, np.ndarray)}
+    d64 = {k: v.double() for k, v in d32.items()}
+    mask = None
+    if masked:
+        mask = torch.as_tensor(np.random.RandomState(B + T).rand(T, B, nu) < 0.35).cuda().to(torch.uint8).contiguous()
+    f32, f64 = d32.get("f") if with_f else None, d64.get("f") if with_f else None
+    x, u, Ks, ks = solve_device(d32["C"], d32["c"], d32["F"] if T > 1 else None, f32, d32["x_init"], mask, T, nx, nu, want_gains=True)
+    x64, u64, Ks64, ks64 = solve_device_f64(d64["C"], d64["c"], d64["F"] if T > 1 else None, f64, d64["x_init"], mask, T, nx, nu,
+                                            want_gains=True)
+    tol = 3e-4 if nx > 16 else 1e-4 if not masked else 2e-4
+    assert_close(x.cpu().numpy(), x64.cpu().numpy(), tol, "x")
+    assert_close(u.cpu().numpy(), u64.cpu().numpy(), tol, "u")
+    assert_close(Ks.cpu().numpy(), Ks64.cpu().numpy(), tol, "Ks")
+    assert_close(ks.cpu().numpy(), ks64.cpu().numpy(), tol, "ks")
+    if masked:
+        assert bool((u[mask.bool()] == 0).all())
+
+
+def _grad_fuzz_cases():
+    rng = np.random.RandomState(77)
+    cases = []
+    for _ in range(24):
+        nx = int(rng.randint(1, 25))
+        nu = int(rng.randint(1, min(8, 32 - nx) + 1))
+        T = int(rng.choice([2, 3, 7, 20, 50, 60]))
+        B = int(rng.choice([1, 4, 5, 16, 68]))
+        if nx * T > 600:
+            T = max(2, 600 // nx)
+        cases.append((B, T, nx, nu, bool(rng.randint(2))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _grad_fuzz_cases(), ids=lambda c: "B%d_T%d_%dx%d_%s" % (c[0], c[1], c[2], c[3], "strict" if c[4] else "faithful"))
+def test_float32_gradient_against_the_float64_kernels_over_the_shape_space(case):
+    """DiffLqr forward + backward (whichever kernels the dispatch picks: saved gains / one launch, re-solve + co-state sweep,
+    containers) against the float64 kernels on identical inputs"""
+    from tests.helpers import assert_close
+    B, T, nx, nu, strict = case
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=B * 100 + T + nx)
+    rng = np.random.RandomState(B + nx)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    outs = {}
+    for prec, dt in (("float32", torch.float32), ("float64", torch.float64)):
+        args = tuple(None if p[k] is None else torch.as_tensor(p[k], dtype=torch.float32).to(dt).cuda() for k in ("x_init", "C", "c", "F", "f"))
+        node = DiffLqr(T, B, nx, nu, strict_math=strict, precision=prec)
+        node.forward(args)
+        outs[prec] = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx, dtype=dt).cuda(), torch.as_tensor(gu, dtype=dt).cuda()))
+    for got, want, key in zip(outs["float32"], outs["float64"], ("d_x_init", "dC", "dc", "dF", "df")):
+        assert_close(got.cpu().numpy(), want.cpu().numpy(), 1e-3 if nx > 12 else 5e-4, key)
