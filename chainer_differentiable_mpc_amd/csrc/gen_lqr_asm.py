@@ -39,7 +39,7 @@ OUT = os.path.join(HERE, "lqr_asm_gen.hpp")
 
 SHAPES = [(8, 2), (3, 1), (4, 2), (6, 2), (2, 2), (1, 1), (2, 1), (3, 2)]
 DB = 3        # backward ring depth == number of rotating register sets
-DF = 6        # forward ring depth == unroll (lcm of 2 row sets and 3 accumulators)
+DF = int(os.environ.get("GEN_FWD_DEPTH", "6"))   # forward ring depth == unroll (a multiple of 6: lcm of 2 row sets and 3 accumulators)
 KROW = 12     # floats per gain row in LDS: [K_m (nx) | 0 (nu) | k_m | pad], 8-byte aligned rows
 VBASE = 128   # first VGPR owned by the asm block (operands chosen by hipcc live below)
 
