@@ -79,10 +79,12 @@ def test_anchor_boyd_notebook():
     assert_close(npy(u), a["boyd_u"], TOL_PRIMAL, "u")
 
 
-@pytest.mark.parametrize("shape", [(7, 9, 5, 3), (3, 6, 7, 1), (2, 5, 12, 3), (5, 4, 1, 1), (2, 4, 20, 6)])
+@pytest.mark.parametrize("shape", [(7, 9, 5, 3), (3, 6, 7, 1), (2, 5, 12, 3), (5, 4, 1, 1), (2, 4, 20, 6), (2, 4, 40, 4), (3, 5, 10, 9),
+                                   (2, 3, 50, 12)])
 @pytest.mark.parametrize("with_f", [True, False])
 def test_other_shapes_against_oracle(shape, with_f):
-    """shapes that dispatch to other specialisations or to the runtime-dimension kernel"""
+    """shapes that dispatch to other specialisations, to a container, or - beyond 32 states / 8 controls - to the
+    runtime-dimension kernel"""
     B, T, nx, nu = shape
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=3, with_f=with_f)
     xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
