@@ -27,5 +27,8 @@ struct CostateArgs {
 
 // Shape dispatch (defined in kkt_api.hip).
 int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream);
+// dC_sum / dc_sum are formed by the LDS-DMA co-state kernel alone: does launch_costate take that kernel for this size?
+// (callers refuse the sums with DMPC_E_UNSUPPORTED otherwise - the other kernels would leave them untouched)
+bool costate_sums_available(int T, int B, int nx, int nu);
 
 }  // namespace dmpc

@@ -50,7 +50,17 @@ static bool costate_dma_disabled() {  // DMPC_NO_COSTATE_DMA=1: register-prefetc
 }
 constexpr int kCostateDmaDepth = 4;
 
+bool costate_sums_available(int T, int B, int nx, int nu) {
+  if (B < 4 || B % 4 != 0 || T < 2 || costate_dma_disabled()) return false;
+#define X(NX_, NU_, L_) \
+  if (nx == NX_ && nu == NU_) return L_ == 16;
+  DMPC_COSTATE_SHAPES(X)
+#undef X
+  return false;
+}
+
 int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
+  if (a.dC_sum != nullptr && !costate_sums_available(a.T, a.B, nx, nu)) return DMPC_E_UNSUPPORTED;
 #define X(NX_, NU_, L_)                                                                                     \
   if (nx == NX_ && nu == NU_) {                                                                             \
     constexpr int GPB = 256 / L_;                                                                           \

@@ -641,7 +641,7 @@ int dmpc_mpc_step_backward(int T, int B, int nx, int nu, const float *C_hat, con
   if (!C_hat || !c_hat || !F_hat || !x || !u || !u_lower || !u_upper || !d_x_init || !ws) return DMPC_E_BADARG;
   if ((dC_sum == nullptr) != (dc_sum == nullptr) || (dc == nullptr && dc_sum == nullptr)) return DMPC_E_BADARG;
   // the sums are formed by the LDS-DMA co-state kernel only (whole wavefronts of four trajectories, 16-lane shapes)
-  if (dC_sum != nullptr && (B % 4 != 0 || nx + nu + 1 > 16 || dmpc_lqr_kernel_family(nx, nu) != 1)) return DMPC_E_UNSUPPORTED;
+  if (dC_sum != nullptr && !costate_sums_available(T, B, nx, nu)) return DMPC_E_UNSUPPORTED;   // (nothing launched)
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(dC) || !aligned16(dF))
     return DMPC_E_BADARG;
   const MpcWs w = mpc_layout(T, B, nx, nu);
