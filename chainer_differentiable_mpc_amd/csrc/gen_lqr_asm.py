@@ -56,6 +56,9 @@ X_WARM_STUBS = os.environ.get("GEN_WARM_STUBS") == "1"  # experiment: run every 
 X_RET_DIRECT = os.environ.get("GEN_RET_SETPC") != "1"   # stash stubs return by a direct s_branch (else s_setpc_b64)
 MFMA_USE = int(os.environ.get("GEN_MFMA_USE", "5"))     # wait states kept before a non-accumulating use of an MFMA result
 MFMA_DEP = int(os.environ.get("GEN_MFMA_DEP", "2"))     # wait states kept before an accumulation into the same tile
+# box QP: the clamped-set test on the VALU alone (6 VALU per control instead of 4 VALU + 3 SALU that wait for them): MPC step
+# at config-3 size 101.7 -> 99.0 us.  (Replacing the scalar OR behind the off-diagonal mask by two selects: no change.)
+X_QP_VALU = os.environ.get("GEN_QP_VALU", "1") == "1"
 X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (not before) the G MFMAs
 # Ring depth of the plain / saving / affine streams (the masked and MPC streams keep DB slots of whole 1 KB pieces: their
 # flags and bounds ride in the slot padding).  With more than DB slots the slot stride is the slot's own size (rounded up
@@ -549,6 +552,16 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, gh
             for l in range(1, nu):
                 P.v("v_fmac_f32_e32 %s, %s, %s" % (Gv[m], A[m][l], XK[l]), writes=(Gv[m],), reads=(A[m][l], XK[l], Gv[m]))
         for m in range(nu):
+            if X_QP_VALU:
+                # clamped = (x == lo & g > 0) | (x == hi & g < 0)  <=>  max(x == lo ? g : -1, x == hi ? -g : -1) > 0
+                # (a NaN gradient gives "not clamped" either way: v_max returns the other operand, the compare is false)
+                P.v("v_cmp_eq_f32_e32 vcc, %s, %s" % (XK[m], LO[m]), reads=(XK[m], LO[m]))
+                P.v("v_cndmask_b32_e32 %s, -1.0, %s, vcc" % (tRA, Gv[m]), writes=(tRA,), reads=(Gv[m],))
+                P.v("v_cmp_eq_f32_e32 vcc, %s, %s" % (XK[m], HI[m]), reads=(XK[m], HI[m]))
+                P.v("v_cndmask_b32_e64 %s, -1.0, -%s, vcc" % (tRB, Gv[m]), writes=(tRB,), reads=(Gv[m],))
+                P.v("v_max_f32_e32 %s, %s, %s" % (tRA, tRA, tRB), writes=(tRA,), reads=(tRA, tRB))
+                P.v("v_cmp_lt_f32_e64 %s, 0, %s" % (S_ACT[m], tRA), reads=(tRA,))
+                continue
             P.v("v_cmp_eq_f32_e64 %s, %s, %s" % (S_T0, XK[m], LO[m]), reads=(XK[m], LO[m]))
             P.v("v_cmp_lt_f32_e64 %s, 0, %s" % (S_T1, Gv[m]), reads=(Gv[m],))
             P.v("v_cmp_eq_f32_e64 %s, %s, %s" % (S_T2, XK[m], HI[m]), reads=(XK[m], HI[m]))
