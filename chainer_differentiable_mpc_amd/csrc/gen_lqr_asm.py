@@ -66,8 +66,10 @@ X_G10_MIX = os.environ.get("GEN_G10_MIX") == "1"        # g1 DPP FMAs between (n
 RING_DEPTH = int(os.environ.get("GEN_RING_DEPTH", "3"))
 # nt (streaming) cache policy on the backward groups' LDS-DMA, per kind of stream (plain, save, affine, masked, mpc):
 # the inputs of a solve are read once; with the default policy they displace each other from L2 / the Infinity Cache on
-# their way through (HBM-streamed headline solve 38-40 -> 33.5-35 us, B = 8192: 78 -> 64 us; profiles/r03/ring_ab.txt)
-X_NT = set(os.environ.get("GEN_NT", "plain").split(","))
+# their way through (HBM-streamed headline solve 38-40 -> 33.5-35 us, B = 8192: 78 -> 64 us; profiles/r03/ring_ab.txt).
+# With steady clocks (profiles/r03/nt_steady_state_variants.txt): save / affine / adj (DiffLqr's two launches) 110 -> 103.7 us
+# per training step; masked: no change; mpc: 99 -> 104 us - so the DiffLqr streams carry it too, the other two do not.
+X_NT = set(os.environ.get("GEN_NT", "plain,save,affine,adj").split(","))
 USE_MFMA = os.environ.get("GEN_NO_MFMA") != "1"         # F^T V F on v_mfma_f32_4x4x1_16b_f32 (else DPP FMAs)          # s_memtime at the phase boundaries -> info[] (no flags then)
 
 
