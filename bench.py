@@ -174,12 +174,13 @@ SETTLE_MS = 60.0       # how long the device is kept busy before a measurement (
                        # steady 33 us from ~30 ms on, for as many seconds as the load lasts)
 
 
-def settle(fn, min_ms=SETTLE_MS, max_ms=600.0, block=25):
+def settle(fn, min_ms=SETTLE_MS, max_ms=600.0, block=25, fixed_blocks=None):
     """Bring the GPU to the power state of a running job before timing anything: fn() back to back in blocks of `block`
     for at least `min_ms`, until two consecutive blocks take the same time within 3 % (at most `max_ms`).  A freshly
     woken MI355X ramps its clocks over tens of milliseconds (and dips on the way); a measurement window that starts one
-    millisecond after the first launch times that transient, not the kernel.  Returns (calls made, milliseconds spent,
-    [first block's, last block's] seconds per call)."""
+    millisecond after the first launch times that transient, not the kernel.  `fixed_blocks`: that many blocks, no
+    stopping rule - for an fn() with a collective inside, where every rank must make the same number of calls.
+    Returns (calls made, milliseconds spent, [first block's, last block's] seconds per call)."""
     fn()                               # (first-call costs - lazy initialisation, workspace allocation - are not the ramp)
     torch.cuda.synchronize()
     t_begin = time.perf_counter()
@@ -195,7 +196,10 @@ def settle(fn, min_ms=SETTLE_MS, max_ms=600.0, block=25):
         last = e0.elapsed_time(e1) * 1e-3 / block
         first = last if first is None else first
         spent = (time.perf_counter() - t_begin) * 1e3
-        if spent >= max_ms or (spent >= min_ms and prev is not None and abs(last - prev) <= 0.03 * prev):
+        if fixed_blocks is not None:
+            if calls >= 1 + fixed_blocks * block:
+                return calls, spent, [first, last]
+        elif spent >= max_ms or (spent >= min_ms and prev is not None and abs(last - prev) <= 0.03 * prev):
             return calls, spent, [first, last]
         prev = last
 
@@ -456,7 +460,9 @@ def main():
         torch.cuda.synchronize()
         cold = (time.perf_counter() - c0) / args.steps
     # the device in the power state of a running job (every rank its own GPU), then the contract's W warm-up steps
-    pre_calls, pre_ms, pre_times = (0, 0.0, [None, None]) if args.no_settle else settle(step)
+    # (with --gather the step holds a collective: every rank runs the same, fixed number of blocks)
+    pre_calls, pre_ms, pre_times = (0, 0.0, [None, None]) if args.no_settle else settle(
+        step, fixed_blocks=(80 if B * T * (nx + nu) ** 2 < 1e8 else 4) if gx is not None else None)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
