@@ -59,24 +59,29 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
     const size_t tb = (size_t)t * B + b;
     const float *Cp = a.C + tb * ns * ns;
     for (int e = lane; e < ns * ns; e += 64) Qt[(e / ns) * nc + (e % ns)] = Cp[e];
-    for (int i = lane; i < ns; i += 64) {
-      float ci = a.c[tb * ns + i];
-      if (a.states != nullptr) {   // need_expand inside the sweep: c_hat = C [x_t; u_t] + c          :305-317
-        for (int j = 0; j < nx; ++j) ci = fmaf(Cp[i * ns + j], a.states[tb * nx + j], ci);
-        for (int m = 0; m < NU; ++m) ci = fmaf(Cp[i * ns + nx + m], a.controls[tb * NU + m], ci);
-      }
-      Qt[i * nc + ns] = ci;
-    }
     if (t < T - 1) {
       const float *Fp = a.F + tb * nx * ns;
       for (int e = lane; e < nx * ns; e += 64) Ft[(e / ns) * nc + (e % ns)] = Fp[e];
       for (int i = lane; i < nx; i += 64) Ft[i * nc + ns] = a.f ? a.f[tb * nx + i] : 0.f;
+    }
+    if (a.states != nullptr) {   // [x_t; u_t] into the (still unused) first row of W
+      for (int j = lane; j < ns; j += 64) Wt[j] = j < nx ? a.states[tb * nx + j] : a.controls[tb * NU + (j - nx)];
+    }
+    __syncthreads();
+    for (int i = lane; i < ns; i += 64) {
+      float ci = a.c[tb * ns + i];
+      if (a.states != nullptr) {   // need_expand inside the sweep: c_hat = C [x_t; u_t] + c, from the LDS copy of C   :305-317
+#pragma unroll 8
+        for (int j = 0; j < ns; ++j) ci = fmaf(Qt[i * nc + j], Wt[j], ci);
+      }
+      Qt[i * nc + ns] = ci;
     }
     __syncthreads();
     if (t < T - 1) {  // Q~ = C~ + F^T (V F~ + v e_aff)                                   mpc_step.py:110,116
       if (col) {
         for (int i = 0; i < nx; ++i) {
           float acc = (lane == ns) ? Vt[i * nc + ns] : 0.f;
+#pragma unroll 8
           for (int k = 0; k < nx; ++k) acc = fmaf(Vt[i * nc + k], Ft[k * nc + lane], acc);
           Wt[i * nc + lane] = acc;
         }
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
       if (col) {
         for (int i = 0; i < ns; ++i) {
           float acc = Qt[i * nc + lane];
+#pragma unroll 8
           for (int k = 0; k < nx; ++k) acc = fmaf(Ft[k * nc + i], Wt[k * nc + lane], acc);
           Qt[i * nc + lane] = acc;
         }
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(64) void mpc_generic_backward_kernel(const MpcBackA
     }
     __syncthreads();
     if (col && t > 0) {
+#pragma unroll 4
       for (int i = 0; i < nx; ++i) {
         float acc = Qt[i * nc + lane];
 #pragma unroll
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(64) void mpc_generic_forward_kernel(const MpcFwdArg
         const int m = lane;
         const float *Kr = a.Ks + (tb * nu + m) * nx;
         float v = alpha * a.ks[tb * nu + m];
+#pragma unroll 8
         for (int i = 0; i < nx; ++i) v = fmaf(Kr[i], xh[i] - a.states[tb * nx + i], v);
         v += a.controls[tb * nu + m];                                                    // :209-219
         const float lb = a.lower[tb * nu + m], ub = a.upper[tb * nu + m];
@@ -224,7 +232,8 @@ __global__ __launch_bounds__(64) void mpc_generic_forward_kernel(const MpcFwdArg
       if (lane < ns) {                                                                   // :246-251, util.py:162-198
         const float *Cr = a.C + (tb * ns + lane) * ns;
         float qi = 0.f, q0 = 0.f, qd = 0.f;
-        for (int j = 0; j < ns; ++j) {
+#pragma unroll 8
+        for (int j = 0; j < ns; ++j) {   // (unrolled: the row's loads go out together instead of one per FMA)
           const float cij = Cr[j];
           qi = fmaf(cij, tau[j], qi);
           q0 = fmaf(cij, tau0[j], q0);
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(64) void mpc_generic_forward_kernel(const MpcFwdArg
       if (lane < nx && t < T - 1) {                                                      // :229-236
         const float *Fr = a.F + (tb * nx + lane) * ns;
         xn = a.f != nullptr ? a.f[tb * nx + lane] : 0.f;
+#pragma unroll 8
         for (int j = 0; j < ns; ++j) xn = fmaf(Fr[j], tau[j], xn);
       }
       __syncthreads();
