@@ -50,6 +50,12 @@ struct LqrArgs {
   int df_shift = 0;
   // container launches (lqr_kernel<..., PAD>): the problem's own dimensions, nx_log <= NX and nu_log <= NU of the kernel
   int nx_log = 0, nu_log = 0;
+  // MPCstep.backward_rec on the wavefront-per-trajectory kernel (lqr_wave_mfma_backward<..., MPC>): k_t is a box QP
+  // on (Quu, qu) with the bounds lower - u, upper - u (mpc/mpc_step.py:119-146); with mpc_states the re-centring
+  // c_hat = C [x_t; u_t] + c happens inside the sweep (:305-317); mpc_n_qp_total [B] receives sum_t (1 + i_t)
+  const float *mpc_controls = nullptr, *mpc_lower = nullptr, *mpc_upper = nullptr, *mpc_states = nullptr;
+  int mpc_n_qp_iter = 0;
+  int32_t *mpc_n_qp_total = nullptr;
 };
 
 enum LqrMode { kSolve = 0, kBackwardOnly = 1, kForwardOnly = 2 };

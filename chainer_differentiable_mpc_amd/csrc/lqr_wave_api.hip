@@ -24,6 +24,19 @@ int launch_lqr_wave_mfma_backward(int nx, int nu, bool masked, bool rollout, con
   return DMPC_E_UNSUPPORTED;
 }
 
+// MPCstep.backward_rec at the wavefront-per-trajectory shapes: the sweep with the box QP inside (a.mpc_* set)
+int launch_mpc_wave_backward(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
+  const dim3 grid((a.B + 3) / 4), block(256);
+#define X(NX_, NU_)                                                                                                \
+  if (nx == NX_ && nu == NU_) {                                                                                    \
+    DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, false, false, false, true>), grid, block, 0, stream, a);     \
+    return (int)hipGetLastError();                                                                                 \
+  }
+  X(16, 8) X(32, 8)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
 int launch_lqr_wave_container_sweep(int cnx, int cnu, bool masked, const LqrArgs &a, hipStream_t stream) {
   const dim3 grid((a.B + 3) / 4), block(256);
 #define X(NX_, NU_)                                                                                                \

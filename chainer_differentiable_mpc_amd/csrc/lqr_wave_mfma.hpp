@@ -33,6 +33,7 @@
 #include "colwise.hpp"
 #include "dma_gather.hpp"
 #include "lqr_kernels.hpp"
+#include "pnqp_device.hpp"
 
 namespace dmpc {
 
@@ -230,9 +231,15 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
 // PAD: container for a smaller problem (a.nx_log <= NX, a.nu_log <= NU; lqr_kernel<..., PAD> of lqr_kernels.hpp has the
 // argument): rows by buffer loads at the problem's own strides, columns outside it out of range (= 0), a unit diagonal for
 // the unused controls; sweep only (the rollout is the forward-only container kernel).
-template <int NX, int NU, bool MASKED, bool ROLLOUT, bool PAD = false>
-__global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void lqr_wave_mfma_backward(const LqrArgs a) {
+// MPC: MPCstep.backward_rec (mpc/mpc_step.py:70-173) - the feed-forward term k_t is the solution of the box QP on (Quu, qu)
+// (pnqp_solve_rows of pnqp_device.hpp, executed by every lane on the same broadcast data, warm-started from the later
+// step), K_t comes from the QP's own last factorisation with the rows of clamped controls zeroed (:147-157), the value update
+// keeps the unmasked blocks (:165-166).  The QP's registers (Quu, its LU, the iterates) come on top of the sweep's: one
+// wavefront per SIMD, and the LDS-DMA slot is what keeps the loads ahead of it.
+template <int NX, int NU, bool MASKED, bool ROLLOUT, bool PAD = false, bool MPC = false>
+__global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OCC) void lqr_wave_mfma_backward(const LqrArgs a) {
   static_assert(!(PAD && ROLLOUT), "containers roll out in a launch of their own");
+  static_assert(!MPC || (!MASKED && !ROLLOUT && !PAD && DMPC_WAVE_DMA && !DMPC_WAVE_PREFETCH), "MPC: the plain sweep's DMA form");
   constexpr int NS = NX + NU, AFF = NS;
   static_assert(NX % 4 == 0 && NU % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
   constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4, TU = NU / 4;
@@ -359,7 +366,15 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
   };
   // slot -> bank.  Lanes beyond the affine column are never written: they hold the zeros the bank starts with (their
   // columns of Q~ only ever add products with those zeros), as the out-of-range buffer loads of the other form give.
+  f4v crow[MPC ? TS : 1];   // MPC with re-centring: row min(lane, NS-1) of C_t, taken from the slot before it is refilled
   auto read_bank = [&](int t, Bank &k) {
+    if constexpr (MPC) {
+      if (a.mpc_states != nullptr) {
+        const f4v *rp = reinterpret_cast<const f4v *>(slot + kSlotC + (lane < NS ? lane : NS - 1) * NS);
+#pragma unroll
+        for (int q = 0; q < TS; ++q) crow[q] = rp[q];
+      }
+    }
     if (lane < NS) {
       static_for<0, NS>([&](auto i) { k.Q4[i.value / 4][i.value % 4] = slot[kSlotC + i.value * NS + lane]; });
       if (t < T - 1) static_for<0, NX>([&](auto r) { k.Fc[r.value] = slot[kSlotF + r.value * NS + lane]; });
@@ -395,9 +410,83 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
 #define DMPC_STAMP(i) do { } while (0)
 #endif
 
+  // ---- MPC: the box QP and what follows it (replaces the gain solve and the value update of the LQR sweep)
+  float kprev[NU];
+#pragma unroll
+  for (int m = 0; m < NU; ++m) kprev[m] = 0.f;
+  int n_qp_total = 0;
+  auto mpc_gains = [&](int t, size_t tb, f4v(&Q4)[TS]) {
+    float Kr[NU];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Kr[m] = Q4[(NX + m) / 4][(NX + m) % 4];
+    // every lane gets Quu, qu and the QP's bounds                                            mpc_step.py:119-138
+    float H[NU][NU], qu[NU], lo[NU], hi[NU], kt[NU];
+    static_for<0, NU>([&](auto l) {
+#pragma unroll
+      for (int m = 0; m < NU; ++m) H[m][l.value] = G64::template bcast<NX + l.value>(Kr[m]);
+    });
+#pragma unroll
+    for (int m = 0; m < NU; ++m) {
+      qu[m] = G64::template bcast<AFF>(Kr[m]);
+      const float uc = a.mpc_controls[tb * NU + m];
+      lo[m] = a.mpc_lower[tb * NU + m] - uc;
+      hi[m] = a.mpc_upper[tb * NU + m] - uc;
+      kt[m] = kprev[m];
+    }
+    PnqpResult<NU> qp;
+    QpTermination per_row;
+    pnqp_solve<NU>(H, qu, lo, hi, kt, /*warm=*/t != T - 1, a.mpc_n_qp_iter, qp, per_row);   // :141-146
+    n_qp_total += 1 + qp.it;
+    if (!qp.converged) info_bits |= 4;
+#pragma unroll
+    for (int m = 0; m < NU; ++m) kprev[m] = kt[m];
+    // K_t = -LU_free^-1 Qux, rows of clamped controls zero; the affine column carries k_t       :147-157
+    float Kt[NU];
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Kt[m] = qp.free_[m] ? Kr[m] : 0.f;
+    lu_solve_rinv<NU>(qp.fac, qp.piv, qp.rinv, Kt);
+#pragma unroll
+    for (int m = 0; m < NU; ++m) Kt[m] = col_aff ? kt[m] : -Kt[m];
+    if (k_lane && live) {
+      float *kp = col_aff ? ks + tb * NU : Ks + tb * NU * NX + lane;
+      const int kstride = col_aff ? 1 : NX;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) kp[m * kstride] = Kt[m];
+    }
+    if (t > 0) {   // V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~), unmasked blocks                  :165-166
+#pragma unroll
+      for (int I = 0; I < TX; ++I) V4[I] = Q4[I];
+      f4v XU4[TU];
+      static_for<0, TU>([&](auto q) { XU4[q.value] = reinterpret_cast<const f4v *>(xu_lds + (lane < NX ? lane : 0) * NU)[q.value]; });
+      static_for<0, NU>([&](auto m) {
+        const float xm = XU4[m.value / 4][m.value % 4];
+        static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(xm, Kt[m.value], V4[I.value]); });
+      });
+      float R[NU];
+      static_for<0, NU>([&](auto m) {
+        R[m.value] = Kr[m.value];
+        static_for<0, NU>([&](auto l) { R[m.value] = fmaf(H[m.value][l.value], Kt[l.value], R[m.value]); });
+      });
+      static_for<0, NU>([&](auto m) {
+        static_for<0, TX>([&](auto I) { V4[I.value] = mfma_bcast<I.value>(Kt[m.value], R[m.value], V4[I.value]); });
+      });
+    }
+  };
+
   auto step = [&](int t, Bank &k, Bank &next) {
     const size_t tb = (size_t)t * B + b;
     f4v(&Q4)[TS] = k.Q4;
+    if constexpr (MPC) {
+      if (a.mpc_states != nullptr) {   // c_hat = C [x_t; u_t] + c: lane i forms row i's sum, the affine lane of row i takes it   :305-317
+        const float tau = lane < NX ? a.mpc_states[tb * NX + lane] : (lane < NS ? a.mpc_controls[tb * NU + (lane - NX)] : 0.f);
+        float y = 0.f;
+        static_for<0, NS>([&](auto kk) { y = fmaf(crow[kk.value / 4][kk.value % 4], G64::template bcast<kk.value>(tau), y); });
+        static_for<0, NS>([&](auto i) {
+          const float yi = G64::template bcast<i.value>(y);
+          Q4[i.value / 4][i.value % 4] += col_aff ? yi : 0.f;
+        });
+      }
+    }
     if (t < T - 1) {
       // ---- G = [V|v]^T F~ : tiles 0..TX-1 (x columns of V) and TA (row 0 = v^T F~)
       f4v G4[TX + 1];
@@ -429,6 +518,10 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
     // wavefront instead of 64 more MFMAs per step accumulating (F~^T G)[u rows] (round 2, first version)
     if (t > 0 && lane >= NX && lane < NS) {
       static_for<0, NX>([&](auto i) { xu_lds[i.value * NU + (lane - NX)] = Q4[i.value / 4][i.value % 4]; });
+    }
+    if constexpr (MPC) {
+      mpc_gains(t, tb, Q4);
+      return;
     }
     // ---- gains (:112-120): Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie.  Row m is one register
     // across the lanes; the multiplier of row i at pivot k is ONE lane of it (lane nx+k).
@@ -610,6 +703,9 @@ __global__ __launch_bounds__(256, DMPC_WAVE_PREFETCH ? 1 : DMPC_WAVE_OCC) void l
     __threadfence();
 #endif
     wave_rollout<NX, NU, MASKED>(a, b, lane, live, Ks, ks, info_bits);
+  }
+  if constexpr (MPC) {
+    if (live && lane == 0) a.mpc_n_qp_total[b] = n_qp_total;
   }
   if (a.info != nullptr && live && info_bits != 0) atomicOr(&a.info[b], info_bits);
 }

@@ -11,6 +11,7 @@
 #include "mpc_asm_kernel.hpp"
 #include "mpc_dma_kernels.hpp"
 #include "mpc_fwd_asm_kernel.hpp"
+#include "lqr_wave_api.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_kernels.hpp"
 
@@ -98,6 +99,10 @@ static bool mpc_container_disabled() {   // DMPC_NO_CONTAINER=1: the runtime-dim
   return off;
 }
 
+static bool mpc_wave_disabled() {   // DMPC_NO_MPC_WAVE=1: wide MPC shapes on the runtime-dimension kernel (A/B timing)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_WAVE"); return e && e[0] == '1'; }();
+  return off;
+}
 static bool mpc_dma_disabled() {
   static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_DMA"); return e && e[0] == '1'; }();
   return off;
@@ -184,6 +189,19 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   if (sel != nullptr && !(dma_ok && sel_sync != nullptr)) return DMPC_E_BADARG;   // callers ask mpc_back_dma_ok first
   DMPC_MPC_SHAPES(X)
 #undef X
+  // (16,8), (32,8): the matrix-core sweep with the box QP inside (lqr_wave_mfma_backward<..., MPC>); per-trajectory
+  // termination, not inside the device-driven BoxDDP loop (no `done` flag there)
+  if (a.sync == nullptr && a.done == nullptr && !a.info_store && ((nx == 16 && nu == 8) || (nx == 32 && nu == 8)) &&
+      a.T >= 1 && !mpc_wave_disabled()) {
+    LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
+    s.mpc_controls = a.controls;
+    s.mpc_lower = a.lower;
+    s.mpc_upper = a.upper;
+    s.mpc_states = a.states;
+    s.mpc_n_qp_iter = a.n_qp_iter;
+    s.mpc_n_qp_total = a.n_qp_total;
+    return launch_mpc_wave_backward(nx, nu, s, stream);
+  }
   if (!mpc_container_disabled()) {   // a smaller problem inside the first container that holds it
     a.nx_log = nx;
     a.nu_log = nu;
