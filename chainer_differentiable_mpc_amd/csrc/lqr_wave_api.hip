@@ -37,6 +37,19 @@ int launch_mpc_wave_backward(int nx, int nu, const LqrArgs &a, hipStream_t strea
   return DMPC_E_UNSUPPORTED;
 }
 
+// ... of a smaller problem (a.nx_log, a.nu_log) padded inside the (cnx, cnu) instance
+int launch_mpc_wave_container_backward(int cnx, int cnu, const LqrArgs &a, hipStream_t stream) {
+  const dim3 grid((a.B + 3) / 4), block(256);
+#define X(NX_, NU_)                                                                                                \
+  if (cnx == NX_ && cnu == NU_) {                                                                                  \
+    DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, false, false, true, true>), grid, block, 0, stream, a);      \
+    return (int)hipGetLastError();                                                                                 \
+  }
+  X(16, 8) X(32, 8)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
 int launch_lqr_wave_container_sweep(int cnx, int cnu, bool masked, const LqrArgs &a, hipStream_t stream) {
   const dim3 grid((a.B + 3) / 4), block(256);
 #define X(NX_, NU_)                                                                                                \

@@ -12,6 +12,7 @@ namespace dmpc {
 int launch_lqr_wave_mfma_backward(int nx, int nu, bool masked, bool rollout, const LqrArgs &a, hipStream_t stream);
 // MPCstep.backward_rec with the box QP inside the sweep (a.mpc_* set); (16,8) and (32,8); DMPC_E_UNSUPPORTED otherwise
 int launch_mpc_wave_backward(int nx, int nu, const LqrArgs &a, hipStream_t stream);
+int launch_mpc_wave_container_backward(int cnx, int cnu, const LqrArgs &a, hipStream_t stream);
 // the sweep of a smaller problem (a.nx_log, a.nu_log) padded inside the (cnx, cnu) instance - (16,8) or (32,8)
 int launch_lqr_wave_container_sweep(int cnx, int cnu, bool masked, const LqrArgs &a, hipStream_t stream);
 

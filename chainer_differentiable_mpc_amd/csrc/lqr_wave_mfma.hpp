@@ -239,7 +239,7 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
 template <int NX, int NU, bool MASKED, bool ROLLOUT, bool PAD = false, bool MPC = false>
 __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OCC) void lqr_wave_mfma_backward(const LqrArgs a) {
   static_assert(!(PAD && ROLLOUT), "containers roll out in a launch of their own");
-  static_assert(!MPC || (!MASKED && !ROLLOUT && !PAD && DMPC_WAVE_DMA && !DMPC_WAVE_PREFETCH), "MPC: the plain sweep's DMA form");
+  static_assert(!MPC || (!MASKED && !ROLLOUT && DMPC_WAVE_DMA && !DMPC_WAVE_PREFETCH), "MPC: the plain sweep (DMA form, or padded)");
   constexpr int NS = NX + NU, AFF = NS;
   static_assert(NX % 4 == 0 && NU % 4 == 0 && NS + 1 <= 64, "tiles of 4 rows, one wavefront per trajectory");
   constexpr int TX = NX / 4, TS = NS / 4, TA = AFF / 4, TU = NU / 4;
@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
       while (wall_clock64() - t0 < (unsigned long long)DMPC_WAVE_STAGGER_TICKS) __builtin_amdgcn_s_sleep(64);
     }
   }
+  float crow_pad[(MPC && PAD) ? NS : 1];   // MPC in a container: this lane's row of C_t for the re-centring
   struct Bank {
     f4v Q4[TS];    // rows of [C_t | c_t], column-per-lane
     float Fc[NX];  // rows of [F_t | f_t]
@@ -301,6 +302,16 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
 #pragma unroll
         for (int m = 0; m < NU; ++m) bits |= (m < nu && a.mask[tb * nu + (m < nu ? m : 0)] != 0 ? 1u : 0u) << m;
         k.act = __builtin_amdgcn_readfirstlane(bits);
+      }
+      if constexpr (MPC) {
+        if (a.mpc_states != nullptr) {   // the re-centring's row of C for this lane (container positions; 0 outside the problem)
+          const float *rp = a.C + (tb * ns + (lcol >= 0 ? lcol : 0)) * ns;
+          static_for<0, NS>([&](auto kk) {
+            const int lk = logical(kk.value);   // uniform
+            const float v = rp[lk >= 0 ? lk : 0];
+            crow_pad[kk.value] = (lk >= 0 && lcol >= 0) ? v : 0.f;
+          });
+        }
       }
       return;
     }
@@ -428,9 +439,11 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
 #pragma unroll
     for (int m = 0; m < NU; ++m) {
       qu[m] = G64::template bcast<AFF>(Kr[m]);
-      const float uc = a.mpc_controls[tb * NU + m];
-      lo[m] = a.mpc_lower[tb * NU + m] - uc;
-      hi[m] = a.mpc_upper[tb * NU + m] - uc;
+      const bool real = !PAD || m < nu;    // an unused control of a container: qu = 0, unit diagonal, the box [-1, 1] around 0
+      const int mc = real ? m : 0;
+      const float uc = a.mpc_controls[tb * nu + mc];
+      lo[m] = real ? a.mpc_lower[tb * nu + mc] - uc : -1.f;
+      hi[m] = real ? a.mpc_upper[tb * nu + mc] - uc : 1.f;
       kt[m] = kprev[m];
     }
     PnqpResult<NU> qp;
@@ -447,11 +460,14 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
     lu_solve_rinv<NU>(qp.fac, qp.piv, qp.rinv, Kt);
 #pragma unroll
     for (int m = 0; m < NU; ++m) Kt[m] = col_aff ? kt[m] : -Kt[m];
-    if (k_lane && live) {
-      float *kp = col_aff ? ks + tb * NU : Ks + tb * NU * NX + lane;
-      const int kstride = col_aff ? 1 : NX;
+    if (k_lane && live && (!PAD || col_aff || lane < nx)) {
+      float *kp = col_aff ? ks + tb * nu : Ks + tb * nu * nx + lane;
+      const int kstride = col_aff ? 1 : nx;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) kp[m * kstride] = Kt[m];
+      for (int m = 0; m < NU; ++m) {
+        if (PAD && m >= nu) break;   // uniform
+        kp[m * kstride] = Kt[m];
+      }
     }
     if (t > 0) {   // V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~), unmasked blocks                  :165-166
 #pragma unroll
@@ -478,9 +494,14 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
     f4v(&Q4)[TS] = k.Q4;
     if constexpr (MPC) {
       if (a.mpc_states != nullptr) {   // c_hat = C [x_t; u_t] + c: lane i forms row i's sum, the affine lane of row i takes it   :305-317
-        const float tau = lane < NX ? a.mpc_states[tb * NX + lane] : (lane < NS ? a.mpc_controls[tb * NU + (lane - NX)] : 0.f);
+        float tau = 0.f;
+        if (lane < NX) { if (lane < nx) tau = a.mpc_states[tb * nx + lane]; }
+        else if (lane < NS) { if (lane - NX < nu) tau = a.mpc_controls[tb * nu + (lane - NX)]; }
         float y = 0.f;
-        static_for<0, NS>([&](auto kk) { y = fmaf(crow[kk.value / 4][kk.value % 4], G64::template bcast<kk.value>(tau), y); });
+        static_for<0, NS>([&](auto kk) {
+          const float ck = PAD ? crow_pad[PAD ? kk.value : 0] : crow[PAD ? 0 : kk.value / 4][kk.value % 4];
+          y = fmaf(ck, G64::template bcast<kk.value>(tau), y);
+        });
         static_for<0, NS>([&](auto i) {
           const float yi = G64::template bcast<i.value>(y);
           Q4[i.value / 4][i.value % 4] += col_aff ? yi : 0.f;
@@ -625,6 +646,9 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
       fetch_cost(t, kp);
       fetch_dyn(t, kp);
       step(t, kp, kp);
+    }
+    if constexpr (MPC) {
+      if (live && lane == 0) a.mpc_n_qp_total[b] = n_qp_total;
     }
     if (a.info != nullptr && live && info_bits != 0) atomicOr(&a.info[b], info_bits);
     return;

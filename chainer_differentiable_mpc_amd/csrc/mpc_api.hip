@@ -202,6 +202,20 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     s.mpc_n_qp_total = a.n_qp_total;
     return launch_mpc_wave_backward(nx, nu, s, stream);
   }
+  auto wave_container = [&](int cnx, int cnu) {   // wider than the 16-lane containers: padded inside a wave instance
+    LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
+    s.mpc_controls = a.controls;
+    s.mpc_lower = a.lower;
+    s.mpc_upper = a.upper;
+    s.mpc_states = a.states;
+    s.mpc_n_qp_iter = a.n_qp_iter;
+    s.mpc_n_qp_total = a.n_qp_total;
+    s.nx_log = nx;
+    s.nu_log = nu;
+    return launch_mpc_wave_container_backward(cnx, cnu, s, stream);
+  };
+  const bool wave_ok = a.sync == nullptr && a.done == nullptr && !a.info_store && !mpc_wave_disabled() && !mpc_container_disabled();
+  const bool small = nu <= 4 && nx + nu <= 15;     // (the 16-lane containers below take these)
   if (!mpc_container_disabled()) {   // a smaller problem inside the first container that holds it
     a.nx_log = nx;
     a.nu_log = nu;
@@ -216,6 +230,11 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     DMPC_MPC_CONTAINERS(X)
 #undef X
   }
+  // A padded wave instance costs what ITS shape costs (and fetches element by element, one wavefront per SIMD): measured at
+  // B = 4096, T = 50 it beats the runtime-dimension kernel where the latter's QP in lane 0 is widest - (24,8) 9.2 against
+  // 12.5 ms - and loses below - (20,6) 7.8 against 5.4 ms, (10,5) 5.4 against 2.9 ms.  So: seven or eight controls only.
+  if (wave_ok && !small && nu >= 7 && nx <= 16 && nu <= 8) return wave_container(16, 8);
+  if (wave_ok && !small && nu >= 7 && nx <= 32 && nu <= 8) return wave_container(32, 8);
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
   if (nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
     void *args2[] = {&a, &nx};
