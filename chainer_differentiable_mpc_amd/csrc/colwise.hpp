@@ -139,7 +139,10 @@ __device__ __forceinline__ float fast_rcp(float d) {
 }
 
 // LU as lu_factor_inplace, additionally returning the reciprocal pivots for lu_solve_rinv.
-template <int N>
+// UNIFORM: every lane of the wavefront holds the SAME matrix (the wavefront-per-trajectory kernels): the pivot row is then a
+// wave-uniform value and the interchange - N selects per candidate row and column, most of this routine's instructions at
+// N = 8 - sits behind a scalar branch that a well-conditioned matrix never takes.  Same arithmetic, same results.
+template <int N, bool UNIFORM = false>
 __device__ __forceinline__ bool lu_factor_rinv(float (&A)[N][N], int (&piv)[N], float (&rinv)[N]) {
   bool singular = false;
 #pragma unroll
@@ -153,8 +156,9 @@ __device__ __forceinline__ bool lu_factor_rinv(float (&A)[N][N], int (&piv)[N], 
       best = gt ? v : best;
       p = gt ? i : p;
     }
+    if constexpr (UNIFORM) p = __builtin_amdgcn_readfirstlane(p);
     piv[k] = p + 1;
-    if constexpr (N > 1) {
+    if (N > 1 && (!UNIFORM || p != k)) {
 #pragma unroll
       for (int c = 0; c < N; ++c) {
         const float ak = A[k][c];
@@ -183,12 +187,13 @@ __device__ __forceinline__ bool lu_factor_rinv(float (&A)[N][N], int (&piv)[N], 
   return singular;
 }
 
-template <int N>
+template <int N, bool UNIFORM = false>
 __device__ __forceinline__ void lu_solve_rinv(const float (&LU)[N][N], const int (&piv)[N], const float (&rinv)[N],
                                               float (&x)[N]) {
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int p = piv[k] - 1;
+    if (UNIFORM && p == k) continue;   // (uniform pivots: the interchange behind a scalar branch)
     const float xk = x[k];
     float nk = xk;
 #pragma unroll

@@ -447,8 +447,7 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
       kt[m] = kprev[m];
     }
     PnqpResult<NU> qp;
-    QpTermination per_row;
-    pnqp_solve<NU>(H, qu, lo, hi, kt, /*warm=*/t != T - 1, a.mpc_n_qp_iter, qp, per_row);   // :141-146
+    pnqp_solve_rows<NU, /*UNIFORM=*/true>(H, qu, lo, hi, kt, /*warm=*/t != T - 1, a.mpc_n_qp_iter, qp);   // :141-146
     n_qp_total += 1 + qp.it;
     if (!qp.converged) info_bits |= 4;
 #pragma unroll
@@ -457,7 +456,7 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
     float Kt[NU];
 #pragma unroll
     for (int m = 0; m < NU; ++m) Kt[m] = qp.free_[m] ? Kr[m] : 0.f;
-    lu_solve_rinv<NU>(qp.fac, qp.piv, qp.rinv, Kt);
+    lu_solve_rinv<NU, /*UNIFORM=*/true>(qp.fac, qp.piv, qp.rinv, Kt);   // (the pivots are the QP's: uniform)
 #pragma unroll
     for (int m = 0; m < NU; ++m) Kt[m] = col_aff ? kt[m] : -Kt[m];
     if (k_lane && live && (!PAD || col_aff || lane < nx)) {

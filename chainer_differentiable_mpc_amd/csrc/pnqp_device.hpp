@@ -84,7 +84,7 @@ __device__ __forceinline__ float pnqp_obj(const float (&H)[N][N], const float (&
 // Same decisions, NaN included (both comparisons are false), without the ~20 instructions of an IEEE square root.
 constexpr unsigned kPnqpDxTolSqBits = 0x322BCC76u;
 
-template <int N>
+template <int N, bool UNIFORM = false>
 __device__ __forceinline__ void pnqp_cold_start(const float (&H)[N][N], const float (&q)[N], float (&x)[N]) {
   if constexpr (N == 1) {  // x_init = -H^-1 q                                        pnqp.py:75-83
     x[0] = -fast_rcp(H[0][0]) * q[0];
@@ -95,10 +95,10 @@ __device__ __forceinline__ void pnqp_cold_start(const float (&H)[N][N], const fl
     for (int r = 0; r < N; ++r)
 #pragma unroll
       for (int c = 0; c < N; ++c) A[r][c] = H[r][c];
-    lu_factor_rinv<N>(A, piv, ri);
+    lu_factor_rinv<N, UNIFORM>(A, piv, ri);
 #pragma unroll
     for (int r = 0; r < N; ++r) x[r] = q[r];
-    lu_solve_rinv<N>(A, piv, ri, x);
+    lu_solve_rinv<N, UNIFORM>(A, piv, ri, x);
 #pragma unroll
     for (int r = 0; r < N; ++r) x[r] = -x[r];
   }
@@ -114,11 +114,12 @@ __device__ __forceinline__ void pnqp_cold_start(const float (&H)[N][N], const fl
 // hipcc structurises the data-dependent loops of the straightforward form below (kept for the batch-coupled mode) into
 // nested exec-mask bookkeeping that costs more than the arithmetic: 42-47 % of mpc_backward_rec's time went there
 // (scripts/microbench/mpc_phases.hip).  Same arithmetic, same order, same results as that form with slots == nullptr.
-template <int N>
+// UNIFORM: all lanes of the wavefront run the SAME problem (lqr_wave_mfma_backward<..., MPC>): see lu_factor_rinv.
+template <int N, bool UNIFORM = false>
 __device__ __forceinline__ void pnqp_solve_rows(const float (&H)[N][N], const float (&q)[N], const float (&lo)[N],
                                                 const float (&hi)[N], float (&x)[N], bool warm, int n_iter,
                                                 PnqpResult<N> &res) {
-  if (!warm) pnqp_cold_start<N>(H, q, x);
+  if (!warm) pnqp_cold_start<N, UNIFORM>(H, q, x);
 #pragma unroll
   for (int r = 0; r < N; ++r) x[r] = fminf(fmaxf(x[r], lo[r]), hi[r]);  // :93
   res.converged = false;
@@ -161,10 +162,10 @@ __device__ __forceinline__ void pnqp_solve_rows(const float (&H)[N][N], const fl
       res.rinv[0] = fast_rcp(res.fac[0][0]);
       dx[0] = -res.rinv[0] * gf[0];  // :134
     } else {
-      lu_factor_rinv<N>(res.fac, res.piv, res.rinv);  // :136
+      lu_factor_rinv<N, UNIFORM>(res.fac, res.piv, res.rinv);  // :136
 #pragma unroll
       for (int r = 0; r < N; ++r) dx[r] = gf[r];
-      lu_solve_rinv<N>(res.fac, res.piv, res.rinv, dx);
+      lu_solve_rinv<N, UNIFORM>(res.fac, res.piv, res.rinv, dx);
 #pragma unroll
       for (int r = 0; r < N; ++r) dx[r] = -dx[r];
     }
