@@ -348,13 +348,16 @@ def secondary_metrics(device, d_headline):
     # scripts/imitation_update_timing.py in a process of its own: one of its three figures replays the update from a
     # hipGraph, and a capture that goes wrong inside the HIP runtime must not take the benchmark line with it
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "imitation_update_timing.py")], capture_output=True,
-                       text=True, timeout=600)
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if line:
-        out["config4_imitation_step"] = json.loads(line[-1])
-    else:
-        out["config4_imitation_step"] = {"error": "imitation_update_timing.py rc=%d: %s" % (r.returncode, r.stderr[-400:])}
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "imitation_update_timing.py")], capture_output=True,
+                           text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if line:
+            out["config4_imitation_step"] = json.loads(line[-1])
+        else:
+            out["config4_imitation_step"] = {"error": "imitation_update_timing.py rc=%d: %s" % (r.returncode, r.stderr[-400:])}
+    except subprocess.TimeoutExpired:       # only this entry carries the error: the other secondary numbers stand
+        out["config4_imitation_step"] = {"error": "imitation_update_timing.py did not finish within 600 s"}
     return out
 
 
@@ -379,7 +382,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS))
-    ap.add_argument("--gather", action="store_true", help="all-gather (x*, u*) over RCCL inside the timed region")
+    ap.add_argument("--gather", action="store_true", help="all-gather (x*, u*) over RCCL inside the timed region, overlapped "
+                    "with the next solve (dist.GatherPipeline); the line then carries solve / gather / serial / overlapped times")
+    ap.add_argument("--gather-chunks", type=int, default=0, help="pieces per gathered tensor (0: by size, <= 64 MB each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-procs", type=int, default=0, help="worker processes of the sharded CPU baseline "
@@ -413,13 +418,20 @@ def main():
         cb, xr, ur = cpu_baseline(p_host, T, nx, nu, args.cpu_seconds)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    # rehearsal knobs (tests/test_dist_gpu.py runs this file with two ranks on a ONE-GPU box): DMPC_BENCH_BACKEND=gloo takes
+    # the collectives through the host (RCCL refuses two ranks on one device), DMPC_BENCH_DEVICE pins every rank's device
+    backend = os.environ.get("DMPC_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", int(os.environ.get("DMPC_BENCH_DEVICE", local_rank)))
     torch.cuda.set_device(device)
+    red_dev = device if backend == "nccl" else torch.device("cpu")     # where the timing reductions live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     p, d = make_inputs(B, T, nx, nu, seed=rank, device=device)
     # "Inputs resident in HBM when the timed region starts" - in HBM, not in the 256 MiB Infinity Cache: where one input
@@ -430,20 +442,26 @@ def main():
     sets = [d] + [make_inputs(B, T, nx, nu, seed=1000 + 16 * rank + k, device=device)[1] for k in range(1, n_sets)]
     x = torch.empty((T, B, nx), dtype=torch.float32, device=device)
     u = torch.empty((T, B, nu), dtype=torch.float32, device=device)
-    gx = gu = None
+    # --gather: the all-gather of (x*, u*) travels on a side stream, in chunks, while the NEXT solve runs
+    # (dist.GatherPipeline; SURVEY.md section 5: at config 5 the gather costs about what the solve costs)
+    gx = pipe = None
     if args.gather and world > 1:
-        gx = torch.empty((world,) + tuple(x.shape), dtype=torch.float32, device=device)
-        gu = torch.empty((world,) + tuple(u.shape), dtype=torch.float32, device=device)
+        from chainer_differentiable_mpc_amd.dist import GatherPipeline
+        pipe = GatherPipeline([tuple(x.shape), tuple(u.shape)], device, chunks=args.gather_chunks or None)
+        gx = pipe
 
     k_step = [0]
 
     def step():
-        e = sets[k_step[0] % n_sets]
+        k = k_step[0]
+        e = sets[k % n_sets]
         k_step[0] += 1
-        solve_device(e["C"], e["c"], e["F"], e["f"], e["x_init"], None, T, nx, nu, out=(x, u))
-        if gx is not None:
-            dist.all_gather_into_tensor(gx, x)
-            dist.all_gather_into_tensor(gu, u)
+        if pipe is None:
+            solve_device(e["C"], e["c"], e["F"], e["f"], e["x_init"], None, T, nx, nu, out=(x, u))
+        else:
+            xs, us = pipe.local_buffers(k)
+            solve_device(e["C"], e["c"], e["F"], e["f"], e["x_init"], None, T, nx, nu, out=(xs, us))
+            pipe.gather(k)
 
     # For the record, the contract's protocol from a cold device first (W warm-up steps, K timed ones - a window of a
     # millisecond at the driver's K = 20): reported as `cold_start`, never as `value`
@@ -484,13 +502,52 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kern_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
     kern_name = kernel_name() if gx is None else None      # (with --gather the last launch is RCCL's, not ours)
+    gather_info = None
+    if pipe is not None:
+        # the three times the overlapped figure is made of, every rank making the same number of calls (collectives inside):
+        # the solve alone, the gather alone (side stream, waited for), and the two one after the other on one stream
+        e0 = sets[0]
+
+        def timed(fn, reps=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t_0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_0) / reps
+
+        def solve_only():
+            solve_device(e0["C"], e0["c"], e0["F"], e0["f"], e0["x_init"], None, T, nx, nu, out=(x, u))
+
+        def gather_only():
+            pipe.gather(0)
+            pipe.result(0)
+
+        def serial():
+            xs, us = pipe.local_buffers(0)
+            solve_device(e0["C"], e0["c"], e0["F"], e0["f"], e0["x_init"], None, T, nx, nu, out=(xs, us))
+            pipe.gather(0)
+            pipe.result(0)
+            torch.cuda.current_stream().synchronize()
+
+        ts = torch.tensor([timed(solve_only), timed(gather_only), timed(serial)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        gather_info = {"solve_ms": float(ts[0]) * 1e3, "gather_ms": float(ts[1]) * 1e3, "serial_ms": float(ts[2]) * 1e3,
+                       "overlapped_ms": elapsed / args.steps * 1e3, "chunks": pipe.chunks,
+                       "gathered_bytes_per_rank": world * (x.numel() + u.numel()) * 4,
+                       "what": "max over ranks; overlapped = the timed region of this line (solve k+1 on the launch stream "
+                               "while the chunked all-gather of solve k's (x, u) runs on a side stream)"}
     # for the parity check: the solution of set 0, whatever set the last timed step solved
     solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u))
+    torch.cuda.synchronize()
     x_host, u_host = x.cpu().numpy(), u.cpu().numpy()
     # context for the number above (N = 1): the same launch re-solving ONE input set (what rounds 1-2 timed: a set that
     # fits the Infinity Cache), and what this box's memory system sustains on a plain copy
@@ -530,11 +587,27 @@ def main():
                                    "input sets in rotation)"
                                    % (args.workload, B, T, nx, nu),
                        "global_batch": world * B, "parallelism": "batch-shard x%d%s" % (
-                           world, " + all-gather(x,u)" if gx is not None else ", no collective")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                           world, " + overlapped all-gather(x,u)" if gx is not None else ", no collective")
+                       + ("" if backend == "nccl" else " [REHEARSAL: backend %s, every rank on %s - not a scaling number]" % (backend, device))},
+            # `frac` is the SMALLER of the two clocks' figures: HIP events on the launch stream around the K timed launches
+            # (`frac_events`) and the host's wall clock around the same region incl. the final synchronisation
+            # (`frac_wall`, from `ms_per_step`).  The protocol of the measurement travels inside this object (the driver's
+            # parsed record keeps `roofline` whole): the untimed run-up and what the same W + K steps take from a cold start.
+            "roofline": {"bound": "hbm", "achieved": min(achieved, alg_bytes / (elapsed / args.steps) / 1e9),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": min(achieved, alg_bytes / (elapsed / args.steps) / 1e9) / HBM_PEAK_GBS,
+                         "frac_events": achieved / HBM_PEAK_GBS,
+                         "frac_wall": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kern_name,
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3},
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
+                         "kernel_ms_wall": elapsed / args.steps * 1e3,
+                         "protocol": "value/frac are taken AFTER an untimed run-up of the same step to the device's steady "
+                                     "clocks (device_run_up_steps launches, device_run_up_ms), then the contract's W warm-up and "
+                                     "K timed steps; cold_start_ms_per_step is the same W + K protocol run before the run-up",
+                         "device_run_up_steps": pre_calls, "device_run_up_ms": pre_ms,
+                         "cold_start_ms_per_step": None if cold is None else cold * 1e3,
+                         "cold_start_frac": None if cold is None else alg_bytes / cold / 1e9 / HBM_PEAK_GBS},
             # what ran on the device before the W warm-up steps and the K timed ones: the same step, untimed, until its
             # time had settled (the steady power state of a running job; scripts/clock_ramp.py has the ramp)
             "cold_start": None if cold is None else {
@@ -564,6 +637,8 @@ def main():
                                     "box_copy_what": "device-to-device copy of 1 GiB on this box (read + write traffic, GB/s): "
                                                      "what its memory system sustains on the plainest streaming pattern "
                                                      "(MI355X_MICROARCH.md: 6290); boxes of the pool differ"})
+        if gather_info is not None:
+            out["gather"] = gather_info
         parity_ok, secondary_failed = True, False
         if cb is not None:
             out["cpu_baseline"] = cb

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdmpc_hip.so"
 LIB_PATH = os.environ.get("DMPC_LIB", os.path.join(_HERE, LIB_NAME))
 
+ABI_VERSION = 400           # include/dmpc.h: DMPC_VERSION the signatures below were written for
 E_BADARG, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 INFO_SINGULAR, INFO_NONFINITE, INFO_QP_ITERCAP, INFO_LS_ITERCAP = 1, 2, 4, 8
 
@@ -85,9 +86,35 @@ def load(path=None):
             fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        _check_identity(lib, p, explicit=path is not None or "DMPC_LIB" in os.environ)
         if path is None:
             _lib = lib
         return lib
+
+
+def _check_identity(lib, p, explicit):
+    """A library with another ABI number would receive shifted pointer arguments: refuse it.  The in-tree library must
+    also be the one built from the sources in the tree (`dmpc_source_hash()` against csrc/build.py's hash of them); a
+    library named explicitly (`load(path)`, `DMPC_LIB`: the variant builds of scripts/*_variants.sh) is exempt from the
+    hash comparison, never from the version check.  `DMPC_SKIP_HASH_CHECK=1` drops the hash comparison for the default
+    library too (a checkout whose sources are being edited while an older build is deliberately kept)."""
+    ver = lib.dmpc_version()
+    if ver != ABI_VERSION:
+        raise DmpcError("%s has C-ABI version %d, this binding was written for %d - rebuild it (python %s)" % (
+            p, ver, ABI_VERSION, os.path.join(_HERE, "csrc", "build.py")))
+    if explicit or os.environ.get("DMPC_SKIP_HASH_CHECK") == "1":
+        return
+    build_py = os.path.join(_HERE, "csrc", "build.py")
+    if not os.path.exists(build_py):
+        return                      # installed without sources: nothing to compare against
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_dmpc_build", build_py)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want, got = mod.source_hash(), lib.dmpc_source_hash().decode()
+    if want != got:
+        raise DmpcError("%s was built from other sources (library %s, tree %s) - rebuild it (python %s), or set "
+                        "DMPC_SKIP_HASH_CHECK=1 to use it anyway" % (p, got, want, build_py))
 
 
 def last_kernel_name():

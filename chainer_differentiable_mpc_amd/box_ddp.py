@@ -220,13 +220,20 @@ class BoxDDP(torch.nn.Module):
         if rc == _lib.E_UNSUPPORTED:
             return None
         _lib.check(rc, "dmpc_box_ddp")
-        self._pending = (state, info)
         self._loop_flag = state[7:8]              # device int: some trajectory's best full_du_norm is above eps (:263)
         self._warn_unconverged = False
-        if self not in _UNRESOLVED:
-            _UNRESOLVED.append(self)
-        if not self.lazy_status:
-            self._resolve()                       # the one synchronisation of the loop
+        if torch.cuda.is_current_stream_capturing():
+            # recorded into a hipGraph, not executed: `state` holds nothing until a replay, and a replay is not this call -
+            # there is no read-back to defer (a captured solve reports through its outputs and device flags only)
+            self._pending = None
+            if self in _UNRESOLVED:
+                _UNRESOLVED.remove(self)
+        else:
+            self._pending = (state, info)
+            if self not in _UNRESOLVED:
+                _UNRESOLVED.append(self)
+            if not self.lazy_status:
+                self._resolve()                   # the one synchronisation of the loop
         dev, dt = x_init.device, x_init.dtype
         best = {'x': bx.to(device=dev, dtype=dt), 'u': bu.to(device=dev, dtype=dt),
                 'costs': bc.to(device=dev, dtype=dt), 'full_du_norm': bn.to(device=dev, dtype=dt)}
@@ -388,11 +395,13 @@ class BoxDDP(torch.nn.Module):
         node = MPCstep(controls=u, T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=nx, n_ctrl=nu, current_states=x,
                        true_cost=detached_cost(), true_dynamics=detached_dyn(), ls_decay=self.ls_decay,
                        max_ls_iter=self.max_ls_iter, verbose=self.ilqr_verbose, need_expand=True, no_op_forward=True)
+        if isinstance(cost, TiledQuadCost) and not self.update_dynamics:
+            # host loop / CPU tensors / a refused device loop: tile (Q, p) ON the graph before asking whether anything can
+            # receive a gradient - TiledQuadCost.C / .c are detached copies, the learnable tensors are Q and p
+            Cm = cost.Q[None, None].expand(T, B, -1, -1)
+            cm = cost.p[None, None].expand(T, B, -1)
         needs_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (Cm, cm, Fm, fm, x_init))
         if needs_graph:
-            if isinstance(cost, TiledQuadCost) and not self.update_dynamics:   # (host loop / CPU tensors: tile on the graph)
-                Cm = cost.Q[None, None].expand(T, B, -1, -1)
-                cm = cost.p[None, None].expand(T, B, -1)
             x, u = node.apply((x[0].detach(), Cm, cm, Fm, fm))
         if self.detach_unconverged and unconverged():                                      # :263-289
             self._warn()

@@ -7,10 +7,34 @@ independent, so the batch axis shards with NO data-path collective: each rank ow
   * `all_gather_batch`  - the final x*, u* (SURVEY.md 8e); a direct all-gather, outputs stay sharded unless
     the caller asks for them;
   * `all_reduce_param_grad` - gradients AFTER reduction to parameter shape (e.g. dA, dB = sum_{t,b} dF of
-    LqrNet: `expand_time_batch`'s backward is a sum), never the per-sample dC/dF.
+    LqrNet: `expand_time_batch`'s backward is a sum), never the per-sample dC/dF;
+  * `GatherPipeline` - the same all-gather taken OFF the solver's stream (at config 5 the gather of
+    (x*, u*) costs about what the solve costs): solve k+1 runs on the caller's stream while the (x, u) of solve k travel,
+    in chunks, on a side stream; two output buffers in rotation.
+
+A backend that cannot move device memory (gloo: the CPU tests, and the two-ranks-on-one-GPU test of the HIP path) is served
+by staging the collective through host memory - same calls, same results.
 """
 import torch
 import torch.distributed as dist
+
+
+def _needs_host_staging(t, group=None):
+    """gloo has no device all-gather: device tensors go through the host for the collective"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out, inp, group=None):
+    """dist.all_gather_into_tensor for any backend / device combination; `out` is [world * n, ...] or [world, n, ...] for an
+    input [n, ...] (gloo accepts only the concatenated form: the stacked one is passed as its flat view)"""
+    if out.dim() == inp.dim() + 1:
+        out = out.view((out.shape[0] * out.shape[1],) + tuple(out.shape[2:]))
+    if _needs_host_staging(inp, group):
+        h_out = torch.empty(out.shape, dtype=out.dtype, device="cpu")
+        dist.all_gather_into_tensor(h_out, inp.cpu(), group=group)
+        out.copy_(h_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
 
 
 def shard_bounds(n_batch, rank, world):
@@ -50,18 +74,18 @@ def all_gather_batch(local, n_batch_total=None, batch_dim=1, group=None):
     else:
         mine = torch.tensor([local.shape[batch_dim]], dtype=torch.int64, device=local.device)
         every = torch.empty((world,), dtype=torch.int64, device=local.device)
-        dist.all_gather_into_tensor(every, mine, group=group)
+        _all_gather_into(every, mine, group)
         sizes = [int(v) for v in every.cpu().tolist()]
     moved = local.movedim(batch_dim, 0).contiguous()
     if len(set(sizes)) == 1:
         out = torch.empty((world * moved.shape[0],) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
-        dist.all_gather_into_tensor(out, moved, group=group)
+        _all_gather_into(out, moved, group)
     else:   # ragged split: pad every shard to the largest, gather, drop the padding
         mx = max(sizes)
         padded = torch.zeros((mx,) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
         padded[: moved.shape[0]] = moved
         buf = torch.empty((world * mx,) + tuple(moved.shape[1:]), dtype=moved.dtype, device=moved.device)
-        dist.all_gather_into_tensor(buf, padded, group=group)
+        _all_gather_into(buf, padded, group)
         out = torch.cat([buf[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
     return out.movedim(0, batch_dim).contiguous()
 
@@ -69,5 +93,107 @@ def all_gather_batch(local, n_batch_total=None, batch_dim=1, group=None):
 def all_reduce_param_grad(g, group=None):
     """sum a parameter-shaped gradient over ranks (in place)"""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+        if _needs_host_staging(g, group):
+            h = g.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            g.copy_(h)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
     return g
+
+
+class GatherPipeline:
+    """All-gather of a solve's outputs overlapped with the NEXT solve (one process per GPU, equal shards).
+
+        pipe = GatherPipeline([(T, b, nx), (T, b, nu)], device)           # shapes of the local x, u
+        for k in range(steps):
+            x, u = pipe.local_buffers(k)            # where solve k writes (two sets in rotation)
+            solve_device(..., out=(x, u))           # caller's stream
+            pipe.gather(k)                          # enqueued on the side stream; returns at once
+        gx, gu = pipe.result(k)                     # the gathered x, u of solve k (pieces), the caller's stream waits
+        x_all = GatherPipeline.as_time_major(gx)    # [T, world * b, nx], the reference's layout (one copy)
+
+    Each tensor travels in `chunks` pieces along the time axis, one collective per piece, written straight into its final
+    place: a gathered tensor is a list of pieces `[world, dt, b, ...]` (rank-major inside a piece - what an all-gather writes
+    without a transposing copy), all pieces of a tensor carved out of one allocation.  Pieces of a few tens of MB keep
+    RCCL's ring busy without holding the side stream for the whole 270 MB of a config-5 shard in one call.  Ordering: the
+    side stream waits for solve k (an event on the caller's stream); the caller's stream waits for gather k-2 before solve
+    k overwrites that buffer set (`local_buffers`), and for gather k in `result(k)`."""
+
+    def __init__(self, shapes, device, dtype=torch.float32, chunks=None, group=None, max_chunk_bytes=64 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        self.shapes = [tuple(int(v) for v in s) for s in shapes]
+        T = self.shapes[0][0]
+        assert all(s[0] == T for s in self.shapes), "every tensor is time-major with the same horizon"
+        if chunks is None:
+            esz = torch.empty(0, dtype=dtype).element_size()
+            biggest = max(esz * self.world * _prod(s) for s in self.shapes)
+            chunks = max(1, min(T, -(-biggest // max_chunk_bytes)))
+        self.chunks = max(1, min(int(chunks), T))
+        step = -(-T // self.chunks)
+        self.slices = [(t0, min(T, t0 + step)) for t0 in range(0, T, step)]
+        self.local = [[torch.empty(s, dtype=dtype, device=self.device) for s in self.shapes] for _ in range(2)]
+        self.out = [[self._pieces(s, dtype) for s in self.shapes] for _ in range(2)]
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.gathered = [None, None]    # event: gather k has finished (side stream)
+
+    def _pieces(self, shape, dtype):
+        flat = torch.empty((self.world * _prod(shape),), dtype=dtype, device=self.device)
+        pieces, off = [], 0
+        for (t0, t1) in self.slices:
+            n = self.world * (t1 - t0) * _prod(shape[1:])
+            pieces.append(flat[off:off + n].view((self.world, t1 - t0) + tuple(shape[1:])))
+            off += n
+        return pieces
+
+    def local_buffers(self, k):
+        """the buffer set solve k writes; the caller's stream first waits for the gather that last read it (k - 2)"""
+        ev = self.gathered[k % 2]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return self.local[k % 2]
+
+    def gather(self, k):
+        """enqueue the all-gather of buffer set k % 2 behind the work now on the caller's stream, on the side stream"""
+        loc, out = self.local[k % 2], self.out[k % 2]
+        if not self.cuda:
+            for pieces, t in zip(out, loc):
+                for piece, (t0, t1) in zip(pieces, self.slices):
+                    _all_gather_into(piece, t[t0:t1], self.group)
+            return
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(done)
+            for pieces, t in zip(out, loc):
+                for piece, (t0, t1) in zip(pieces, self.slices):
+                    _all_gather_into(piece, t[t0:t1], self.group)     # t[t0:t1] of a time-major tensor is contiguous
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.gathered[k % 2] = ev
+
+    def result(self, k):
+        """the gathered tensors of solve k (one list of pieces per tensor); the caller's stream waits for their arrival"""
+        ev = self.gathered[k % 2]
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+        return self.out[k % 2]
+
+    @staticmethod
+    def as_time_major(pieces):
+        """pieces [world, dt, b, ...] -> [T, world * b, ...] (a contiguous copy): the reference's layout"""
+        rows = []
+        for g in pieces:
+            w, dt, b = g.shape[:3]
+            rows.append(g.transpose(0, 1).reshape((dt, w * b) + tuple(g.shape[3:])))
+        return torch.cat(rows, dim=0)
+
+
+def _prod(shape):
+    n = 1
+    for v in shape:
+        n *= int(v)
+    return n

@@ -14,8 +14,12 @@ from .util import TiledQuadCost
 class IL_Env:
     """Imitation-learning environment (il_env.py:22).  `device` is where the trajectories are computed."""
 
-    def __init__(self, env, lqr_iter=500, mpc_T=20, device="cuda", dtype=torch.float32, quiet=True):
+    def __init__(self, env, lqr_iter=500, mpc_T=20, device="cuda", dtype=torch.float32, quiet=True, lazy_status=False):
+        # lazy_status=True (opt-in): `BoxDDP(lazy_status=True)` - a solve returns before the device loop's read-back, so a
+        # training loop keeps launching; asserts / NaN checks of a solve then arrive with `flush()`, the next solve, or the
+        # first access of `last_solver.status`.  Default: every solve is checked before `mpc` returns, as in the reference.
         assert env == 'pendulum'                                     # il_env.py:35-38
+        self.lazy_status = bool(lazy_status)
         self.env = env
         self.true_dx = PendulumDx()
         self.lqr_iter = lqr_iter
@@ -24,7 +28,14 @@ class IL_Env:
         self.train_data = self.val_data = self.test_data = None
 
     # the pickle of env_dx/make_dataset.py holds numpy arrays; keep that format (and no device handles) on disk
+    def flush(self):
+        """resolve every deferred read-back (asserts, NaN flags, status, the non-convergence warning) - called at the data
+        set and pickle boundaries; a training loop with lazy_status=True calls it once per epoch"""
+        for solver in getattr(self, "_solvers", {}).values():
+            solver._resolve()
+
     def __getstate__(self):
+        self.flush()
         st = dict(self.__dict__)
         st.pop("_solvers", None)
         st.pop("last_solver", None)
@@ -66,6 +77,7 @@ class IL_Env:
         true_q, true_p = self.true_dx.get_true_obj()
         with torch.no_grad():
             x_mpc, u_mpc = self.mpc(self.true_dx, xinit, true_q, true_p, update_dynamics=True)
+        self.flush()
         tau = torch.cat((x_mpc, u_mpc), dim=2).transpose(0, 1).contiguous()
         self.train_data = tau[:n_train]
         self.val_data = tau[n_train:n_train + n_val]
@@ -83,7 +95,8 @@ class IL_Env:
         # the reference builds a BoxDDP per call (il_env.py:131-156); the solver object holds nothing of a solve but its
         # status, so one per configuration is kept (a torch Module costs ~0.1 ms to construct - a seventh of a step)
         key = (n_batch, eps_override if eps_override else self.true_dx.mpc_eps,
-               lqr_iter_override if lqr_iter_override else self.lqr_iter, bool(update_dynamics), self.quiet, str(self.device))
+               lqr_iter_override if lqr_iter_override else self.lqr_iter, bool(update_dynamics), self.quiet, str(self.device),
+               getattr(self, "lazy_status", False))
         solver = self._solvers.get(key) if hasattr(self, "_solvers") else None
         if solver is None:
             solver = BoxDDP(T=self.mpc_T, u_lower=self.true_dx.lower, u_upper=self.true_dx.upper, n_batch=n_batch,
@@ -91,7 +104,7 @@ class IL_Env:
                             max_iter=key[2], verbose=False, exit_unconverged=False, detach_unconverged=True,
                             line_search_decay=self.true_dx.linesearch_decay,
                             max_line_search_iter=self.true_dx.max_linesearch_iter, update_dynamics=update_dynamics,
-                            quiet=self.quiet, lazy_status=self.quiet)   # (quiet: nothing to print, nothing to wait for)
+                            quiet=self.quiet, lazy_status=key[6])
             if not hasattr(self, "_solvers"):
                 self._solvers = {}
             self._solvers[key] = solver

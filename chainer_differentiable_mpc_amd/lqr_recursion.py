@@ -146,27 +146,26 @@ class LqrRecursion:
 
 
 _ws_cache = collections.OrderedDict()
-_WS_CACHE_STREAMS = 4      # scratch buffers kept (least recently used first out): programs with short-lived streams
+_WS_CACHE_PER_DEVICE = 4   # scratch buffers kept per device (least recently used first out): programs with short-lived streams
 
 
 def _workspace(nbytes, device):
     """grow-only scratch per (device, stream) - the C library allocates nothing itself.  Calls enqueued on one stream
     are ordered, so they may share a buffer; calls on different streams get different buffers.  A buffer that is
-    replaced by a larger one, or dropped as the least recently used, goes back to torch's caching allocator, which keeps
-    it tied to the stream it was allocated on (the same one), so kernels still in flight on it are safe; a buffer
-    found under a stream handle that torch has recycled was allocated on another stream and is marked as used on this
-    one (`record_stream`)."""
+    replaced by a larger one, or dropped as the least recently used OF ITS DEVICE (a process driving eight GPUs keeps
+    eight working sets, not four buffers in all), goes back to torch's caching allocator, which keeps it tied to the stream
+    it was allocated on (the same one), so kernels still in flight on it are safe.  The key is the raw stream handle: a
+    handle that torch hands out again after the stream object died names a stream on which the earlier work has been
+    submitted in order, which is all the sharing rule needs."""
     stream = _lib.stream_ptr(device) if device.type == "cuda" else 0
     key = (device.type, device.index, stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
-        while len(_ws_cache) > _WS_CACHE_STREAMS:
-            _ws_cache.popitem(last=False)
-    elif device.type == "cuda":
-        ws.record_stream(torch.cuda.current_stream(device)) if stream != getattr(ws, "_dmpc_stream", stream) else None
-    ws._dmpc_stream = stream
+        mine = [k for k in _ws_cache if k[:2] == key[:2]]
+        for k in mine[:max(0, len(mine) - _WS_CACHE_PER_DEVICE)]:
+            del _ws_cache[k]
     _ws_cache.move_to_end(key)
     return ws
 

@@ -26,7 +26,12 @@
 extern "C" {
 #endif
 
-#define DMPC_VERSION 202 /* 0.2.1: dmpc_box_ddp clears info itself and reports its input checks in state[4:8] */
+/* Bumped whenever a signature, the meaning of an argument or a workspace size changes; the Python binding refuses a library
+ * whose number differs from the one its ctypes signatures were written for (_lib.py: ABI_VERSION).
+ * 400 (round 4): covers the round-3 changes that were made under 202 (dmpc_lqr_solve_saving + Vv_out, dmpc_lqr_kkt_grad_saved
+ * + Vv, dmpc_pendulum_rollout_linearize + clamp_grad_closed, dmpc_mpc_step_backward + 5 arguments, dmpc_box_ddp dyn_params[6],
+ * larger dmpc_lqr_workspace_bytes) and this round's additions. */
+#define DMPC_VERSION 400
 
 #define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
 #define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */

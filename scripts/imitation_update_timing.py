@@ -11,7 +11,7 @@ device = torch.device("cuda")
 Bp, Tp = int(os.environ.get("B", "1024")), 20
 dx = PendulumDx()
 out = {}
-env = IL_Env("pendulum", lqr_iter=10, mpc_T=Tp, device=device)
+env = IL_Env("pendulum", lqr_iter=10, mpc_T=Tp, device=device, lazy_status=True)
 np.random.seed(0)
 xi = torch.as_tensor(IL_Env.sample_xinit(Bp), dtype=torch.float32, device=device)
 with warnings.catch_warnings():

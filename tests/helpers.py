@@ -9,6 +9,27 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 #   |delta| <= 1e-4 * max(1, |ref|) for x, u, dC, dc;  5e-4 * max(1, |ref|) for dx_init, dF, df
 TOL_PRIMAL = 1e-4
 TOL_COSTATE = 5e-4
+# One MPC step (backward_rec with a box QP per timestep + line search): the SAME contract - gains, controls, states and
+# costs at 1e-4, the step's co-state gradients at 5e-4.  Round 3 ran these at 2e-4 / 5e-4 without having measured them; the
+# measured worst cases (profiles/r04/parity_margins.txt) are 1e-6 ... 7e-6 on the synthetic goldens.  The one place that
+# needs more is a step of the NON-LINEAR pendulum problem from a common iterate (configs 2 and 4): there float32 evaluation of
+# the step's model (rollout, linearisation, re-centred cost) differs from the float64 reference's and the box QP /
+# line search amplify that to 1.3e-4 worst over 1,024 trajectories - TOL_STEP_PENDULUM, calibrated the way SURVEY 8d calibrated
+# the LQR contract: the oracle's own arithmetic with the rollout, linearisation and re-centring in float32 moves the worst rows
+# of that step by 1e-4 (tests/test_oracle_golden.py::test_pendulum_step_float32_calibration; rounding the inputs alone: 7e-7).
+TOL_STEP = TOL_PRIMAL
+TOL_STEP_PENDULUM = 2e-4
+
+
+def log_margin(what, worst, tol):
+    """DMPC_PARITY_LOG=<file>: every parity assertion appends `test id | quantity | measured worst error | tolerance`, so
+    that one run of the GPU suite writes the margins the tolerances are stated against (`scripts/parity_margins.py`
+    condenses the file into profiles/rNN/parity_margins.txt)."""
+    path = os.environ.get("DMPC_PARITY_LOG")
+    if path:
+        test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" (")[0]
+        with open(path, "a") as fh:
+            fh.write("%s | %s | %.3e | %.1e\n" % (test, what, worst, tol))
 
 
 def assert_close(got, ref, tol, what=""):
@@ -17,6 +38,7 @@ def assert_close(got, ref, tol, what=""):
     assert got.shape == ref.shape, "%s shape %s vs %s" % (what, got.shape, ref.shape)
     err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
     worst = float(err.max()) if err.size else 0.0
+    log_margin(what, worst, tol)
     assert np.isfinite(got).all(), "%s: non-finite values" % what
     assert worst <= tol, "%s: max |delta|/max(1,|ref|) = %.3e > %.1e" % (what, worst, tol)
     return worst

@@ -13,7 +13,7 @@ from chainer_differentiable_mpc_amd.util import get_traj
 from chainer_differentiable_mpc_amd.pendulum import sample_xinit
 from oracle import box_ddp as obox
 from oracle import mpc as ompc
-from tests.helpers import GOLDEN, assert_close, assert_step_close, npy
+from tests.helpers import GOLDEN, TOL_COSTATE, TOL_PRIMAL, TOL_STEP_PENDULUM, assert_close, assert_step_close, npy
 
 pytestmark = pytest.mark.gpu
 
@@ -32,9 +32,9 @@ def test_box_ddp_reference_trace():
         warnings.simplefilter("ignore")
         x, u, costs = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
     assert solver.status in str(g["stdout"])
-    assert_close(npy(u), g["u"], 5e-4, "u")
-    assert_close(npy(x), g["x"], 5e-4, "x")
-    assert_close(npy(costs), g["costs"], 5e-4, "costs")
+    assert_close(npy(u), g["u"], TOL_PRIMAL, "u")
+    assert_close(npy(x), g["x"], TOL_PRIMAL, "x")
+    assert_close(npy(costs), g["costs"], TOL_PRIMAL, "costs")
 
 
 def pendulum_problem(B, T, seed=0):
@@ -106,7 +106,7 @@ def test_pendulum_box_ddp_config2_against_oracle():
                                         np.full(len(rows), alpha), T)
             return xc, uc
 
-        nt, nf = assert_step_close(npy(un), npy(xn), uo, xo, old, fo.costs, candidates, 2e-4, "step from iterate %d" % k)
+        nt, nf = assert_step_close(npy(un), npy(xn), uo, xo, old, fo.costs, candidates, TOL_STEP_PENDULUM, "step from iterate %d" % k)
         n_tie, n_fork = n_tie + nt, n_fork + nf
         assert (npy(step.for_out.costs) <= old + 4e-6 * np.abs(old) + 1e-5).all(), k      # descent on every sample
     assert n_tie < 3 * B // 2                          # ties are a minority: most rows were held to the plain tolerance
@@ -136,9 +136,9 @@ def test_box_ddp_lindx_b128_against_oracle():
                                                   T, -0.3, 0.3, nx, nu, batch_coupled=False, eps=1e-3)
     assert solver.status.strip() == status.strip() and solver.n_iter == n_iter, (solver.status, solver.n_iter, status, n_iter)
     assert float((u.abs() == 0.3).float().mean()) > 0.1
-    assert_close(npy(u), ur, 5e-4, "u")
-    assert_close(npy(x), xr, 1e-3, "x")        # the open-loop rollout over T = 20 amplifies the controls' 5e-4
-    assert_close(npy(costs), cr, 5e-4, "costs")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(costs), cr, TOL_PRIMAL, "costs")
 
 
 def test_pendulum_analytic_linearisation_matches_autograd():
@@ -185,7 +185,7 @@ def test_mpcnet_gradient_flows_to_dynamics_parameters():
     dF = out[3].sum(axis=(0, 1))
     got = np.concatenate((net.A.grad.cpu().numpy(), net.B.grad.cpu().numpy()), axis=1)
     if net.mpc_layer.status == "Converged":
-        assert_close(got, dF, 2e-3, "d(A|B)")
+        assert_close(got, dF, TOL_COSTATE, "d(A|B)")
     else:   # unconverged samples are detached (box_ddp.py:263-289): only check the gradient is finite and non-zero
         assert np.isfinite(got).all() and np.abs(got).max() > 0
 
@@ -336,7 +336,7 @@ def test_device_loop_matches_host_loop_pendulum_long_horizon():
                                     ompc.QuadCost(Q[:, rows], pv[:, rows]), obox.pendulum_step, np.full(len(rows), alpha), T)
         return xc, uc
 
-    assert_step_close(npy(un), npy(xn), uo, xo, old, fo.costs, candidates, 2e-4, "step at T = 40")
+    assert_step_close(npy(un), npy(xn), uo, xo, old, fo.costs, candidates, TOL_STEP_PENDULUM, "step at T = 40")
 
 
 @pytest.mark.parametrize("shape", [(16, 8, 3, 2, 0.3), (64, 12, 8, 2, 0.5), (5, 6, 4, 2, 10.0), (12, 6, 5, 3, 0.5)])
@@ -348,9 +348,9 @@ def test_device_loop_matches_host_loop_lindx(shape):
         lambda dl: BoxDDP(T, -bound, bound, B, nx, nu, None, max_iter=10, quiet=True, device_loop=dl),
         lambda: (dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
     assert dev_[3] == host[3] and dev_[4] == host[4], (dev_[3:], host[3:])
-    assert_close(dev_[1], host[1], 5e-4, "u")
-    assert_close(dev_[0], host[0], 5e-4, "x")
-    assert_close(dev_[2], host[2], 5e-4, "costs")
+    assert_close(dev_[1], host[1], TOL_PRIMAL, "u")
+    assert_close(dev_[0], host[0], TOL_PRIMAL, "x")
+    assert_close(dev_[2], host[2], TOL_PRIMAL, "costs")
 
 
 def test_device_loop_stops_early_and_freezes_the_result():
@@ -381,4 +381,4 @@ def test_device_loop_gradient_through_the_final_node():
         (x.sum() + u.sum()).backward()
         grads.append(npy(F.grad))
     assert np.abs(grads[0]).max() > 0
-    assert_close(grads[0], grads[1], 2e-3, "dF")   # rollout rounding (kernel vs torch ops) through the co-state sweep
+    assert_close(grads[0], grads[1], TOL_COSTATE, "dF")

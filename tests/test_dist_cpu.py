@@ -65,3 +65,39 @@ def test_shard_bounds_partition_the_batch():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def pipeline_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chainer_differentiable_mpc_amd.dist import GatherPipeline
+    T, b, nx, nu = 7, 3, 4, 2
+    for chunks in (1, 3, None):
+        pipe = GatherPipeline([(T, b, nx), (T, b, nu)], "cpu", chunks=chunks)
+        got = []
+        for k in range(4):               # four "solves" through the two buffer sets
+            x, u = pipe.local_buffers(k)
+            x.copy_(torch.arange(T * b * nx, dtype=torch.float32).view(T, b, nx) + 1000 * rank + 10000 * k)
+            u.copy_(-(torch.arange(T * b * nu, dtype=torch.float32).view(T, b, nu) + 1000 * rank + 10000 * k))
+            pipe.gather(k)
+            gx, gu = pipe.result(k)
+            got.append((GatherPipeline.as_time_major(gx).clone(), GatherPipeline.as_time_major(gu).clone()))
+        for k, (gx, gu) in enumerate(got):
+            for r in range(world):
+                want = torch.arange(T * b * nx, dtype=torch.float32).view(T, b, nx) + 1000 * r + 10000 * k
+                assert torch.equal(gx[:, r * b:(r + 1) * b], want), (chunks, k, r)
+                want_u = -(torch.arange(T * b * nu, dtype=torch.float32).view(T, b, nu) + 1000 * r + 10000 * k)
+                assert torch.equal(gu[:, r * b:(r + 1) * b], want_u), (chunks, k, r)
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pipeline_world2_chunked(tmp_path):
+    """`GatherPipeline` (the all-gather of (x*, u*) taken off the solver's stream, chunked along time): every piece of
+    every rank lands at its [T, B, ...] position, through both buffer sets, for 1, 3 and the default number of chunks"""
+    port = free_port()
+    mp.spawn(pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))

@@ -16,7 +16,7 @@ from tests.test_host_cpu import helpers_against_oracle
 
 pytestmark = pytest.mark.gpu
 
-TOL_STEP = 2e-4     # one MPC step, float32 against the float64 reference
+from tests.helpers import TOL_STEP_PENDULUM as TOL_STEP     # noqa: E402  one MPC step of the pendulum problem: 2e-4, calibrated (tests/helpers.py)
 
 
 def dev(a, dtype=torch.float32):
@@ -141,8 +141,43 @@ def test_tiled_cost_gradient_is_the_reduced_dense_gradient(B):
     assert_close(res[True][2], res[False][2], 2e-5, "d learn_p")
 
 
+def test_tiled_cost_gets_its_gradient_on_the_host_loop_too():
+    """with `device_loop=False` (also: verbose solvers, a refused `dmpc_box_ddp`, CPU-resident tensors) the fused
+    tiled node is not taken; `TiledQuadCost.C/.c` are detached, so the learnable (Q, p) must be tiled ON the graph before
+    BoxDDP decides whether anything needs a gradient (mpc/box_ddp.py:234-259).  Same gradients as the dense `QuadCost`."""
+    from chainer_differentiable_mpc_amd import TiledQuadCost
+    T, B = 20, 16
+    dx = PendulumDx()
+    x0 = dev(sample_xinit_np(B, seed=5))
+    u_exp = dev(np.random.RandomState(6).uniform(-2, 2, size=(T, B, 1)))
+    kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter,
+              max_iter=4, exit_unconverged=False, quiet=True, update_dynamics=False, device_loop=False)
+    res = {}
+    for tiled in (True, False):
+        logit = torch.tensor([0.3, -0.2, 0.1, -1.0], device="cuda", requires_grad=True)
+        learn_p = torch.tensor([-0.4, 0.1, 0.05, 0.02], device="cuda", requires_grad=True)
+        q = torch.sigmoid(logit)
+        p = torch.sqrt(q) * learn_p
+        if tiled:
+            cost = TiledQuadCost(torch.diag(q), p, T, B)
+        else:
+            cost = QuadCost(torch.diag(q)[None, None].expand(T, B, -1, -1).contiguous(),
+                            p[None, None].expand(T, B, -1).contiguous())
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, _ = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, **kw)((x0, cost, dx))
+        assert u.requires_grad, "no graph behind the solution (tiled=%r)" % tiled
+        loss = ((u - u_exp) ** 2).mean() + 0.1 * (x ** 2).mean()
+        loss.backward()
+        res[tiled] = (npy(u), npy(logit.grad), npy(learn_p.grad))
+    assert np.array_equal(res[True][0], res[False][0])
+    assert np.abs(res[False][1]).max() > 1e-6
+    assert_close(res[True][1], res[False][1], 2e-5, "d logit: host loop, tiled vs dense")
+    assert_close(res[True][2], res[False][2], 2e-5, "d learn_p: host loop, tiled vs dense")
+
+
 def test_training_update_pipelined_and_graph_replayed_equal_the_synchronous_one():
-    """IL_Env(quiet=True) defers the device loop's read-back (`BoxDDP(lazy_status=True)`): the update needs no host
+    """IL_Env(lazy_status=True) defers the device loop's read-back (`BoxDDP(lazy_status=True)`): the update needs no host
     decision - solution, gradient node and its detach mask all read device flags - so it can run ahead of the GPU and be
     captured in a hipGraph.  Three RMSprop updates (il_exp.py:213-302) run (a) synchronously with an eager status read
     after every solve, (b) back to back without synchronisation, (c) as a captured graph replayed three times give the
@@ -153,7 +188,7 @@ def test_training_update_pipelined_and_graph_replayed_equal_the_synchronous_one(
     xi = dev(IL_Env.sample_xinit(B))
 
     def make():
-        env = IL_Env("pendulum", lqr_iter=6, mpc_T=T, device="cuda")
+        env = IL_Env("pendulum", lqr_iter=6, mpc_T=T, device="cuda", lazy_status=True)
         net = Pendulum_Net_cost_logit(4, device="cuda")
         with torch.no_grad():
             net.learn_q_logit.copy_(torch.tensor([0.2, -0.1, 0.0, -2.0], device="cuda"))
@@ -190,6 +225,11 @@ def test_training_update_pipelined_and_graph_replayed_equal_the_synchronous_one(
         st = env.last_solver.status                          # ... until somebody asks
         assert env.last_solver._pending is None and st in ("Converged", "Not improved lim", "Not Converged")
         results["pipelined"] = [npy(p_) for p_ in net.parameters()]
+        update(env, net, opt)
+        assert env.last_solver._pending is not None
+        env.flush()                                          # the defined point: epoch / data set / pickle boundaries
+        assert env.last_solver._pending is None
+        assert IL_Env("pendulum", lqr_iter=6, mpc_T=T).lazy_status is False      # opt-in: the default checks every solve
         env, net, opt = make()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -208,6 +248,7 @@ def test_training_update_pipelined_and_graph_replayed_equal_the_synchronous_one(
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             update(env, net, opt)
+        assert env.last_solver._pending is None              # a captured solve leaves no read-back behind (nothing ran)
         for _ in range(3):
             graph.replay()
         torch.cuda.synchronize()
@@ -246,8 +287,8 @@ def test_pendulum_kernel_matches_the_reference_on_and_beyond_the_clamp():
 def test_pendulum_box_ddp_iterates_match_the_reference(k):
     """BoxDDP around the non-linear pendulum (config 2 family, B=16, T=20): the iterate returned after k outer
     iterations by the unmodified reference (chainer.grad linearisation, PendulumDx as the true dynamics callable).
-    The swing-up iteration amplifies rounding, so float32 is held to 1e-3 on the controls; per-step parity at the
-    plain tolerance is test_imitation_step_config4_b1024 and test_box_ddp_gpu's common-iterate steps."""
+    Held to the pendulum step's calibrated 2e-4 (tests/helpers.py; measured worst over the four iterates: 9.6e-5 on x
+    after 2 iterations, profiles/r04/parity_margins.txt) - round 3 had 1e-3 here without a measurement."""
     g = load("pendulum_boxddp.npz")
     B, T = int(g["B"]), int(g["T"])
     dx = PendulumDx()
@@ -261,9 +302,9 @@ def test_pendulum_box_ddp_iterates_match_the_reference(k):
             warnings.simplefilter("ignore")
             x, u, costs = solver((dev(g["x_init"]), QuadCost(dev(Q), dev(pv)), dx))
         assert solver.status in str(g["stdout_%d" % k])
-        assert_close(npy(costs), g["costs_%d" % k], 1e-3, "costs after %d" % k)
-        assert_close(npy(u), g["u_%d" % k], 1e-3, "u after %d" % k)
-        assert_close(npy(x), g["x_%d" % k], 1e-3, "x after %d" % k)
+        assert_close(npy(costs), g["costs_%d" % k], TOL_STEP, "costs after %d" % k)
+        assert_close(npy(u), g["u_%d" % k], TOL_STEP, "u after %d" % k)
+        assert_close(npy(x), g["x_%d" % k], TOL_STEP, "x after %d" % k)
         sat_ref = np.abs(g["u_%d" % k]) == 2.0
         assert (np.abs(npy(u)) == 2.0)[sat_ref].mean() > 0.98
 
@@ -443,7 +484,7 @@ def test_imitation_loop_three_updates_against_the_reference():
             for got, ref in ((net.learn_q_logit.grad, g["g_logit_%d" % k]), (net.learn_p.grad, g["g_p_%d" % k])):
                 assert np.abs(npy(got) - ref).max() <= 5e-2 * np.abs(ref).max(), (k, npy(got), ref)
             opt.step()
-            assert_close(npy(net.learn_p), g["learn_p_%d" % k], 1e-3, "learn_p after update %d" % k)
+            assert_close(npy(net.learn_p), g["learn_p_%d" % k], 1e-4, "learn_p after update %d" % k)
             assert np.array_equal(npy(net.learn_q_logit), g["q_logit0"].astype(np.float32))     # only p moves (:268-281)
             with torch.no_grad():       # the evaluation pass: warm start = what the previous pass predicted
                 q = torch.sigmoid(net.learn_q_logit)

@@ -129,8 +129,8 @@ def test_quu_that_needs_row_interchanges(shape):
     rec = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu)
     x, u = rec.solve_recursion()
     assert int(rec.info.abs().max().item()) == 0
-    assert_close(npy(x), xr, 5e-4, "x")
-    assert_close(npy(u), ur, 5e-4, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
 
 
 @pytest.mark.parametrize("shape", [(64, 50, 8, 2), (8, 10, 8, 2), (12, 52, 8, 2), (16, 20, 3, 1), (8, 9, 4, 2),
@@ -149,6 +149,6 @@ def test_active_set_lqr_on_the_generated_stream(shape, with_f):
     d = to_dev(p)
     rec = LQR_active(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu, u_zero_Index=torch.as_tensor(act).cuda())
     x, u = rec.solve_recursion()
-    assert_close(npy(x), xr, 2e-4, "x")
-    assert_close(npy(u), ur, 2e-4, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
     assert np.all(npy(u)[act] == 0)

@@ -134,8 +134,8 @@ def test_container_shapes_against_oracle(dims):
     d = to_dev(p)
     x, u = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
                         u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
-    assert_close(npy(x), xr, 2e-4, "x active")
-    assert_close(npy(u), ur, 2e-4, "u active")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x active")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u active")
     assert np.all(npy(u)[act] == 0)
 
 
@@ -170,8 +170,8 @@ def test_wide_container_shapes_against_oracle(dims):
     d = to_dev(p)
     x, u = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
                         u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
-    assert_close(npy(x), xr, 2e-4, "x active")
-    assert_close(npy(u), ur, 2e-4, "u active")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x active")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u active")
     assert np.all(npy(u)[act] == 0)
 
 
@@ -184,8 +184,8 @@ def test_container_long_horizon_and_full_batch(dims):
     xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
     d = to_dev(p)
     x, u = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu).solve_recursion()
-    assert_close(npy(x), xr, 5e-4, "x")
-    assert_close(npy(u), ur, 5e-4, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
     B, T = 4096, 20
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=9)
     d = to_dev(p)
@@ -225,8 +225,8 @@ def test_long_horizon_spills_gains_to_hbm(shape):
     xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
     d = to_dev(p)
     x, u = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu).solve_recursion()
-    assert_close(npy(x), xr, 5e-4, "x")
-    assert_close(npy(u), ur, 5e-4, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
 
 
 @pytest.mark.parametrize("shape", [(6, 8, 3, 1), (8, 10, 8, 2), (4, 5, 3, 2), (3, 6, 5, 3), (2, 5, 32, 8)])
@@ -241,8 +241,8 @@ def test_active_set_lqr_against_oracle(shape):
     rec = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
                        u_zero_Index=torch.as_tensor(act).cuda())
     x, u = rec.solve_recursion()
-    assert_close(npy(x), xr, 2e-4, "x")
-    assert_close(npy(u), ur, 2e-4, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
     assert np.all(npy(u)[act] == 0)
 
 
@@ -371,7 +371,7 @@ def test_batched_lu_large_n_generic_path():
     LU, piv = batch_lu_factor(torch.as_tensor(A, dtype=torch.float32).cuda())
     np.testing.assert_array_equal(piv.cpu().numpy(), pivr)
     x = batch_lu_solve((LU, piv), torch.as_tensor(b, dtype=torch.float32).cuda())
-    assert_close(npy(x), xr, 1e-3, "x")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
 
 
 @pytest.mark.parametrize("shape", [(5, 1, 8, 2), (1, 1, 3, 1), (2, 1, 32, 8)])

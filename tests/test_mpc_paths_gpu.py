@@ -17,10 +17,10 @@ import torch
 
 from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost, synthetic
 from oracle import mpc as ompc
-from tests.helpers import assert_close, npy
+from tests.helpers import TOL_STEP, assert_close, npy
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-4
+TOL = TOL_STEP      # 1e-4
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
