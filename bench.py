@@ -376,6 +376,50 @@ def secondary_cfg5(device):
             "frac_mfma_f32": flops * B * T / t / 1e12 / MFMA_F32_PEAK_TFLOPS, "kernel": kernel_name()}
 
 
+def secondary_cfg5_full(device):
+    """config 5 at its FULL size on ONE GPU: B=65536, T=50, (32,8) - 39 GB of inputs in this GPU's 288 GB.  The N = 1 point of
+    a strong-scaling curve for the configuration BASELINE.json shards over 8 GPUs (8 x `cfg5_shard` on one device)"""
+    _, T, nx, nu = WORKLOADS["cfg5-shard"]
+    B = 65536
+    _, d = make_inputs(B, T, nx, nu, 55, device)
+    x = torch.empty((T, B, nx), dtype=torch.float32, device=device)
+    u = torch.empty((T, B, nu), dtype=torch.float32, device=device)
+    t = event_time(lambda: solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u)), 3, warm=1)
+    bts = synthetic.lqr_algorithmic_bytes_per_timestep(nx, nu)
+    ok = bool(torch.isfinite(x).all()) and bool(torch.isfinite(u).all())
+    # size-independent property at full size: the returned trajectory satisfies the dynamics it was rolled out with
+    tau = torch.cat((x[:-1], u[:-1]), dim=2)
+    res = float((torch.einsum("tbij,tbj->tbi", d["F"], tau) + d["f"] - x[1:]).abs().max())
+    return {"what": "config 5 whole (B=65536, T=50, (32,8)) on one GPU, fused solve: the N=1 point of its strong-scaling curve",
+            "ms_per_solve": t * 1e3, "timestep_solves_per_s": B * T / t, "algorithmic_bytes": bts * B * T,
+            "input_gb": sum(v.numel() * 4 for v in d.values()) / 1e9,
+            "frac_hbm": bts * B * T / t / 1e9 / HBM_PEAK_GBS, "finite": ok, "dynamics_residual_max": res, "kernel": kernel_name()}
+
+
+def secondary_f64(device, d):
+    """the headline workload at the REFERENCE's precision (float64: lqr/differentiable_lqr.py:169-172): dmpc_lqr_solve_f64 on
+    the register-resident float64 kernels (f64_row_kernels.hpp), with its own roofline - twice the float32 bytes"""
+    from chainer_differentiable_mpc_amd import _lib
+    from chainer_differentiable_mpc_amd.lqr_recursion import solve_device_f64
+    B, T, nx, nu = WORKLOADS["headline"]
+    d64 = {k: v.double() for k, v in d.items()}
+    fn = lambda: solve_device_f64(d64["C"], d64["c"], d64["F"], d64["f"], d64["x_init"], None, T, nx, nu)   # noqa: E731
+    t = event_time(fn, 30)
+    name = kernel_name()
+    x64, u64, _, _ = fn()
+    x32, u32, _, _ = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)
+    ex = float(((x32.double() - x64).abs() / x64.abs().clamp(min=1.0)).max())
+    eu = float(((u32.double() - u64).abs() / u64.abs().clamp(min=1.0)).max())
+    bts = 2 * synthetic.lqr_algorithmic_bytes_per_timestep(nx, nu)
+    return {"what": "the headline workload in float64 (B=4096, T=50, (8,2), fused solve), dtype f64", "us": t * 1e6,
+            "timestep_solves_per_s": B * T / t,
+            "roofline": {"bound": "hbm", "achieved": bts * B * T / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bts * B * T / t / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bts * B * T,
+                         "kernel": name},
+            "path": int(_lib.load().dmpc_lqr_f64_path(nx, nu)),
+            "float32_stream_vs_this": {"max_rel_err_x": ex, "max_rel_err_u": eu, "tolerance": PARITY_TOL}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -657,11 +701,21 @@ def main():
             except Exception as e:  # pragma: no cover
                 sec["error"] = "secondary_metrics: %r" % (e,)
             try:
+                sec["headline_f64"] = secondary_f64(device, d)
+            except Exception as e:  # pragma: no cover
+                sec["headline_f64"] = {"error": repr(e)}
+            try:
                 del d, x, u
                 torch.cuda.empty_cache()
                 sec["cfg5_shard"] = secondary_cfg5(device)
             except Exception as e:  # pragma: no cover
                 sec["cfg5_shard"] = {"error": repr(e)}
+            try:
+                torch.cuda.empty_cache()
+                sec["cfg5_full_1gpu"] = secondary_cfg5_full(device)
+            except Exception as e:  # pragma: no cover
+                sec["cfg5_full_1gpu"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
             out["secondary"] = sec
             secondary_failed = "error" in sec or any(isinstance(v, dict) and "error" in v for v in sec.values())
         print(json.dumps(out))

@@ -39,6 +39,7 @@ SIGNATURES = {
     "dmpc_lqr_kkt_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_lqr_kkt_grad": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_lqr_kkt_grad_saved": (_c_i, [_c_i] * 4 + [_c_f] * 11 + [_c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_lqr_f64_path": (_c_i, [_c_i, _c_i]),
     "dmpc_lqr_f64_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_lqr_solve_f64": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_lqr_kkt_grad_f64": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),

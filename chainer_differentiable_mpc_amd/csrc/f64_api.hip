@@ -1,19 +1,25 @@
 // f64_api.hip - reference-precision variants of the LQR solve and of its analytic gradient (`_f64` entry
 // points, optional; the reference computes in float64 - lqr/differentiable_lqr.py:169-172, numpy's default everywhere).
 //
-// These are the COMPLETENESS path for precision, not a fast path: one lane per trajectory, every matrix of the
-// trajectory in a caller workspace laid out element-major / trajectory-minor (`ws[e * B + b]`, so the 64 lanes of a
-// wavefront touch one run of HBM per access), runtime dimensions, no cross-lane traffic.  Same algorithm and operation
-// order as the float32 kernels' runtime-dimension version (lqr_generic.hpp) and the oracle:
+// Two families behind the same entry points:
+//   * f64_row_kernels.hpp (round 4): the register-resident column-per-lane kernels in double - a trajectory per 16 lanes
+//     (`v_fmac_f64_dpp` blocks) or per wavefront - for the shapes of DMPC_F64_ROW_SHAPES; the fast path
+//     (`dmpc_lqr_f64_path` says which; DMPC_NO_F64_ROW=1 takes it out);
+//   * the kernels below: one lane per trajectory, every matrix of the trajectory in a caller workspace laid out
+//     element-major / trajectory-minor (`ws[e * B + b]`, so the 64 lanes of a wavefront touch one run of HBM per access),
+//     runtime dimensions, no cross-lane traffic - any shape with nx + nu + 1 <= 64; the completeness path.
+// Same algorithm and operation order as the float32 kernels' runtime-dimension version (lqr_generic.hpp) and the oracle:
 //   solve      lqr/lqr_recursion.py:69-209 (LqrRecursion.backward + .forward; LQR_active with `mask`,
 //              mpc/active_constrained_lqr.py:110-145), LU with partial pivoting in LAPACK getf2 order for F.batch_inv
 //   gradient   lqr/differentiable_lqr.py:78-142 (second solve on [grad_x; grad_u], co-state recursions, outer products)
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
+#include "f64_row_kernels.hpp"
 
 namespace dmpc {
 
@@ -255,11 +261,76 @@ __global__ __launch_bounds__(64) void costate_f64_kernel(const F64Costate a) {
 
 static size_t round256(size_t n) { return (n + 255) / 256 * 256; }
 
+// ---- the register-resident float64 kernels (f64_row_kernels.hpp): shapes with an instantiation
+// 16 lanes per trajectory (fused v_fmac_f64_dpp blocks) / a wavefront per trajectory
+#define DMPC_F64_ROW_SHAPES(X)                                                                                         \
+  X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) X(4, 4, 16)         \
+  X(8, 4, 16) X(12, 3, 16) X(16, 4, 64) X(16, 8, 64) X(32, 8, 64)
+
+static constexpr size_t kMaxLds = 160 * 1024;
+
+template <class K>
+static void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024)   // above the default limit the runtime wants to be told (once per kernel; cheap to repeat)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// returns 0 / a HIP error, or DMPC_E_UNSUPPORTED when the shape has no instantiation (nothing launched)
+static int launch_f64_row_solve(int nx, int nu, F64RowSolve a, hipStream_t stream) {
+#define X(NX_, NU_, L_)                                                                                                \
+  if (nx == NX_ && nu == NU_) {                                                                                        \
+    constexpr int GPB = 256 / L_;                                                                                      \
+    const size_t lds = (size_t)GPB * a.T * NU_ * (NX_ + 1) * sizeof(double);                                           \
+    a.k_lds = lds <= kMaxLds ? 1 : 0;                                                                                  \
+    const size_t shmem = a.k_lds ? lds : 0;                                                                            \
+    const dim3 grid((a.B + GPB - 1) / GPB);                                                                            \
+    if (a.mask != nullptr) {                                                                                           \
+      allow_lds(lqr_f64_row_kernel<NX_, NU_, L_, true>, shmem);                                                        \
+      DMPC_LAUNCH_GGL((lqr_f64_row_kernel<NX_, NU_, L_, true>), grid, dim3(256), shmem, stream, a);                    \
+    } else {                                                                                                           \
+      allow_lds(lqr_f64_row_kernel<NX_, NU_, L_, false>, shmem);                                                       \
+      DMPC_LAUNCH_GGL((lqr_f64_row_kernel<NX_, NU_, L_, false>), grid, dim3(256), shmem, stream, a);                   \
+    }                                                                                                                  \
+    return (int)hipGetLastError();                                                                                     \
+  }
+  DMPC_F64_ROW_SHAPES(X)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
+static int launch_f64_row_costate(int nx, int nu, const F64RowCostate &a, hipStream_t stream) {
+#define X(NX_, NU_, L_)                                                                                                \
+  if (nx == NX_ && nu == NU_) {                                                                                        \
+    constexpr int GPB = 256 / L_;                                                                                      \
+    DMPC_LAUNCH_GGL((costate_f64_row_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, a);    \
+    return (int)hipGetLastError();                                                                                     \
+  }
+  DMPC_F64_ROW_SHAPES(X)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
+static bool f64_row_off() {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_F64_ROW"); return e && e[0] == '1'; }();
+  return off;
+}
+
 }  // namespace dmpc
 
 using namespace dmpc;
 
 extern "C" {
+
+int dmpc_lqr_f64_path(int nx, int nu) {
+  if (nx <= 0 || nu <= 0) return DMPC_E_BADARG;
+  if (nx + nu + 1 > 64) return DMPC_E_UNSUPPORTED;
+  if (!f64_row_off()) {
+#define X(NX_, NU_, L_) if (nx == NX_ && nu == NU_) return L_ == 16 ? 1 : 2;
+    DMPC_F64_ROW_SHAPES(X)
+#undef X
+  }
+  return 0;
+}
 
 size_t dmpc_lqr_f64_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
@@ -283,6 +354,16 @@ int dmpc_lqr_solve_f64(int T, int B, int nx, int nu, const double *C, const doub
   double *area = reinterpret_cast<double *>(p);
   p += round256((f64_solve_ws_elems(nx, nu) + 4 * (size_t)nx) * B * sizeof(double)) + round256((size_t)T * B * ns * sizeof(double));
   double *gains = reinterpret_cast<double *>(p);
+  if (!f64_row_off()) {   // the register-resident kernel where the shape has one; gains through the workspace only when LDS is short
+    F64RowSolve r{T, B, C, c, F, f, x_init, nullptr, u_zero_mask, Ks_out, ks_out, x_out, u_out, info, 1};
+    const int lanes = nx + nu + 1 <= 16 ? 16 : 64;
+    if ((size_t)(256 / lanes) * T * nu * (nx + 1) * sizeof(double) > kMaxLds && Ks_out == nullptr) {
+      r.Ks = gains;
+      r.ks = gains + (size_t)T * B * nu * nx;
+    }
+    const int rc = launch_f64_row_solve(nx, nu, r, static_cast<hipStream_t>(stream));
+    if (rc != DMPC_E_UNSUPPORTED) return rc;
+  }
   F64Solve a{T, B, nx, nu, C, c, F, f, x_init, u_zero_mask, Ks_out ? Ks_out : gains,
              ks_out ? ks_out : gains + (size_t)T * B * nu * nx, x_out, u_out, area, info, (int)ns, nullptr};
   DMPC_LAUNCH_GGL(lqr_f64_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a);
@@ -306,6 +387,20 @@ int dmpc_lqr_kkt_grad_f64(int T, int B, int nx, int nu, const double *C, const d
   double *gains = reinterpret_cast<double *>(p);
   double *dxs = dtau, *dus = dtau + (size_t)T * B * nx;
   // the second solve: same C, F; c = [grad_x; grad_u] (two arrays), f = 0, x_init = 0    differentiable_lqr.py:108-114
+  if (!f64_row_off()) {
+    F64RowSolve r{T, B, C, grad_x, F, nullptr, nullptr, grad_u, nullptr, nullptr, nullptr, dxs, dus, info, 1};
+    const int lanes = nx + nu + 1 <= 16 ? 16 : 64;
+    if ((size_t)(256 / lanes) * T * nu * (nx + 1) * sizeof(double) > kMaxLds) {
+      r.Ks = gains;
+      r.ks = gains + (size_t)T * B * nu * nx;
+    }
+    int rc = launch_f64_row_solve(nx, nu, r, s);
+    if (rc != DMPC_E_UNSUPPORTED) {
+      if (rc != 0) return rc;
+      F64RowCostate k{T, B, C, c, F, x, u, dxs, dus, grad_x, strict_math, d_x_init, dC, dc, dF, df};
+      return launch_f64_row_costate(nx, nu, k, s);
+    }
+  }
   F64Solve a{T, B, nx, nu, C, grad_x, F, nullptr, nullptr, nullptr, gains, gains + (size_t)T * B * nu * nx, dxs, dus, area,
              info, 0, grad_u};
   DMPC_LAUNCH_GGL(lqr_f64_kernel, dim3((B + 63) / 64), dim3(64), 0, s, a);

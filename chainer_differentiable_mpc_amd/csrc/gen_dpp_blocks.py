@@ -31,11 +31,15 @@ OUT = os.path.join(HERE, "dpp_blocks_gen.hpp")
 SHAPES = [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (4, 2), (6, 2), (8, 2), (4, 4), (8, 4), (12, 3),
           (14, 1), (13, 2), (11, 4)]      # the last three: containers only (lqr_api.hip DMPC_LQR_CONTAINERS)
 MAX_OPERANDS = 30
+# float64 variant (gen_dpp_blocks_f64.py -> dpp_blocks_f64_gen.hpp, `RiccatiBlocks64<NX, NU, 16>`): gfx90a+ has the DPP form
+# of the double-precision FMA as well - `v_fmac_f64_dpp ... row_newbcast:k` (the only dpp_ctrl a 64-bit DPP takes), operands
+# are 64-bit register pairs ("v" with a double); there is no v_mul_f64_dpp, so outer2 starts from a zeroed row
+PREC = {"fmac": "v_fmac_f32_dpp", "type": "float", "struct": "RiccatiBlocks", "mul": "v_mul_f32_dpp"}
 
 
 def fmac(acc, a, b, lane):
-    return '"v_fmac_f32_dpp %%[%s], %%[%s], %%[%s] row_newbcast:%d row_mask:0xf bank_mask:0xf\\n\\t"' % (
-        acc, a, b, lane)
+    return '"%s %%[%s], %%[%s], %%[%s] row_newbcast:%d row_mask:0xf bank_mask:0xf\\n\\t"' % (
+        PREC["fmac"], acc, a, b, lane)
 
 
 def statement(lines, outs, ins, tail_nop=True):
@@ -109,17 +113,22 @@ def gen_rowdot(n, name, lane0):
 
 
 def mul_dpp(dst, a, b, lane):
-    return '"v_mul_f32_dpp %%[%s], %%[%s], %%[%s] row_newbcast:%d row_mask:0xf bank_mask:0xf\\n\\t"' % (
-        dst, a, b, lane)
+    return '"%s %%[%s], %%[%s], %%[%s] row_newbcast:%d row_mask:0xf bank_mask:0xf\\n\\t"' % (
+        PREC["mul"], dst, a, b, lane)
 
 
 def gen_outer2(n):
     """row[j] = bcast<j>(x) * a + bcast<j>(y) * b   (j < n): the rows of dC / dF in the co-state kernel"""
     out = ""
     for js in chunks(list(range(n)), MAX_OPERANDS - 4):
-        lines = [mul_dpp("r%d" % j, "x", "a", j) for j in js] + [fmac("r%d" % j, "y", "b", j) for j in js]
         outs = [("r%d" % j, "row[%d]" % j) for j in js]
         ins = [("x", "x"), ("y", "y"), ("a", "a"), ("b", "b")]
+        if PREC["mul"] is None:      # no DPP multiply in this precision: two FMAs into a zeroed row
+            out += "".join("    row[%d] = 0.0;\n" % j for j in js)
+            lines = [fmac("r%d" % j, "x", "a", j) for j in js] + [fmac("r%d" % j, "y", "b", j) for j in js]
+            out += statement(lines, outs, ins, tail_nop=False)
+            continue
+        lines = [mul_dpp("r%d" % j, "x", "a", j) for j in js] + [fmac("r%d" % j, "y", "b", j) for j in js]
         body = statement(lines, outs, ins, tail_nop=False)
         out += body.replace('"+&v"', '"=&v"')
     return out
@@ -138,39 +147,45 @@ def gen_dots2(n):
     return out
 
 
-def main():
+def main(prec="f32"):
+    global OUT
+    if prec == "f64":
+        PREC.update(fmac="v_fmac_f64_dpp", type="double", struct="RiccatiBlocks64", mul=None)
+        OUT = os.path.join(HERE, "dpp_blocks_f64_gen.hpp")
+    T_, S_ = PREC["type"], PREC["struct"]
     s = ["// GENERATED by gen_dpp_blocks.py - do not edit; regenerate and commit.",
-         "// Fused broadcast-FMA (v_fmac_f32_dpp row_newbcast) blocks for the 16-lane row kernels.",
-         "#pragma once", '#include "riccati_blocks.hpp"', "", "namespace dmpc {", ""]
+         "// Fused broadcast-FMA (%s row_newbcast) blocks for the 16-lane row kernels." % PREC["fmac"],
+         "#pragma once", '#include "%s"' % ("riccati_blocks.hpp" if prec == "f32" else "f64_row_blocks.hpp"), "",
+         "namespace dmpc {", ""]
     for nx, nu in SHAPES:
         ns = nx + nu
         assert ns + 1 <= 16
-        s.append("template <>\nstruct RiccatiBlocks<%d, %d, 16> {" % (nx, nu))
+        s.append("template <>\nstruct %s<%d, %d, 16> {" % (S_, nx, nu))
         s.append("  static constexpr bool kAsm = true;")
-        s.append("  static __device__ __forceinline__ void vf(float (&W)[%d], const float (&V)[%d], "
-                 "const float (&Fc)[%d]) {\n%s  }" % (nx, nx, nx, gen_vf(nx)))
-        s.append("  static __device__ __forceinline__ void ftw(float (&Q)[%d], const float (&Fc)[%d], "
-                 "const float (&W)[%d]) {\n%s  }" % (ns, nx, nx, gen_ftw(nx, ns)))
-        s.append("  static __device__ __forceinline__ void vupd(float (&V)[%d], const float (&Q)[%d], "
-                 "const float (&Kt)[%d], const float (&R)[%d]) {\n%s  }" % (nx, ns, nu, nu, gen_vupd(nx, nu)))
+        s.append("  static __device__ __forceinline__ void vf(T_ (&W)[%d], const T_ (&V)[%d], "
+                 "const T_ (&Fc)[%d]) {\n%s  }" % (nx, nx, nx, gen_vf(nx)))
+        s.append("  static __device__ __forceinline__ void ftw(T_ (&Q)[%d], const T_ (&Fc)[%d], "
+                 "const T_ (&W)[%d]) {\n%s  }" % (ns, nx, nx, gen_ftw(nx, ns)))
+        s.append("  static __device__ __forceinline__ void vupd(T_ (&V)[%d], const T_ (&Q)[%d], "
+                 "const T_ (&Kt)[%d], const T_ (&R)[%d]) {\n%s  }" % (nx, ns, nu, nu, gen_vupd(nx, nu)))
         s.append("  // acc += sum_{j<nx} bcast<j>(xu) * M[j]")
-        s.append("  static __device__ __forceinline__ void dot_x(float &acc, const float xu, const float (&M)[%d]) "
+        s.append("  static __device__ __forceinline__ void dot_x(T_ &acc, const T_ xu, const T_ (&M)[%d]) "
                  "{\n%s  }" % (ns + 1, gen_rowdot(nx, "dot_x", 0)))
         s.append("  // acc += sum_{m<nu} bcast<nx+m>(xu) * M[nx+m]")
         body = gen_rowdot(nu, "dot_u", nx).replace("M[", "M[%d + " % nx)
-        s.append("  static __device__ __forceinline__ void dot_u(float &acc, const float xu, const float (&M)[%d]) "
+        s.append("  static __device__ __forceinline__ void dot_u(T_ &acc, const T_ xu, const T_ (&M)[%d]) "
                  "{\n%s  }" % (ns + 1, body))
         s.append("  // row[j] = bcast<j>(x) * a + bcast<j>(y) * b, j < ns")
-        s.append("  static __device__ __forceinline__ void outer2(float (&row)[%d], const float x, const float y, "
-                 "const float a, const float b) {\n%s  }" % (ns, gen_outer2(ns)))
+        s.append("  static __device__ __forceinline__ void outer2(T_ (&row)[%d], const T_ x, const T_ y, "
+                 "const T_ a, const T_ b) {\n%s  }" % (ns, gen_outer2(ns)))
         s.append("  // p += sum_j bcast<j>(x) M[j], q += sum_j bcast<j>(y) M[j]")
-        s.append("  static __device__ __forceinline__ void dots2_ns(float &p, float &q, const float (&M)[%d], const float x, "
-                 "const float y) {\n%s  }" % (ns, gen_dots2(ns)))
-        s.append("  static __device__ __forceinline__ void dots2_nx(float &p, float &q, const float (&M)[%d], const float x, "
-                 "const float y) {\n%s  }" % (nx, gen_dots2(nx)))
+        s.append("  static __device__ __forceinline__ void dots2_ns(T_ &p, T_ &q, const T_ (&M)[%d], const T_ x, "
+                 "const T_ y) {\n%s  }" % (ns, gen_dots2(ns)))
+        s.append("  static __device__ __forceinline__ void dots2_nx(T_ &p, T_ &q, const T_ (&M)[%d], const T_ x, "
+                 "const T_ y) {\n%s  }" % (nx, gen_dots2(nx)))
         s.append("};\n")
     s.append("}  // namespace dmpc")
-    open(OUT, "w").write("\n".join(s) + "\n")
+    open(OUT, "w").write("\n".join(s).replace("T_", T_) + "\n")
     print("wrote", OUT)
 
 

@@ -64,6 +64,59 @@ def test_clamped_controls_at_reference_precision():
     assert np.all(u.cpu().numpy()[act] == 0)
 
 
+ROW_SHAPES = [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (4, 2), (6, 2), (8, 2), (4, 4), (8, 4), (12, 3), (16, 4), (16, 8), (32, 8)]
+
+
+@pytest.mark.parametrize("dims", ROW_SHAPES, ids=lambda d: "%dx%d" % d)
+def test_register_resident_float64_kernels_against_the_oracle(dims):
+    """f64_row_kernels.hpp (round 4: the float64 FAST path - a trajectory per 16 lanes with `v_fmac_f64_dpp` blocks, or per
+    wavefront): every instantiated shape, a ragged batch, with and without f, plain and clamped (LQR_active,
+    mpc/active_constrained_lqr.py:110-145), gains out, and a horizon beyond what the LDS gain rows hold (gains through the
+    workspace) - solution and gains to 1e-9 of the float64 oracle, the gradient's five outputs too (lqr/lqr_recursion.py:69-209,
+    lqr/differentiable_lqr.py:78-142)."""
+    from chainer_differentiable_mpc_amd import _lib
+    from chainer_differentiable_mpc_amd.lqr_recursion import solve_device_f64
+    nx, nu = dims
+    assert _lib.load().dmpc_lqr_f64_path(nx, nu) == (1 if nx + nu + 1 <= 16 else 2)
+    assert _lib.load().dmpc_lqr_f64_path(6, 3) == 0 and _lib.load().dmpc_lqr_f64_path(20, 6) == 0     # the one-lane family
+    long_T = 1 + (160 * 1024) // ((256 // (16 if nx + nu + 1 <= 16 else 64)) * nu * (nx + 1) * 8)
+    for (B, T, with_f, masked) in ((7, 9, True, False), (21, 6, False, True), (5, min(long_T, 400), True, False)):
+        if nx >= 16 and T > 60:
+            T = 60 if (256 // 64) * 60 * nu * (nx + 1) * 8 > 160 * 1024 else T      # (keep the wide shapes' share small)
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7 * nx + nu, with_f=with_f)
+        mask = np.random.RandomState(nx + T).rand(T, B, nu) < 0.4 if masked else None
+        if masked:
+            xr, ur = ompc.lqr_active_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], mask, T, nx, nu)
+            Ksr = ksr = None
+        else:
+            Ksr, ksr = olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+            xr, ur = olqr.lqr_forward(Ksr, ksr, p["x_init"], p["F"], p["f"], T, nx, nu)
+        for want_gains in (True, False):
+            x, u, Ks, ks = solve_device_f64(dev64(p["C"]), dev64(p["c"]), dev64(p["F"]), dev64(p["f"]), dev64(p["x_init"]),
+                                            None if mask is None else torch.as_tensor(mask).cuda().to(torch.uint8).contiguous(),
+                                            T, nx, nu, want_gains=want_gains)
+            tol = 1e-6 if masked else TOL64         # (the 1e-8 regulariser against the reference's explicit inverse, see above)
+            close64(x.cpu().numpy(), xr, "x B=%d T=%d" % (B, T), tol)
+            close64(u.cpu().numpy(), ur, "u B=%d T=%d" % (B, T), tol)
+            if want_gains and Ksr is not None:
+                close64(Ks.cpu().numpy(), np.stack(Ksr), "Ks")
+                close64(ks.cpu().numpy(), np.stack(ksr), "ks")
+            if masked:
+                assert np.all(u.cpu().numpy()[mask] == 0)
+    B, T = 6, 8
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=nx)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    rng = np.random.RandomState(3)
+    gx, gu = rng.randn(T, B, nx), rng.randn(T, B, nu)
+    for strict in (False, True):
+        ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu, strict_math=strict)
+        node = DiffLqr(T, B, nx, nu, strict_math=strict, precision="float64")
+        node.forward((dev64(p["x_init"]), dev64(p["C"]), dev64(p["c"]), dev64(p["F"]), dev64(p["f"])))
+        out = node.backward((0, 1, 2, 3, 4), (dev64(gx), dev64(gu)))
+        for got, want, key in zip(out, ref, ("d_x_init", "dC", "dc", "dF", "df")):
+            close64(got.cpu().numpy(), want, key)
+
+
 LQR_FILES = sorted(glob.glob(os.path.join(GOLDEN, "lqr_*.npz")))
 
 
@@ -152,8 +205,8 @@ def test_wide_mpc_sweeps_against_the_oracle_at_the_contract():
     for (B, T, nx, nu) in ((24, 12, 16, 8), (12, 10, 32, 8)):
         p = synthetic.make_lqr_problem(B, T, nx, nu, seed=nx + 3)
         rng = np.random.RandomState(nx)
-        u_nom = np.clip(0.3 * rng.randn(T, B, nu), -0.4, 0.4).astype(np.float32).astype(np.float64)
-        lo, hi = np.full((T, B, nu), -0.4), np.full((T, B, nu), 0.4)
+        u_nom = np.clip(0.3 * rng.randn(T, B, nu), -0.15, 0.15).astype(np.float32).astype(np.float64)
+        lo, hi = np.full((T, B, nu), -0.15), np.full((T, B, nu), 0.15)
         cost_o, dyn_o = ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"])
         x_nom = obox.get_traj(T, u_nom, p["x_init"], dyn_o).astype(np.float32).astype(np.float64)
         xr, ur, _, fo, Ksr, ksr = ompc.mpc_forward(p["C"], p["c"], p["F"], p["f"], u_nom, x_nom, lo, hi, cost_o, dyn_o, 0.2, 5,
@@ -170,7 +223,9 @@ def test_wide_mpc_sweeps_against_the_oracle_at_the_contract():
         assert_close(u.cpu().numpy(), ur, TOL_STEP, "u" + what)
         assert_close(x.cpu().numpy(), xr, TOL_STEP, "x" + what)
         assert_close(step.for_out.costs.cpu().numpy(), fo.costs, TOL_STEP, "costs" + what)
-        assert ((u.cpu().numpy() == lo) | (u.cpu().numpy() == hi)).any()            # the box is active somewhere
+        un = u.cpu().numpy()
+        on = (un == np.float32(-0.15)) | (un == np.float32(0.15))                    # the box is active somewhere, and where the
+        assert on.any() and np.array_equal(on, (np.abs(ur - lo) <= 1e-8) | (np.abs(ur - hi) <= 1e-8))     # reference has it
 
 
 def _fuzz_cases():
