@@ -35,6 +35,7 @@ SIGNATURES = {
     "dmpc_lqr_solve_saving": (_c_i, [_c_i] * 4 + [_c_f] * 14),
     "dmpc_lqr_saved_solve": (_c_i, [_c_i] * 4 + [_c_f] * 10),
     "dmpc_lqr_backward_sweep": (_c_i, [_c_i] * 4 + [_c_f] * 9),
+    "dmpc_lqr_backward_sweep_ws": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_lqr_forward_sweep": (_c_i, [_c_i] * 4 + [_c_f] * 10),
     "dmpc_lqr_kkt_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_lqr_kkt_grad": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),

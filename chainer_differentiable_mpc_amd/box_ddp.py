@@ -337,7 +337,9 @@ class BoxDDP(torch.nn.Module):
                 self._say("Not Converged ")
         x, u = best['x'], best['u']
         costs = best['costs']
-        deferred = self._pending is not None      # lazy_status: the loop has not been read back (device loop only)
+        # lazy_status: the loop has not been read back (device loop only).  While a hipGraph is being captured nothing has run
+        # and nothing may be read back: host decisions (the non-convergence warning) are skipped, the device flags decide
+        deferred = self._pending is not None or (x.is_cuda and torch.cuda.is_current_stream_capturing())
 
         def unconverged():
             """some trajectory's best full_du_norm is above eps (:263) - a host decision: resolves a deferred read-back"""

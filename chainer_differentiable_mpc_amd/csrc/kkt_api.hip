@@ -100,8 +100,9 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
 #undef X
     }
   }
-  if (nx + nu + 1 > 64) return DMPC_E_UNSUPPORTED;
+  // runtime dimensions, a wavefront per trajectory, vectors in LDS: any size the vectors fit (the reference has no limit)
   const size_t shmem = (size_t)(2 * (nx + nu) + 4 * nx) * sizeof(float);
+  if (shmem > 64 * 1024) return DMPC_E_UNSUPPORTED;
   DMPC_LAUNCH_GGL(costate_generic_kernel, dim3(a.B), dim3(64), shmem, stream, a, CostateDims{nx, nu});
   return (int)hipGetLastError();
 }

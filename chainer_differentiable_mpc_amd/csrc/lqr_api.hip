@@ -10,6 +10,7 @@
 #include "lqr_asm_kernel.hpp"
 #include "lqr_dma_kernel.hpp"
 #include "lqr_generic.hpp"
+#include "lqr_tiled.hpp"
 #include "lqr_kernels.hpp"
 #include "lqr_wave_api.hpp"
 
@@ -311,7 +312,8 @@ static int lqr_family(int nx, int nu) {
   DMPC_LQR_SHAPES(X)
 #undef X
   if (nx >= 1 && nu >= 1 && has_container(nx, nu)) return 4;
-  if (nx >= 1 && nu >= 1 && nx + nu + 1 <= kGenericMaxCols) return 3;
+  if (nx >= 1 && nu >= 1 && nx + nu + 1 <= kGenericMaxCols && lqr_generic_lds_bytes(1, nx, nu, false) <= 64 * 1024) return 3;
+  if (nx >= 1 && nu >= 1) return 5;     // any size: a workgroup per trajectory, matrices in the caller's workspace (lqr_tiled.hpp)
   return DMPC_E_UNSUPPORTED;
 }
 
@@ -367,7 +369,11 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
     DMPC_LQR_WAVE_CONTAINERS(X)
 #undef X
   }
-  if (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) return launch_lqr_generic(mode, nx, nu, a, stream);
+  if (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) {
+    const int rc = launch_lqr_generic(mode, nx, nu, a, stream);
+    if (rc != DMPC_E_UNSUPPORTED) return rc;      // (its matrices did not fit in LDS: the tiled kernel takes any size)
+  }
+  if (nx >= 1 && nu >= 1) return launch_lqr_tiled(mode, nx, nu, a, a.tiled_scratch, stream);
   return DMPC_E_UNSUPPORTED;
 }
 
@@ -428,6 +434,7 @@ int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   DMPC_LQR_SHAPES(X)
 #undef X
   if (lqr_family(nx, nu) == 4 && !container_disabled()) return 7;   // a container kernel (lqr_kernel<..., PAD>)
+  if (lqr_family(nx, nu) == 5) return 8;                              // lqr_tiled_kernel: any size
   return (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) ? 0 : DMPC_E_UNSUPPORTED;
 }
 
@@ -444,7 +451,16 @@ size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
   // gains [T,B,nu,nx] + [T,B,nu], or - the generated stream at long horizons - rows of 12 floats [K_m | 0 | k_m | pad];
   // only touched when they do not fit in LDS (long horizons) or by the generic kernel
-  return (size_t)T * B * nu * (nx + 1 > 12 ? nx + 1 : 12) * sizeof(float);
+  size_t bytes = (size_t)T * B * nu * (nx + 1 > 12 ? nx + 1 : 12) * sizeof(float);
+  // the shapes beyond a wavefront's 64 columns (family 5) keep the matrices of every trajectory behind the gains
+  if (lqr_family(nx, nu) == 5) bytes = round_up(bytes, 256) + (size_t)B * tiled_scratch_floats(nx, nu) * sizeof(float);
+  return bytes;
+}
+
+static float *tiled_scratch_of(void *ws, int T, int B, int nx, int nu) {
+  if (ws == nullptr || lqr_family(nx, nu) != 5) return nullptr;
+  return reinterpret_cast<float *>(static_cast<char *>(ws) +
+                                   round_up((size_t)T * B * nu * (nx + 1 > 12 ? nx + 1 : 12) * sizeof(float), 256));
 }
 
 int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
@@ -460,6 +476,7 @@ int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c,
     if (ws_bytes < dmpc_lqr_workspace_bytes(T, B, nx, nu)) return DMPC_E_WORKSPACE;
     a.wsK = static_cast<float *>(ws);
     a.wsk = a.wsK + (size_t)T * B * nu * nx;
+    a.tiled_scratch = tiled_scratch_of(ws, T, B, nx, nu);
   }
   return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
 }
@@ -494,14 +511,24 @@ int dmpc_lqr_saved_solve(int T, int B, int nx, int nu, const float *c, const flo
   return dispatch_lqr(kSolve, nx, nu, a, static_cast<hipStream_t>(stream));
 }
 
-int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
-                            const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
-                            int32_t *info, dmpc_stream_t stream) {
+int dmpc_lqr_backward_sweep_ws(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                               const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out, void *ws,
+                               size_t ws_bytes, int32_t *info, dmpc_stream_t stream) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return DMPC_E_BADARG;
   if (!C || !c || !Ks_out || !ks_out || (T > 1 && !F)) return DMPC_E_BADARG;
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f)) return DMPC_E_BADARG;
   LqrArgs a{T, B, C, c, F, f, nullptr, u_zero_mask, Ks_out, ks_out, nullptr, nullptr, nullptr, nullptr, info};
+  if (ws != nullptr) {
+    if (ws_bytes < dmpc_lqr_workspace_bytes(T, B, nx, nu)) return DMPC_E_WORKSPACE;
+    a.tiled_scratch = tiled_scratch_of(ws, T, B, nx, nu);
+  }
   return dispatch_lqr(kBackwardOnly, nx, nu, a, static_cast<hipStream_t>(stream));
+}
+
+int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                            const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
+                            int32_t *info, dmpc_stream_t stream) {
+  return dmpc_lqr_backward_sweep_ws(T, B, nx, nu, C, c, F, f, u_zero_mask, Ks_out, ks_out, nullptr, 0, info, stream);
 }
 
 int dmpc_lqr_forward_sweep(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *F,

@@ -23,7 +23,8 @@ struct LqrArgs {
   const float *C, *c, *F, *f, *x_init;
   const uint8_t *mask;  // [T,B,nu] or nullptr
   float *Ks, *ks;       // gains requested by the caller ([T,B,nu,nx], [T,B,nu]) or nullptr
-  float *wsK, *wsk;     // caller workspace used for the gains when they do not fit in LDS
+  float *wsK, *wsk;     // caller workspace used for the gains when they do not fit in LDS (the tiled kernel's per-trajectory
+                        // scratch lies behind them: LqrArgs::tiled_scratch)
   float *x, *u;
   int32_t *info;
   // training form of the solve (generated stream only): Quu_t [T,B,nu,nu] and Qxu_t [T,B,nx,nu] next to Ks / ks, for
@@ -56,6 +57,7 @@ struct LqrArgs {
   const float *mpc_controls = nullptr, *mpc_lower = nullptr, *mpc_upper = nullptr, *mpc_states = nullptr;
   int mpc_n_qp_iter = 0;
   int32_t *mpc_n_qp_total = nullptr;
+  float *tiled_scratch = nullptr;   // lqr_tiled_kernel (any nx, nu): [B][tiled_scratch_floats(nx, nu)] of the caller's workspace
 };
 
 enum LqrMode { kSolve = 0, kBackwardOnly = 1, kForwardOnly = 2 };

@@ -102,10 +102,14 @@ class LqrRecursion:
         Ks = torch.empty((T, B, nu, nx), dtype=torch.float32, device=self._dev)
         ks = torch.empty((T, B, nu), dtype=torch.float32, device=self._dev)
         info = self._new_info()
+        ws, need = None, 0
+        if lib.dmpc_lqr_kernel_family(nx, nu) == 5:     # beyond a wavefront's 64 columns: the sweep's matrices live in a workspace
+            need = lib.dmpc_lqr_workspace_bytes(T, B, nx, nu)
+            ws = _workspace(need, self._dev)
         with _lib.guard(self._dev):
-            _lib.check(lib.dmpc_lqr_backward_sweep(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F),
-                                                   _lib.ptr(f), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks),
-                                                   _lib.ptr(info), _lib.stream_ptr(self._dev)),
+            _lib.check(lib.dmpc_lqr_backward_sweep_ws(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F),
+                                                      _lib.ptr(f), _lib.ptr(mask), _lib.ptr(Ks), _lib.ptr(ks),
+                                                      _lib.ptr(ws), need, _lib.ptr(info), _lib.stream_ptr(self._dev)),
                        "dmpc_lqr_backward_sweep")
         Ks, ks = self._out(Ks), self._out(ks)
         return [Ks[t] for t in range(T)], [ks[t] for t in range(T)]

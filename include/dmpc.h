@@ -111,10 +111,15 @@ int dmpc_lqr_saved_solve(int T, int B, int nx, int nu, const float *c, const flo
                          const float *Quu, const float *Qxu, const float *x_init, float *x_out, float *u_out,
                          int32_t *info, dmpc_stream_t stream);
 
-/* backward(): gains only (lqr_recursion.py:69-158). */
+/* backward(): gains only (lqr_recursion.py:69-158).  The `_ws` form takes the workspace of dmpc_lqr_workspace_bytes: the
+ * shapes of kernel family 5 (nx + nu + 1 > 64: a workgroup per trajectory, matrices in the workspace) need it, every other
+ * shape ignores it; the plain form is the `_ws` form with ws = NULL (DMPC_E_WORKSPACE for family 5). */
 int dmpc_lqr_backward_sweep(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
                             const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out,
                             int32_t *info, dmpc_stream_t stream);
+int dmpc_lqr_backward_sweep_ws(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,
+                               const float *f, const uint8_t *u_zero_mask, float *Ks_out, float *ks_out, void *ws,
+                               size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
 
 /* forward(Ks, ks): closed-loop rollout (lqr_recursion.py:160-200). */
 int dmpc_lqr_forward_sweep(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *F,

@@ -24,6 +24,7 @@ Files written:
   pendulum_boxddp.npz                  BoxDDP around the non-linear PendulumDx (config 2 family): iterates after 1..4 steps
   imitation_16.npz                     config 4 chain, small: Pendulum_Net_cost_logit -> IL_Env.mpc -> loss -> d logit, d p
   imitation_step_1024.npz              config 4 at B=1024, T=20: one MPCstep from a common iterate + the no-op gradient node
+  imitation_step_1024_it1.npz          the same step from the iterate after ONE box-DDP iteration (most rows have a resolvable margin)
   imitation_loop_16.npz                config 4's loop: three RMSprop updates with the evaluation pass's warm-start carry-over
   pnqp_n8_b256.npz                     PNQP n=8, B=256: the batch whose rows fork under the batch-global termination
 """
@@ -350,13 +351,18 @@ def _tiled_cost(ref, q, p, T, B):
     return ref.util.QuadCost(ref.chainer.Variable(Q), ref.chainer.Variable(pv))
 
 
-def gen_pendulum_boxddp(ref):
+def gen_pendulum_boxddp_b128(ref):
+    """the same at config 2's own batch (BASELINE.json configs[1]: B=128, T=20) -> pendulum_boxddp_b128.npz"""
+    gen_pendulum_boxddp(ref, B=128, name="pendulum_boxddp_b128.npz")
+
+
+def gen_pendulum_boxddp(ref, B=16, name="pendulum_boxddp.npz"):
     """BoxDDP.forward (mpc/box_ddp.py:93-291) with the non-linear PendulumDx: linearize_dynamics by chainer.grad,
     MPCstep with the pendulum as the true dynamics callable.  The returned iterate after k = 1..4 outer iterations."""
     V = ref.chainer.Variable
     dx = ref.pendulum.PendulumDx()
     q, p = dx.get_true_obj()
-    B, T = 16, 20
+    T = 20
     np.random.seed(5)
     x0 = _f32(ref.il_env.IL_Env.sample_xinit(B))
     out = dict(B=B, T=T, x_init=x0, q=q, p=p)
@@ -371,8 +377,8 @@ def gen_pendulum_boxddp(ref):
             x, u, costs = ddp((V(x0), _tiled_cost(ref, q, p, T, B), dx))
         out["x_%d" % k], out["u_%d" % k], out["costs_%d" % k] = arr(x), arr(u), arr(costs)
         out["stdout_%d" % k] = buf.getvalue()
-    np.savez_compressed(os.path.join(HERE, "pendulum_boxddp.npz"), **out)
-    print("wrote pendulum_boxddp.npz; mean cost after 1..4:", [float(out["costs_%d" % k].mean()) for k in (1, 2, 3, 4)])
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote %s; mean cost after 1..4:" % name, [float(out["costs_%d" % k].mean()) for k in (1, 2, 3, 4)])
 
 
 def gen_imitation(ref):
@@ -463,6 +469,53 @@ def gen_imitation(ref):
         loss=arr(loss), g_logit=arr(g_logit), g_p=arr(g_p), dC_s=arr(gQ)[:, S], dc_s=arr(gp)[:, S])
     print("wrote imitation_step_1024.npz loss %.6f sat %.2f g_logit %s g_p %s mean_alpha %.3f" % (
         float(arr(loss)), float((np.abs(arr(u1)) == 2.0).mean()), arr(g_logit), arr(g_p), fo.mean_alphas))
+
+
+def gen_imitation_early(ref):
+    """config 4 at B=1024, T=20 once more, from an EARLIER common iterate: ONE box-DDP iteration of the reference under the
+    learner's cost (imitation_step_1024.npz starts after three, where most rows are already near a fixed point and two
+    thirds of them decide their line search by a margin float32 cannot resolve).  After one iteration the step is long and
+    the cost drops by a resolvable margin on most rows: the pin of `MPCstep.forward` (mpc/mpc_step.py:288-328) on the
+    rows that are NOT ties.  Forward only (the gradient node is pinned by imitation_step_1024.npz)."""
+    ch = ref.chainer
+    V, F = ch.Variable, ch.functions
+    B, T = 1024, 20
+    env1 = ref.il_env.IL_Env('pendulum', lqr_iter=1, mpc_T=T)
+    dx = env1.true_dx
+    np.random.seed(0)
+    xinit = _f32(env1.sample_xinit(B))
+    logit0, learn_p0 = np.array([0.5, -0.25, -1.0, -3.0]), np.array([-0.75, 0.125, 0.0625, 0.0])
+    q0 = 1.0 / (1.0 + np.exp(-logit0))
+    with warnings.catch_warnings(), redirect_stdout(io.StringIO()):
+        warnings.simplefilter("ignore")
+        _, u1it = env1.mpc(dx, xinit, V(q0), V(np.sqrt(q0) * learn_p0), update_dynamics=True)
+    u_k = _f32(arr(u1it))
+    logit, learn_p = V(logit0), V(learn_p0)
+    q = F.sigmoid(logit)
+    p = F.sqrt(q) * learn_p
+    Q = ref.util.chainer_diag(q)
+    Q = F.repeat(F.repeat(F.expand_dims(F.expand_dims(Q, 0), 0), T, axis=0), B, axis=1)   # il_env.py:119-123
+    pp = F.repeat(F.repeat(F.expand_dims(F.expand_dims(p, 0), 0), T, axis=0), B, axis=1)
+    lo = np.full((T, B, 1), dx.lower)
+    hi = np.full((T, B, 1), dx.upper)
+    x_k = ref.util.get_traj(T, V(u_k), x_init=V(xinit), dynamics=dx)
+    Fk, fk = ref.approximate.linearize_dynamics(x_k, V(u_k), dx)
+    step = ref.mpc_step.MPCstep(controls=V(u_k), T=T, u_upper=hi, u_lower=lo, n_batch=B, n_state=3, n_ctrl=1,
+                                current_states=x_k, true_cost=ref.util.QuadCost(Q, pp), true_dynamics=dx,
+                                ls_decay=dx.linesearch_decay, max_ls_iter=dx.max_linesearch_iter, need_expand=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x1, u1 = step.apply((arr(x_k)[0], Q, pp, arr(Fk), arr(fk)))
+    fo = step.for_out
+    old = arr(ref.util.get_cost(T, V(u_k), ref.util.QuadCost(Q, pp), x=x_k)) if hasattr(ref.util, "get_cost") else None
+    S = np.arange(0, B, 8)
+    np.savez_compressed(
+        os.path.join(HERE, "imitation_step_1024_it1.npz"), B=B, T=T, sample=S, logit=arr(logit), learn_p=arr(learn_p),
+        u_k=u_k.astype(np.float32), x_k_s=arr(x_k)[:, S], x1=arr(x1).astype(np.float32), u1=arr(u1).astype(np.float32),
+        costs=fo.costs, full_du_norm=fo.full_du_norm, mean_alphas=fo.mean_alphas,
+        n_total_qp_iter=step.back_out.n_total_qp_iter)
+    print("wrote imitation_step_1024_it1.npz sat %.2f mean_alpha %.3f mean cost %.4f" % (
+        float((np.abs(arr(u1)) == 2.0).mean()), fo.mean_alphas, float(np.mean(fo.costs))))
 
 
 def gen_imitation_loop(ref):
@@ -561,7 +614,9 @@ def main():
     gen_pendulum(ref)
     gen_approx_cost(ref)
     gen_pendulum_boxddp(ref)
+    gen_pendulum_boxddp_b128(ref)
     gen_imitation(ref)
+    gen_imitation_early(ref)
     gen_imitation_loop(ref)
     gen_pnqp_fork(ref)
 

@@ -76,7 +76,10 @@ def test_dispatch_table_and_workspace_queries():
     assert lib.dmpc_lqr_kernel_family(5, 5) == 4 and lib.dmpc_lqr_kernel_family(20, 6) == 4   # inside the (16,8) / (32,8) wave kernels
     assert lib.dmpc_lqr_kernel_family(40, 4) == 3       # runtime-dimension kernel
     assert lib.dmpc_lqr_kernel_family(10, 9) == 3
-    assert lib.dmpc_lqr_kernel_family(60, 10) == _lib.E_UNSUPPORTED
+    assert lib.dmpc_lqr_kernel_family(60, 10) == 5      # beyond a wavefront's 64 columns: a workgroup per trajectory, any size
+    assert lib.dmpc_lqr_kernel_family(300, 40) == 5 and lib.dmpc_lqr_kernel_family(0, 3) == _lib.E_UNSUPPORTED
+    ws5 = lib.dmpc_lqr_workspace_bytes(10, 16, 60, 10)
+    assert ws5 > 10 * 16 * 10 * 61 * 4 + 16 * (2 * 60 * 71 + 70 * 71) * 4     # gains + every trajectory's matrices
     assert lib.dmpc_lqr_workspace_bytes(50, 4096, 8, 2) == 50 * 4096 * 2 * 12 * 4     # gain rows of 12 floats (path 6)
     assert lib.dmpc_lqr_workspace_bytes(0, 1, 1, 1) == 0
 
@@ -97,7 +100,7 @@ def test_solve_path_selection_is_host_logic():
     assert lib.dmpc_lqr_solve_path(10, 16, 5, 3) == 7       # a container: the (8,4) kernel, padded by its loads
     assert lib.dmpc_lqr_solve_path(10, 16, 20, 6) == 7      # ... the (32,8) wavefront-per-trajectory kernels
     assert lib.dmpc_lqr_solve_path(10, 16, 40, 4) == 0      # the runtime-dimension kernel
-    assert lib.dmpc_lqr_solve_path(10, 16, 60, 10) == _lib.E_UNSUPPORTED
+    assert lib.dmpc_lqr_solve_path(10, 16, 60, 10) == 8       # lqr_tiled_kernel
 
 
 def test_argument_errors_are_reported_before_any_launch():

@@ -167,3 +167,24 @@ def test_two_forwards_before_backward_keep_their_own_state():
         grads.append([npy(F.grad) for F in Fs])
     for a, b in zip(grads[0], grads[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dims", [(64, 16), (40, 30)], ids=lambda d: "%dx%d" % d)
+@pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
+def test_shapes_beyond_64_columns_against_oracle(dims, strict):
+    """the KKT gradient at shapes beyond a wavefront's 64 columns (refused until round 4): second solve on the tiled kernel
+    (lqr_tiled.hpp), co-state sweep on the runtime-dimension kernel - lqr/differentiable_lqr.py:78-142 has no size limit"""
+    nx, nu = dims
+    B, T = 4, 5
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=40 + nx)
+    rng = np.random.RandomState(nx * 17 + nu)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu, strict_math=strict)
+    d = to_dev(p)
+    node = DiffLqr(T, B, nx, nu, strict_math=strict)
+    node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for got, want, key in zip(out, ref, KEYS):
+        assert_close(npy(got), want, TOLS[key], key)

