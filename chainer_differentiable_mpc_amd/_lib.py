@@ -51,6 +51,7 @@ SIGNATURES = {
     "dmpc_mpc_step_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_mpc_step_forward": (_c_i, [_c_i] * 4 + [_c_f] * 12 + [_c_i, ctypes.c_float, _c_i, _c_i, _c_i]
                               + [_c_f] * 11 + [_c_f, _c_sz, _c_f, _c_f]),
+    "dmpc_mpc_backward_rec_workspace_bytes": (_c_sz, [_c_i] * 6),
     "dmpc_mpc_backward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 7 + [_c_i, _c_i] + [_c_f] * 3 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_mpc_forward_rec": (_c_i, [_c_i] * 4 + [_c_f] * 10 + [ctypes.c_float, _c_i] + [_c_f] * 10),
     "dmpc_mpc_forward_rec_pendulum": (_c_i, [_c_i] * 2 + [_c_f] * 8 + [ctypes.c_float] * 6 + [_c_i] + [_c_f] * 10),
@@ -84,7 +85,10 @@ def load(path=None):
                 "%s not found at %s - build it with `python %s` (hipcc, gfx950). "
                 "There is no CPU fallback." % (LIB_NAME, p, os.path.join(_HERE, "csrc", "build.py")))
         lib = ctypes.CDLL(p)
+        partial = os.environ.get("DMPC_LIB_PARTIAL") == "1" and (path is not None or "DMPC_LIB" in os.environ)
         for name, (res, args) in SIGNATURES.items():
+            if partial and not hasattr(lib, name):   # experiment builds of ONE translation unit (scripts/knob_variants.sh)
+                continue
             fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args

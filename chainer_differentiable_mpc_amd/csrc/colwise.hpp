@@ -52,6 +52,13 @@ struct Group<64> {
   }
 };
 
+// "does any active lane of the wavefront want this?" - a wave-uniform value (one ballot), so the `if` around it is a scalar
+// branch.  LAPACK's row interchange costs ~2 N selects per column and row candidate in every lane; a Quu that is close to
+// diagonally dominant - every problem of the generators, most real ones - never needs one, so the selects sit behind this
+// test and are skipped when no lane's pivot row differs from the diagonal.  Same arithmetic, same results: lanes that do
+// not swap execute selects that select nothing.  (round 4: 83 of the 660 instructions of a (8,4) backward step)
+__device__ __forceinline__ bool any_lane(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
+
 // ---------------------------------------------------------------------------------------
 // In-register LU with partial pivoting (LAPACK getf2 semantics: first max |a| in the column,
 // one row interchange k <-> p, scale by the reciprocal pivot).  Every lane of a group holds
@@ -74,17 +81,19 @@ __device__ __forceinline__ bool lu_factor_inplace(float (&A)[N][N], int (&piv)[N
       p = gt ? i : p;
     }
     piv[k] = p + 1;
+    if (any_lane(p != k)) {   // the interchange behind a wave-uniform branch: see any_lane
 #pragma unroll
-    for (int c = 0; c < N; ++c) {
-      const float ak = A[k][c];
-      float nk = ak;
+      for (int c = 0; c < N; ++c) {
+        const float ak = A[k][c];
+        float nk = ak;
 #pragma unroll
-      for (int i = k + 1; i < N; ++i) {
-        const bool s = (p == i);
-        nk = s ? A[i][c] : nk;
-        A[i][c] = s ? ak : A[i][c];
+        for (int i = k + 1; i < N; ++i) {
+          const bool s = (p == i);
+          nk = s ? A[i][c] : nk;
+          A[i][c] = s ? ak : A[i][c];
+        }
+        A[k][c] = nk;
       }
-      A[k][c] = nk;
     }
     const float d = A[k][k];
     singular = singular || (d == 0.0f);
@@ -107,6 +116,7 @@ __device__ __forceinline__ void lu_solve_inplace(const float (&LU)[N][N], const 
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int p = piv[k] - 1;
+    if (!any_lane(p != k)) continue;
     const float xk = x[k];
     float nk = xk;
 #pragma unroll
@@ -158,7 +168,7 @@ __device__ __forceinline__ bool lu_factor_rinv(float (&A)[N][N], int (&piv)[N], 
     }
     if constexpr (UNIFORM) p = __builtin_amdgcn_readfirstlane(p);
     piv[k] = p + 1;
-    if (N > 1 && (!UNIFORM || p != k)) {
+    if (N > 1 && (UNIFORM ? p != k : any_lane(p != k))) {
 #pragma unroll
       for (int c = 0; c < N; ++c) {
         const float ak = A[k][c];
@@ -193,7 +203,7 @@ __device__ __forceinline__ void lu_solve_rinv(const float (&LU)[N][N], const int
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const int p = piv[k] - 1;
-    if (UNIFORM && p == k) continue;   // (uniform pivots: the interchange behind a scalar branch)
+    if (UNIFORM ? p == k : !any_lane(p != k)) continue;   // the interchange behind a scalar branch
     const float xk = x[k];
     float nk = xk;
 #pragma unroll

@@ -17,7 +17,7 @@
 namespace dmpc {
 
 // LDS a 256-thread workgroup may spend on gains before we spill them to HBM.
-constexpr size_t kGainLdsBudget = 64 * 1024;
+constexpr size_t kGainLdsBudget = 156 * 1024;   // (round 4: was 64 KB - (8,4) and (12,3) at T = 50 sent their gains through HBM)
 // LDS-DMA path: ring depths (timesteps in flight per wave) and the LDS it may use (one workgroup per CU).
 #ifndef DMPC_DMA_DEPTH_B
 #define DMPC_DMA_DEPTH_B 4
@@ -255,6 +255,10 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #define DMPC_LQR_SHAPES(X) X(32, 8, 64)
 #elif defined(DMPC_EXPERIMENT_ONLY_8_2)
 #define DMPC_LQR_SHAPES(X) X(8, 2, 16)
+#elif defined(DMPC_EXPERIMENT_ONLY_4_4)
+#define DMPC_LQR_SHAPES(X) X(4, 4, 16)
+#elif defined(DMPC_EXPERIMENT_ONLY_8_4)
+#define DMPC_LQR_SHAPES(X) X(8, 4, 16)
 #else
 #define DMPC_LQR_SHAPES(X) \
   X(1, 1, 16) X(2, 1, 16) X(3, 1, 16) X(2, 2, 16) X(3, 2, 16) X(4, 2, 16) X(6, 2, 16) X(8, 2, 16) \
@@ -264,14 +268,16 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 // Containers: register-resident kernels that also take any SMALLER problem (lqr_kernel<..., PAD>; the loads pad it in
 // place), in the order they are tried - fewest columns first, fewest controls among equals.  Every shape with
 // nx + nu <= 15 and nu <= 4 has one.
-#if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2)
+#if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2) || defined(DMPC_EXPERIMENT_ONLY_4_4) || \
+    defined(DMPC_EXPERIMENT_ONLY_8_4)
 #define DMPC_LQR_CONTAINERS(X)
 #else
 #define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
 #endif
 
 // ... and the wavefront-per-trajectory kernels take what is larger, up to 32 states and 8 controls
-#if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2)
+#if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2) || defined(DMPC_EXPERIMENT_ONLY_4_4) || \
+    defined(DMPC_EXPERIMENT_ONLY_8_4)
 #define DMPC_LQR_WAVE_CONTAINERS(X)
 #else
 #define DMPC_LQR_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)

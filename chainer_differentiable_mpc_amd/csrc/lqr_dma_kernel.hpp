@@ -19,6 +19,7 @@
 // only make the wait more conservative.  A wave reads only the LDS it filled itself: no barrier.
 #pragma once
 #include "colwise.hpp"
+#include "dma_gather.hpp"
 #include "dpp_blocks_gen.hpp"
 #include "lqr_kernels.hpp"
 #include "riccati_blocks.hpp"
@@ -70,11 +71,17 @@ struct LqrDmaLayout {
   static constexpr int NS = NX + NU;
   static constexpr int C_FL = 4 * NS * NS, c_FL = 4 * NS, F_FL = 4 * NX * NS, f_FL = 4 * NX;  // floats per wave-step
   static constexpr int OFF_C = 0, OFF_c = OFF_C + C_FL, OFF_F = OFF_c + c_FL, OFF_f = OFF_F + F_FL;
-  static constexpr int SLOT_B = OFF_f + f_FL;  // backward slot: [C | c | F | f]
-  static constexpr int SLOT_F = F_FL + f_FL;   // forward slot:  [F | f]
+  // Round 4: the slot is filled by per-lane GATHER DMA (dma_gather.hpp; the scheme of costate_dma_kernel and of the generated
+  // streams): lane l of instruction q copies chunk 64 q + l of [C | c | F | f] from its own 64-bit address.  Before, every
+  // run was a DMA of its own from a uniform base - 4 (small shapes) to 7 instructions per step, each with its M0 write, a
+  // 64-bit scalar pointer step and, for the partial last kilobyte, an exec-mask bracket: ~20 scalar instructions per DMA,
+  // 42 % of the (4,4) kernel's instructions (profiles/r04/knobs_4_4.txt).
+  static constexpr int CH_B = (OFF_f + f_FL) / 4;          // 16-byte chunks of a backward slot
+  static constexpr int CH_F = (F_FL + f_FL) / 4;           // ... of a forward slot [F | f]
+  static constexpr int kDmaB = (CH_B + 63) / 64, kDmaF = (CH_F + 63) / 64;
+  static constexpr int SLOT_B = kDmaB * 256;   // floats: whole kilobytes (the lanes past the last chunk re-fetch chunk 0)
+  static constexpr int SLOT_F = kDmaF * 256;
   static constexpr int RING_FL = (DB * SLOT_B > DF * SLOT_F) ? DB * SLOT_B : DF * SLOT_F;  // per wave
-  static constexpr int kDmaB = dma_count<C_FL * 4>() + dma_count<c_FL * 4>() + dma_count<F_FL * 4>() + dma_count<f_FL * 4>();
-  static constexpr int kDmaF = dma_count<F_FL * 4>() + dma_count<f_FL * 4>();
   static constexpr size_t lds_bytes(int T) {
     return (size_t)4 * RING_FL * 4 + (size_t)16 * T * NU * (NS + 1) * 4;  // rings + gain rows [K_m | 0 | k_m]
   }
@@ -114,24 +121,41 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
 
   // ------------------------------------------------------------------ backward Riccati sweep
   {
-    // running (wave-uniform) source pointers of the next timestep to fetch; F_{T-1} does not exist and is
-    // replaced by F_{T-2}; a missing f still issues its DMA (from c) so that the DMA count per step is exact
-    const size_t sC = B * (NS * NS * 4), sc = B * (NS * 4), sF = B * (NX * NS * 4), sf = B * (NX * 4);
-    int ti = T - 1;  // next timestep to fetch
-    const char *pC = (const char *)a.C + ((size_t)(T - 1) * B + b0) * (NS * NS * 4);
-    const char *pc = (const char *)a.c + ((size_t)(T - 1) * B + b0) * (NS * 4);
-    const char *pF = (const char *)(T > 1 ? a.F : a.C) + ((size_t)(T > 1 ? T - 2 : 0) * B + b0) * (NX * NS * 4);
-    const char *pf = (const char *)(has_f ? a.f : a.c) + ((size_t)(T > 1 ? T - 2 : 0) * B + b0) * (NX * 4);
+    // per-lane source pointers of the gather groups: chunk g = 64 q + lane64 of the slot [C | c | F | f].  Every array steps
+    // back by one timestep per fetch; F (and f) have no slice T-1, so their lanes start at T-2 and sit out the first step.
+    // A missing f is fetched from c (never used: step() zeroes the affine column of F~ then).
+    unsigned long long ptr[Lay::kDmaB], str[Lay::kDmaB], str1[Lay::kDmaB];
+#pragma unroll
+    for (int q = 0; q < Lay::kDmaB; ++q) {
+      const int g = q * 64 + lane64;
+      const int gg = g < Lay::CH_B ? g : 0;          // padding lanes repeat chunk 0 of C (lands past the slot's last chunk)
+      const char *base;
+      size_t per;
+      int g0;
+      bool dyn = false;
+      if (gg < Lay::OFF_c / 4) { base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = 0; }
+      else if (gg < Lay::OFF_F / 4) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::OFF_c / 4; }
+      else if (gg < Lay::OFF_f / 4) { base = (const char *)(T > 1 ? a.F : a.C); per = (size_t)NX * NS * 4; g0 = Lay::OFF_F / 4; dyn = true; }
+      else { base = (const char *)(has_f ? a.f : a.c); per = (size_t)NX * 4; g0 = Lay::OFF_f / 4; dyn = true; }
+      const int t0 = dyn ? (T > 1 ? T - 2 : 0) : T - 1;
+      ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 -
+               (unsigned long long)(q % 4) * 1024u;
+      str[q] = 0ull - (unsigned long long)(B * per);
+      str1[q] = dyn ? 0ull : str[q];
+    }
+    int ti = T - 1;  // timesteps still to step back over
     auto issue_next = [&](int slot) {
+#ifndef DMPC_TIMING_NO_DMA
       const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT_B * 4);
-      dma_run<Lay::C_FL * 4>(pC, dst + Lay::OFF_C * 4, lane_off);
-      dma_run<Lay::c_FL * 4>(pc, dst + Lay::OFF_c * 4, lane_off);
-      dma_run<Lay::F_FL * 4>(pF, dst + Lay::OFF_F * 4, lane_off);
-      dma_run<Lay::f_FL * 4>(pf, dst + Lay::OFF_f * 4, lane_off);
-      if (ti > 0) {  // past t = 0 the same block is fetched again (never consumed): the count stays exact
-        if (ti <= T - 2) { pF -= sF; pf -= sf; }
-        pC -= sC;
-        pc -= sc;
+      static_for<0, Lay::kDmaB>([&](auto q) {  // the instruction offset is 13 bits signed: M0 moves every 4 KB
+        if constexpr (q.value % 4 == 0) set_m0(dst + (unsigned)q.value * 1024u);
+        dma16_gather<(q.value % 4) * 1024>(ptr[q.value]);
+      });
+#endif
+      if (ti > 0) {  // past t = 0 the same blocks are fetched again (never consumed): the count per step stays exact
+        const bool first = ti == T - 1;
+#pragma unroll
+        for (int q = 0; q < Lay::kDmaB; ++q) ptr[q] += first ? str1[q] : str[q];
         --ti;
       }
     };
@@ -174,28 +198,47 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
         Blk::vf(W, V, Fc);   // lqr_recursion.py:89,96
         Blk::ftw(Q, Fc, W);
       }
-      float Quu[NU][NU];
-      static_for<0, NU>([&](auto l) {
+      float Kt[NU], R[NU];
+      if constexpr (NU >= kRowGainsFromNu) {   // Gauss-Jordan on the rows where they lie (riccati_blocks.hpp)
+        float Qu[NU];
+        bool act[NU];
 #pragma unroll
-        for (int m = 0; m < NU; ++m) Quu[m][l.value] = G::template bcast<NX + l.value>(Q[NX + m]);
-      });
-      float Kt[NU];
-#pragma unroll
-      for (int m = 0; m < NU; ++m) Kt[m] = Q[NX + m];
-      if constexpr (NU == 1) {
-        Kt[0] = -(fast_rcp(Quu[0][0]) * Kt[0]);  // :112-115
-        if (Quu[0][0] == 0.f) info_bits |= 1;
+        for (int m = 0; m < NU; ++m) {
+          Qu[m] = Q[NX + m];
+          act[m] = false;
+        }
+        if (gains_on_rows<NX, NU, L, false>(Qu, act, lane, Kt, R, t > 0)) info_bits |= 1;   // :112-120
       } else {
-        float A[NU][NU], rinv[NU];
-        int piv[NU];
+        float Quu[NU][NU];
+        static_for<0, NU>([&](auto l) {
 #pragma unroll
-        for (int m = 0; m < NU; ++m)
+          for (int m = 0; m < NU; ++m) Quu[m][l.value] = G::template bcast<NX + l.value>(Q[NX + m]);
+        });
 #pragma unroll
-          for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
-        if (lu_factor_rinv<NU>(A, piv, rinv)) info_bits |= 1;  // :116-120
-        lu_solve_rinv<NU>(A, piv, rinv, Kt);
+        for (int m = 0; m < NU; ++m) Kt[m] = Q[NX + m];
+        if constexpr (NU == 1) {
+          Kt[0] = -(fast_rcp(Quu[0][0]) * Kt[0]);  // :112-115
+          if (Quu[0][0] == 0.f) info_bits |= 1;
+        } else {
+          float A[NU][NU], rinv[NU];
+          int piv[NU];
 #pragma unroll
-        for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
+          for (int m = 0; m < NU; ++m)
+#pragma unroll
+            for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
+          if (lu_factor_rinv<NU>(A, piv, rinv)) info_bits |= 1;  // :116-120
+          lu_solve_rinv<NU>(A, piv, rinv, Kt);
+#pragma unroll
+          for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
+        }
+        if (t > 0) {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) {
+            R[m] = Q[NX + m];
+#pragma unroll
+            for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
+          }
+        }
       }
       if (lane <= NS) {  // row m of the gains as [K_m (nx) | 0 (nu) | k_m]: the forward sweep reads it like an F row
 #pragma unroll
@@ -211,13 +254,6 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
         }
       }
       if (t > 0) {  // :151-152
-        float R[NU];
-#pragma unroll
-        for (int m = 0; m < NU; ++m) {
-          R[m] = Q[NX + m];
-#pragma unroll
-          for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
-        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) V[i] = Q[i];
         Blk::vupd(V, Q, Kt, R);
@@ -258,17 +294,31 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
 
   // ------------------------------------------------------------------ forward rollout (lqr_recursion.py:160-200)
   {
-    const size_t sF = B * (NX * NS * 4), sf = B * (NX * 4);
+    // gather pointers of the forward slot [F_t | f_t]; the arrays have T-1 slices: beyond that the last one is fetched again
+    unsigned long long ptr[Lay::kDmaF], str[Lay::kDmaF];
+#pragma unroll
+    for (int q = 0; q < Lay::kDmaF; ++q) {
+      const int g = q * 64 + lane64;
+      const int gg = g < Lay::CH_F ? g : 0;
+      const bool isf = gg >= Lay::F_FL / 4;
+      const char *base = isf ? (const char *)(has_f ? a.f : a.C) : (const char *)(T > 1 ? a.F : a.C);
+      const size_t per = isf ? (size_t)NX * 4 : (size_t)NX * NS * 4;
+      ptr[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)(gg - (isf ? Lay::F_FL / 4 : 0)) * 16 -
+               (unsigned long long)(q % 4) * 1024u;
+      str[q] = (unsigned long long)(B * per);
+    }
     int ti = 0;
-    const char *pF = (const char *)(T > 1 ? a.F : a.C) + (size_t)b0 * (NX * NS * 4);
-    const char *pf = (const char *)(has_f ? a.f : a.C) + (has_f ? (size_t)b0 * (NX * 4) : 0);
     auto issue_next = [&](int slot) {
+#ifndef DMPC_TIMING_NO_DMA
       const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT_F * 4);
-      dma_run<Lay::F_FL * 4>(pF, dst, lane_off);
-      dma_run<Lay::f_FL * 4>(pf, dst + Lay::F_FL * 4, lane_off);
+      static_for<0, Lay::kDmaF>([&](auto q) {
+        if constexpr (q.value % 4 == 0) set_m0(dst + (unsigned)q.value * 1024u);
+        dma16_gather<(q.value % 4) * 1024>(ptr[q.value]);
+      });
+#endif
       if (ti < T - 2) {  // F/f have T-1 slices; beyond that the last one is fetched again (never consumed)
-        pF += sF;
-        if (has_f) pf += sf;
+#pragma unroll
+        for (int q = 0; q < Lay::kDmaF; ++q) ptr[q] += str[q];
         ++ti;
       }
     };

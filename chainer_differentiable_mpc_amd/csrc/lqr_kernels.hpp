@@ -216,47 +216,70 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
         Blk::vf(W, V, Fc);
         Blk::ftw(Q, Fc, W);  // Q~ += F^T W~
       }
-      // every lane gets the full Quu                                lqr_recursion.py:102
-      float Quu[NU][NU];
-      static_for<0, NU>([&](auto l) {
-#pragma unroll
-        for (int m = 0; m < NU; ++m) Quu[m][l.value] = G::template bcast<NX + l.value>(Q[NX + m]);
-      });
-      // gains: K~ = -Quu^-1 * (own column of the u-rows)
-      float Kt[NU];
-#pragma unroll
-      for (int m = 0; m < NU; ++m) Kt[m] = Q[NX + m];
-      float A[NU][NU];
-      if constexpr (MASKED) {
-        // active_constrained_lqr.py:110-137: zero q_u / Qux rows of clamped controls, zero Quu
-        // outside free x free, 1e-8 on the clamped diagonal.
+      float Kt[NU], R[NU];
+      if constexpr (NU >= kRowGainsFromNu) {
+        // three and more controls: Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie (riccati_blocks.hpp)
+        float Qu[NU];
         bool act[NU];
-        static_for<0, NU>([&](auto m) { act[m.value] = (!PAD || m.value < nu) && a.mask[tb * nu + (m.value < nu ? m.value : 0)] != 0; });
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
-          Kt[m] = act[m] ? 0.f : Kt[m];
+          Qu[m] = Q[NX + m];
+          act[m] = false;
+        }
+        if constexpr (MASKED) {
+          static_for<0, NU>([&](auto m) { act[m.value] = (!PAD || m.value < nu) && a.mask[tb * nu + (m.value < nu ? m.value : 0)] != 0; });
+        }
+        if (gains_on_rows<NX, NU, L, MASKED>(Qu, act, lane, Kt, R, t > 0)) info_bits |= 1;
+      } else {
+        // every lane gets the full Quu                                lqr_recursion.py:102
+        float Quu[NU][NU];
+        static_for<0, NU>([&](auto l) {
 #pragma unroll
-          for (int l = 0; l < NU; ++l) {
-            float v = (act[m] || act[l]) ? 0.f : Quu[m][l];
-            if (m == l) v = act[m] ? (v + 1e-8f) : v;
-            A[m][l] = v;
+          for (int m = 0; m < NU; ++m) Quu[m][l.value] = G::template bcast<NX + l.value>(Q[NX + m]);
+        });
+        // gains: K~ = -Quu^-1 * (own column of the u-rows)
+#pragma unroll
+        for (int m = 0; m < NU; ++m) Kt[m] = Q[NX + m];
+        float A[NU][NU];
+        if constexpr (MASKED) {
+          // active_constrained_lqr.py:110-137: zero q_u / Qux rows of clamped controls, zero Quu
+          // outside free x free, 1e-8 on the clamped diagonal.
+          bool act[NU];
+          static_for<0, NU>([&](auto m) { act[m.value] = (!PAD || m.value < nu) && a.mask[tb * nu + (m.value < nu ? m.value : 0)] != 0; });
+#pragma unroll
+          for (int m = 0; m < NU; ++m) {
+            Kt[m] = act[m] ? 0.f : Kt[m];
+#pragma unroll
+            for (int l = 0; l < NU; ++l) {
+              float v = (act[m] || act[l]) ? 0.f : Quu[m][l];
+              if (m == l) v = act[m] ? (v + 1e-8f) : v;
+              A[m][l] = v;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < NU; ++m)
+#pragma unroll
+            for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
+        }
+        if constexpr (NU == 1) {
+          Kt[0] = -((1.0f / A[0][0]) * Kt[0]);  // lqr_recursion.py:112-115, active_constrained_lqr.py:131-133
+          if (A[0][0] == 0.f) info_bits |= 1;
+        } else {
+          int piv[NU];
+          if (lu_factor_inplace<NU>(A, piv)) info_bits |= 1;  // reference: F.batch_inv (:116-120) / torch.lu
+          lu_solve_inplace<NU>(A, piv, Kt);
+#pragma unroll
+          for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
+        }
+        if (t > 0) {   // (Qu. + Quu K~) column, UNMASKED Quu
+#pragma unroll
+          for (int m = 0; m < NU; ++m) {
+            R[m] = Q[NX + m];
+#pragma unroll
+            for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
           }
         }
-      } else {
-#pragma unroll
-        for (int m = 0; m < NU; ++m)
-#pragma unroll
-          for (int l = 0; l < NU; ++l) A[m][l] = Quu[m][l];
-      }
-      if constexpr (NU == 1) {
-        Kt[0] = -((1.0f / A[0][0]) * Kt[0]);  // lqr_recursion.py:112-115, active_constrained_lqr.py:131-133
-        if (A[0][0] == 0.f) info_bits |= 1;
-      } else {
-        int piv[NU];
-        if (lu_factor_inplace<NU>(A, piv)) info_bits |= 1;  // reference: F.batch_inv (:116-120) / torch.lu
-        lu_solve_inplace<NU>(A, piv, Kt);
-#pragma unroll
-        for (int m = 0; m < NU; ++m) Kt[m] = -Kt[m];
       }
       // hand the gains to the forward sweep / the caller
       if (k_lane) {
@@ -275,13 +298,6 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
       }
       if (t > 0) {
         // value update, UNMASKED blocks (lqr_recursion.py:151-152; active_constrained_lqr.py:143-145)
-        float R[NU];  // (Qu. + Quu K~) column
-#pragma unroll
-        for (int m = 0; m < NU; ++m) {
-          R[m] = Q[NX + m];
-#pragma unroll
-          for (int l = 0; l < NU; ++l) R[m] = fmaf(Quu[m][l], Kt[l], R[m]);
-        }
 #pragma unroll
         for (int i = 0; i < NX; ++i) V[i] = Q[i];
         Blk::vupd(V, Q, Kt, R);

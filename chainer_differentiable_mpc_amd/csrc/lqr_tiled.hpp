@@ -27,6 +27,7 @@ __host__ __device__ inline size_t tiled_scratch_floats(int nx, int nu) {
   return 2 * (size_t)nx * nc + ns * nc + (size_t)nu * nu + 2 * (size_t)nu * nc + nu + 4;
 }
 
+template <int kInstance = 0>   // (a template so that the header may be included by several translation units)
 __global__ __launch_bounds__(kTiledThreads) void lqr_tiled_kernel(const LqrArgs a, const TiledDims d) {
   const int nx = d.nx, nu = d.nu, ns = nx + nu, nc = ns + 1;
   const int tid = threadIdx.x;
@@ -231,7 +232,7 @@ static int launch_lqr_tiled(int mode, int nx, int nu, const LqrArgs &a, float *s
   const size_t shmem = (size_t)(2 * nx + nu) * sizeof(float);
   if (shmem > 60 * 1024) return DMPC_E_UNSUPPORTED;       // (more than 15,000 states + controls)
   TiledDims d{nx, nu, mode, scratch};
-  DMPC_LAUNCH_GGL(lqr_tiled_kernel, dim3(a.B), dim3(kTiledThreads), shmem, stream, a, d);
+  DMPC_LAUNCH_GGL(lqr_tiled_kernel<0>, dim3(a.B), dim3(kTiledThreads), shmem, stream, a, d);
   return (int)hipGetLastError();
 }
 

@@ -84,6 +84,9 @@ constexpr int kOutOfRange = 0x40000000;
 #ifndef DMPC_WAVE_STAGGER_TICKS
 #define DMPC_WAVE_STAGGER_TICKS 10000
 #endif
+#ifndef DMPC_WAVE_JITTER_TICKS
+#define DMPC_WAVE_JITTER_TICKS 0
+#endif
 #if DMPC_WAVE_DMA_NT
 #define DMPC_WAVE_DMA_POLICY " nt"
 #else
@@ -264,13 +267,19 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
   float *ks = a.Ks != nullptr ? a.ks : a.wsk;
   int info_bits = 0;
 
-  if constexpr (ROLLOUT && DMPC_WAVE_STAGGER_TICKS > 0) {
+  if constexpr (ROLLOUT && (DMPC_WAVE_STAGGER_TICKS > 0 || DMPC_WAVE_JITTER_TICKS > 0)) {
     // HW_ID (hwreg 4) bits 3:0 = the wavefront's slot in its SIMD; first round only (later rounds inherit the offset)
     const unsigned slot_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);
     constexpr unsigned kResident = 2 * 256;   // workgroups the chip holds at once: two per CU (LDS, registers)
-    if ((slot_id & 1u) && gridDim.x > kResident && blockIdx.x < kResident) {
+    if (gridDim.x > kResident && blockIdx.x < kResident) {
+      // DMPC_WAVE_JITTER_TICKS: besides the half-period offset of the odd slots, every wavefront starts at its own point of a
+      // step (16 phases over JITTER ticks): 2,048 wavefronts that run in lock step request their 11.7 KB slots in the same
+      // microsecond of every step - a 24 MB burst that the memory system needs most of a step to drain
+      const unsigned phase = ((blockIdx.x * 4u + (threadIdx.x >> 6)) * 7u) & 15u;
+      const unsigned long long wait_ticks = ((slot_id & 1u) ? (unsigned long long)DMPC_WAVE_STAGGER_TICKS : 0ull) +
+                                            (unsigned long long)(DMPC_WAVE_JITTER_TICKS) * phase / 16u;
       const unsigned long long t0 = wall_clock64();
-      while (wall_clock64() - t0 < (unsigned long long)DMPC_WAVE_STAGGER_TICKS) __builtin_amdgcn_s_sleep(64);
+      while (wall_clock64() - t0 < wait_ticks) __builtin_amdgcn_s_sleep(8);
     }
   }
   float crow_pad[(MPC && PAD) ? NS : 1];   // MPC in a container: this lane's row of C_t for the re-centring

@@ -13,6 +13,7 @@
 #include "mpc_fwd_asm_kernel.hpp"
 #include "lqr_wave_api.hpp"
 #include "mpc_generic.hpp"
+#include "mpc_tiled.hpp"
 #include "mpc_kernels.hpp"
 
 namespace dmpc {
@@ -249,8 +250,19 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     switch (nu) { G(1) G(2) G(3) G(4) G(5) G(6) G(7) G(8) }
 #undef G
   }
-  return DMPC_E_UNSUPPORTED;
+  // any other size (more than 8 controls, more than 64 columns): a workgroup per trajectory, matrices in the caller's
+  // workspace (mpc_tiled.hpp); per-trajectory termination of the QP only
+  if (a.sync == nullptr && a.tiled_scratch != nullptr) {
+    const size_t shmem = (pnqp_tiled_lds_floats(nu) + (size_t)(nx + nu)) * sizeof(float);
+    if (shmem > 60 * 1024) return DMPC_E_UNSUPPORTED;
+    DMPC_LAUNCH_GGL(mpc_tiled_backward_kernel, dim3(a.B), dim3(kTiledThreads), shmem, stream, a, nx, nu, a.tiled_scratch);
+    return (int)hipGetLastError();
+  }
+  return a.sync == nullptr ? DMPC_E_WORKSPACE : DMPC_E_UNSUPPORTED;
 }
+
+// shapes that only the tiled kernels take
+static bool mpc_needs_tiles(int nx, int nu) { return !(nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu); }
 
 static bool spec_line_search_disabled() {  // DMPC_NO_SPEC_LS=1: sequential line search for the pendulum (A/B timing)
   static const bool off = [] { const char *e = getenv("DMPC_NO_SPEC_LS"); return e && e[0] == '1'; }();
@@ -342,11 +354,17 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
                        nx, nu);
     return (int)hipGetLastError();
   }
+  if (a.dyn_kind == 0) {   // any other size: mpc_tiled.hpp
+    const size_t shmem = (size_t)(2 * nx + 2 * (nx + nu) + 4) * sizeof(float);
+    if (shmem > 60 * 1024) return DMPC_E_UNSUPPORTED;
+    DMPC_LAUNCH_GGL(mpc_tiled_forward_kernel, dim3(a.B), dim3(kTiledThreads), shmem, stream, a, nx, nu);
+    return (int)hipGetLastError();
+  }
   return DMPC_E_UNSUPPORTED;
 }
 
 struct MpcWs {
-  size_t c_back, neg, x0, dx, du, mask, sync, lqr, total;
+  size_t c_back, neg, x0, dx, du, mask, sync, tiled, lqr, total;
 };
 constexpr int kSyncQpIterMax = 64;   // the workspace queries do not know n_qp_iter_max: sized for up to this many
 static MpcWs mpc_layout(int T, int B, int nx, int nu) {
@@ -365,6 +383,7 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
   w.du = take((size_t)T * B * nu * sizeof(float));
   w.mask = take((size_t)T * B * nu);
   w.sync = take(coupled_bytes(T, kSyncQpIterMax));
+  w.tiled = take(mpc_needs_tiles(nx, nu) ? (size_t)B * mpc_tiled_scratch_floats(nx, nu) * sizeof(float) : 0);
   w.lqr = off;
   off += round_up(dmpc_lqr_workspace_bytes(T, B, nx, nu), 256);
   w.total = off;
@@ -448,9 +467,21 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
-    default: return DMPC_E_UNSUPPORTED;
+    default: {   // any n: a workgroup per QP (mpc_tiled.hpp); per-row termination only
+      if (sync != nullptr) return DMPC_E_UNSUPPORTED;
+      const size_t shmem = pnqp_tiled_lds_floats(n) * sizeof(float);
+      if (shmem > 60 * 1024) return DMPC_E_UNSUPPORTED;
+      PnqpTiledArgs ta{B, n, H, q, lower, upper, x_init, n_iter, x, fac, piv, index_f, n_iter_out, info};
+      DMPC_LAUNCH_GGL(pnqp_tiled_kernel, dim3(B), dim3(kTiledThreads), shmem, stream, ta);
+    }
   }
   return (int)hipGetLastError();
+}
+
+size_t dmpc_mpc_backward_rec_workspace_bytes(int T, int B, int nx, int nu, int n_qp_iter_max, int batch_coupled) {
+  if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
+  if (batch_coupled) return coupled_bytes(T, n_qp_iter_max);
+  return mpc_needs_tiles(nx, nu) ? (size_t)B * mpc_tiled_scratch_floats(nx, nu) * sizeof(float) : 0;
 }
 
 int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
@@ -464,6 +495,10 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
   if (batch_coupled && (!ws || ws_bytes < coupled_bytes(T, n_qp_iter_max))) return DMPC_E_WORKSPACE;
   MpcBackArgs ba{T, B, C_hat, c_hat, F_hat, f_hat, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
                  n_qp_iter, info, nullptr, batch_coupled ? static_cast<unsigned *>(ws) : nullptr, nullptr};
+  if (!batch_coupled && mpc_needs_tiles(nx, nu)) {
+    if (!ws || ws_bytes < dmpc_mpc_backward_rec_workspace_bytes(T, B, nx, nu, n_qp_iter_max, 0)) return DMPC_E_WORKSPACE;
+    ba.tiled_scratch = static_cast<float *>(ws);
+  }
   return launch_mpc_back(nx, nu, ba, static_cast<hipStream_t>(stream_));
 }
 
@@ -541,6 +576,7 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
   MpcBackArgs ba{T, B, C_hat, c_use, F_hat, f_use, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
                  n_qp_iter, info, nullptr, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
                  need_expand ? states : nullptr};
+  if (mpc_needs_tiles(nx, nu)) ba.tiled_scratch = reinterpret_cast<float *>(base + w.tiled);
   int rc = launch_mpc_back(nx, nu, ba, stream);
   if (rc != 0) return rc;
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,

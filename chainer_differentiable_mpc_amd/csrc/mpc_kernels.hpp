@@ -45,6 +45,8 @@ struct MpcBackArgs {
   int info_store;                       // != 0: info[b] = this sweep's flags (plain store) instead of an atomic OR
   // container launches (PAD kernels, see lqr_kernel): the problem's own dimensions, nx_log <= NX and nu_log <= NU
   int nx_log = 0, nu_log = 0;
+  // mpc_tiled_backward_kernel (any size: more than 8 controls, or more than 64 columns): [B][mpc_tiled_scratch_floats]
+  float *tiled_scratch = nullptr;
 };
 
 // `block` = the workgroup's index among the 256-thread workgroups that share the batch (blockIdx.x for the kernel below)

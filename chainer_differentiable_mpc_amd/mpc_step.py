@@ -198,9 +198,9 @@ class MPCstep:
         ks = torch.empty((T, B, nu), dtype=torch.float32, device=d)
         nqp = torch.empty((B,), dtype=torch.int32, device=d)
         info = torch.zeros(B, dtype=torch.int32, device=d)
-        ws, need = None, 0
-        if self.batch_coupled:
-            need = lib.dmpc_coupled_workspace_bytes(T, self.n_qp_iter_max)
+        ws = None
+        need = lib.dmpc_mpc_backward_rec_workspace_bytes(T, B, nx, nu, self.n_qp_iter_max, 1 if self.batch_coupled else 0)
+        if need:       # batch-coupled decision slots, or the matrices of the tiled kernel (more than 8 controls / 64 columns)
             ws = _workspace(need, d)
         with _lib.guard(d):
             rc = lib.dmpc_mpc_backward_rec(T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f),

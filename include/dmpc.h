@@ -224,6 +224,10 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
                           const float *u_upper, int n_qp_iter_max, int batch_coupled, float *Ks_out, float *ks_out,
                           int32_t *n_qp_iter, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
+/* what dmpc_mpc_backward_rec wants in `ws`: the decision slots of the batch-coupled termination, or - shapes with more than 8
+ * controls or more than 64 columns, which run on the tiled kernels (a workgroup per trajectory, matrices in the workspace;
+ * per-trajectory termination only) - every trajectory's matrices; 0 otherwise (ws may then be NULL). */
+size_t dmpc_mpc_backward_rec_workspace_bytes(int T, int B, int nx, int nu, int n_qp_iter_max, int batch_coupled);
 int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *controls,
                          const float *states, const float *u_lower, const float *u_upper, const float *C_true,
                          const float *c_true, const float *F_true, const float *f_true, float ls_decay,

@@ -121,6 +121,26 @@ def test_factorisation_outputs_against_oracle(n):
     assert_close(npy(x), xr, 1e-4, "x")
 
 
+@pytest.mark.parametrize("n", [9, 12, 16, 40])
+def test_more_than_eight_variables_against_oracle(n):
+    """`PNQP` beyond 8 variables (refused until round 4; mpc/pnqp.py:37-201 has no limit): a workgroup per QP
+    (mpc_tiled.hpp), per-row termination - solution, free set, LU of the last free-set Hessian and LAPACK's pivots against
+    the oracle, cold and warm started"""
+    B = 10
+    p = synthetic.make_box_qp(B, n, seed=90 + n, bound=0.4)
+    for x_init in (None, np.clip(0.3 * np.random.RandomState(n).randn(B, n), -0.1, 0.1)):
+        xr, (LUr, pivr), idxr, ir, info = opnqp.pnqp(p["H"], p["q"], p["lower"], p["upper"], x_init=x_init, batch_coupled=False,
+                                                    return_info=True, warn=False)
+        x, (LU, piv), idx_f, i = PNQP(dev(p["H"]), dev(p["q"]), dev(p["lower"]), dev(p["upper"]),
+                                      x_init=None if x_init is None else dev(x_init))
+        np.testing.assert_array_equal(npy(idx_f), idxr)
+        np.testing.assert_array_equal(piv.cpu().numpy(), pivr)
+        assert_close(npy(LU), LUr, 1e-4, "LU")
+        assert_close(npy(x), xr, 1e-4, "x")
+        assert i == int(info["iters"].max())
+        assert (np.abs(xr - p["lower"]) < 1e-12).any() or (np.abs(xr - p["upper"]) < 1e-12).any()     # bounds are active
+
+
 def test_kkt_conditions_on_a_large_batch():
     """size-independent property: first-order optimality of the box QP for every row"""
     B, n = 65536, 2
