@@ -16,7 +16,10 @@ def ev(fn, reps=20, warm=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
-for (B, T, nx, nu) in ((4096, 50, 8, 2), (4096, 50, 3, 1), (4096, 50, 4, 4), (4096, 50, 12, 3), (2048, 50, 16, 8), (2048, 50, 32, 8)):
+CASES = ((4096, 50, 8, 2), (4096, 50, 3, 1), (4096, 50, 4, 4), (4096, 50, 12, 3), (2048, 50, 16, 8), (2048, 50, 32, 8))
+if len(sys.argv) > 1 and sys.argv[1] == "headline":       # (the PMC passes: the headline size alone)
+    CASES = CASES[:1]
+for (B, T, nx, nu) in CASES:
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=0)
     d = {k: torch.as_tensor(v, dtype=torch.float64).cuda() for k, v in p.items()}
     for _ in range(200): solve_device_f64(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)   # clocks up
