@@ -12,7 +12,7 @@ REPO=$(pwd); OUT=$REPO/gpurun_out/r04; mkdir -p $OUT; export TMPDIR=/tmp
 stats() { name=$1; shift
   ( cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o p -- "$@" > $OUT/prof_$name.log 2>&1 )
   f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv && head -6 "$f"
+  [ -n "$f" ] && cp "$f" $OUT/${name}_kernel_stats.csv
   rm -rf $OUT/prof_$name
 }
 pmc() { name=$1; filt=$2; shift; shift; ctrs="$1"; shift
