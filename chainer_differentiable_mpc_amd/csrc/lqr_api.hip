@@ -267,12 +267,14 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 
 // Containers: register-resident kernels that also take any SMALLER problem (lqr_kernel<..., PAD>; the loads pad it in
 // place), in the order they are tried - fewest columns first, fewest controls among equals.  Every shape with
-// nx + nu <= 15 and nu <= 4 has one.
+// nx + nu <= 15 and nu <= 8 has one.
 #if defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2) || defined(DMPC_EXPERIMENT_ONLY_4_4) || \
     defined(DMPC_EXPERIMENT_ONLY_8_4)
 #define DMPC_LQR_CONTAINERS(X)
 #else
-#define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4)
+// (round 4: five to eight controls too - the gain solve on the rows needs no NU x NU LU per lane; before, (5,5) ran a
+// wavefront per trajectory inside the (16,8) matrix-core kernel at 0.03 of the roof)
+#define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
 #endif
 
 // ... and the wavefront-per-trajectory kernels take what is larger, up to 32 states and 8 controls
