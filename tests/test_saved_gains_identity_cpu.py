@@ -42,7 +42,7 @@ def test_second_solve_from_the_first_solves_blocks(shape, symmetric):
 
 @pytest.mark.parametrize("symmetric", [True, False])
 def test_costate_is_the_value_gradient_along_the_solution(symmetric):
-    """DESIGN.md section 8 (a backward pass that never reads C): the reference's solve is block elimination of its KKT
+    """HISTORY.md section 3.2b (a backward pass that never reads C): the reference's solve is block elimination of its KKT
     system, so the co-state of DiffLqr.backward (differentiable_lqr.py:87-104: lambda_t = C_t[:nx] tau_t + c_t[:nx] +
     F_t[:, :nx]^T lambda_{t+1}) equals V_t x_t + v_t along the solution - also for a C that is not symmetric."""
     B, T, nx, nu = 3, 7, 6, 2
