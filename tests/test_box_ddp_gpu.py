@@ -141,6 +141,25 @@ def test_box_ddp_lindx_b128_against_oracle():
     assert_close(npy(costs), cr, TOL_PRIMAL, "costs")
 
 
+def test_box_ddp_beyond_8_controls_runs_its_host_loop_against_oracle():
+    """`BoxDDP` (mpc/box_ddp.py:93-291) on a problem with 12 controls: `dmpc_box_ddp`'s device-driven loop declines (its
+    workspace has no room for the any-size kernels' matrices), `BoxDDP` runs the reference's loop over `MPCstep` objects on
+    the tiled kernels (mpc_tiled.hpp) - same iterates, same status as the oracle"""
+    B, T, nx, nu = 6, 8, 10, 12
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=33, with_f=True)
+    solver = BoxDDP(T, -0.25, 0.25, B, nx, nu, None, max_iter=6, quiet=True, eps=1e-3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, u, costs = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
+    xr, ur, cr, status, n_iter, *_ = obox.box_ddp(p["x_init"], ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"]),
+                                                  T, -0.25, 0.25, nx, nu, batch_coupled=False, eps=1e-3, max_iter=6)
+    assert solver.status.strip() == status.strip() and solver.n_iter == n_iter, (solver.status, solver.n_iter, status, n_iter)
+    assert float((u.abs() == 0.25).float().mean()) > 0.02
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(costs), cr, TOL_PRIMAL, "costs")
+
+
 def test_pendulum_analytic_linearisation_matches_autograd():
     from chainer_differentiable_mpc_amd.approximate import linearize_dynamics
     dx = PendulumDx()
