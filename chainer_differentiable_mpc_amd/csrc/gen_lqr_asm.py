@@ -37,7 +37,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "lqr_asm_gen.hpp")
 
-SHAPES = [(8, 2), (3, 1), (4, 2), (6, 2), (2, 2), (1, 1), (2, 1), (3, 2)]
+SHAPES = [(8, 2), (3, 1), (4, 2), (6, 2), (2, 2), (1, 1), (2, 1), (3, 2), (4, 4)]   # (4,4): round 4, plain / gains-out / any-horizon forms
 DB = 3        # backward ring depth == number of rotating register sets
 DF = int(os.environ.get("GEN_FWD_DEPTH", "6"))   # forward ring depth == unroll (a multiple of 6: lcm of 2 row sets and 3 accumulators)
 KROW = 12     # floats per gain row in LDS: [K_m (nx) | 0 (nu) | k_m | pad], 8-byte aligned rows
@@ -101,7 +101,7 @@ class Layout:
         deep = RING_DEPTH * ((16 * self.nchunk_b + 63) // 64 * 64) if RING_DEPTH > DB else 0
         self.RING = max(deep, DB * self.ndma_b * 1024, DF * self.SLOT_F)
         assert depth * self.SLOT_B <= self.RING
-        assert self.ndma_b * 1024 - 1024 <= 4095 and ns + 1 <= 12 and nu in (1, 2)
+        assert self.ndma_b * 1024 - 1024 <= 4095 and ns + 1 <= 12 and nu in (1, 2, 3, 4)
         assert (depth - 1) * self.ndma_b <= 63 and (DF - 1) * self.ndma_f <= 63 and 1 <= self.last_lanes <= 64
         # ---- F stash (registers instead of a second HBM read of F), in the layout the forward sweep consumes:
         # lane i < 8 of a 16-lane row keeps columns [0, H) of row i of F_t, lane 8 + i columns [H, ns) - H
@@ -629,12 +629,15 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, gh
         P.v("v_or_b32_e32 %s, %s, %s" % (QINFO, tT, QINFO), writes=(QINFO,), reads=(tT, QINFO))
         P.label("Lqpx%d_%%=" % u_, reset=False)
 
+    swap_id = [0]
+
     def gains(s, first=False):
         """K~ = -Quu^-1 [Qux | Quu | qu] per lane (lqr_recursion.py:112-120); leaves A (Quu), Kt, and MINPIV"""
         Qs = Q[s]
-        for m in range(nu):
-            for l in range(nu):
-                P.mov_dpp(A[m][l], Qs[nx + m], nx + l)
+        if nu <= 2:      # (three and four controls: nobody needs Quu in every lane - the rows are eliminated where they lie and
+            for m in range(nu):      # the value update broadcasts Quu inside its FMAs)
+                for l in range(nu):
+                    P.mov_dpp(A[m][l], Qs[nx + m], nx + l)
         rhs = [Qs[nx + m] for m in range(nu)]
         Au = A
         if mpc:
@@ -662,7 +665,63 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, gh
                         P.v("v_cndmask_b32_e64 %s, %s, 0, s[96:97]" % (Am[m][l], A[m][l]), writes=(Am[m][l],), reads=(A[m][l],))
             rhs = Rm
             Au = Am
-        if nu == 1:
+        if nu >= 3:
+            # Three and four controls (round 4): Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie (the HIP kernels'
+            # gauss_jordan_rows, riccati_blocks.hpp).  Row m is ONE register across the lanes and the multiplier of row i at
+            # pivot k one lane of it (lane nx + k): a DPP broadcast per multiplier, an FMA per row.  Partial pivoting in
+            # LAPACK's order: the candidates below the pivot bubble the first largest entry into row k (strict >: the first
+            # maximum wins; the remaining rows end up permuted differently from getf2's single interchange, which changes
+            # neither which values the later pivots see nor which register holds which unknown).  Working rows: W (the G
+            # tiles are dead here); the K registers themselves are written once, under the K mask, as before.
+            assert not (masked or mpc or save) and len(W) >= nu and nu <= 4
+            Wk = W[:nu]
+            LI = [tL0, tM1, tRA, tRB][:nu]
+            for m in range(nu):
+                P.v("v_mov_b32_e32 %s, %s" % (Wk[m], rhs[m]), writes=(Wk[m],), reads=(rhs[m],))
+            for k in range(nu):
+                P.mov_dpp(tP, Wk[k], nx + k)
+                for i in range(k + 1, nu):
+                    P.mov_dpp(LI[i], Wk[i], nx + k)
+                if k + 1 < nu:
+                    # the interchange behind a wave-uniform branch: taken only when some trajectory of the wavefront has a
+                    # larger entry below its pivot (a Quu that is close to diagonally dominant never does)
+                    cand = [LI[i] for i in range(k + 1, nu)]
+                    if len(cand) == 3:
+                        P.v("v_max3_f32 %s, |%s|, |%s|, |%s|" % (tT, cand[0], cand[1], cand[2]), writes=(tT,), reads=tuple(cand))
+                        mx = "%s" % tT
+                    elif len(cand) == 2:
+                        P.v("v_max_f32_e64 %s, |%s|, |%s|" % (tT, cand[0], cand[1]), writes=(tT,), reads=tuple(cand))
+                        mx = "%s" % tT
+                    else:
+                        mx = "|%s|" % cand[0]
+                    P.v("v_cmp_gt_f32_e64 vcc, %s, |%s|" % (mx, tP), reads=(tT, cand[0], tP))
+                    swap_id[0] += 1
+                    P.raw("s_cbranch_vccz Lnoswap%d_%%=" % swap_id[0])
+                for i in range(k + 1, nu):
+                    P.v("v_cmp_gt_f32_e64 vcc, |%s|, |%s|" % (LI[i], tP), reads=(LI[i], tP))
+                    P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tT, Wk[k], Wk[i]), writes=(tT,), reads=(Wk[k], Wk[i]))
+                    P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (Wk[i], Wk[i], Wk[k]), writes=(Wk[i],), reads=(Wk[k], Wk[i]))
+                    P.v("v_mov_b32_e32 %s, %s" % (Wk[k], tT), writes=(Wk[k],), reads=(tT,))
+                    P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (tT2, tP, LI[i]), writes=(tT2,), reads=(tP, LI[i]))
+                    P.v("v_cndmask_b32_e32 %s, %s, %s, vcc" % (LI[i], LI[i], tP), writes=(LI[i],), reads=(tP, LI[i]))
+                    P.v("v_mov_b32_e32 %s, %s" % (tP, tT2), writes=(tP,), reads=(tT2,))
+                if k + 1 < nu:
+                    P.label("Lnoswap%d_%%=" % swap_id[0])
+                P.v("v_min_f32_e64 %s, |%s|, %s" % (MINPIV, tP, MINPIV), writes=(MINPIV,), reads=(tP, MINPIV))
+                rcp_newton(tRP, tP, tT)
+                P.v("v_mul_f32_e32 %s, %s, %s" % (Wk[k], Wk[k], tRP), writes=(Wk[k],), reads=(Wk[k], tRP))
+                for i in range(nu):
+                    if i == k:
+                        continue
+                    l_ = LI[i]
+                    if i < k:
+                        l_ = tLL
+                        P.mov_dpp(tLL, Wk[i], nx + k)
+                    P.v("v_fma_f32 %s, -%s, %s, %s" % (Wk[i], l_, Wk[k], Wk[i]), writes=(Wk[i],), reads=(l_, Wk[k], Wk[i]))
+            P.raw("s_mov_b64 exec, " + S_KM)
+            for m in range(nu):
+                P.v("v_mul_f32_e32 %s, -1.0, %s" % (Kt[m], Wk[m]), writes=(Kt[m],), reads=(Wk[m],))
+        elif nu == 1:
             P.v("v_rcp_f32_e32 %s, %s" % (tRP, Au[0][0]), writes=(tRP,), reads=(Au[0][0],), trans=True)
             P.v("v_min_f32_e64 %s, |%s|, %s" % (MINPIV, Au[0][0], MINPIV), writes=(MINPIV,), reads=(Au[0][0], MINPIV))
             P.nop(1)
@@ -817,7 +876,13 @@ def gen_kernel(nx, nu, write_k, stash, masked=False, mpc=False, expand=False, gh
     def vupdate(s):
         """V~ = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~) in place in Q[s][0..nx-1]   (lqr_recursion.py:151-152)"""
         Qs = Q[s]
-        for m in range(nu):
+        if nu >= 3:      # R = Q~u. + Quu K~ with Quu[m][l] broadcast from lane nx + l of row m inside the FMA
+            for m in range(nu):
+                P.v("v_mov_b32_e32 %s, %s" % (Rr[m], Qs[nx + m]), writes=(Rr[m],), reads=(Qs[nx + m],))
+            for l in range(nu):
+                for m in range(nu):
+                    P.fmac_dpp(Rr[m], Qs[nx + m], Kt[l], nx + l)
+        for m in range(nu if nu <= 2 else 0):
             P.v("v_fma_f32 %s, %s, %s, %s" % (Rr[m], A[m][0], Kt[0], Qs[nx + m]), writes=(Rr[m],),
                 reads=(A[m][0], Kt[0], Qs[nx + m]))
             for l in range(1, nu):
@@ -1784,11 +1849,13 @@ def main():
                 out.append(gen_kernel(nx, nu, write_k, stash))
                 if write_k and nu in (1, 2):
                     out.append(gen_kernel(nx, nu, write_k, stash, save=True))
-                if stash and not write_k and nx + nu >= 4:
+                if stash and not write_k and nx + nu >= 4 and nu in (1, 2):
                     out.append(gen_kernel(nx, nu, write_k, stash, affine=True))
                     out.append(gen_kernel(nx, nu, write_k, stash, affine=True, adj=True))
                 if not stash and not write_k:
                     out.append(gen_kernel(nx, nu, write_k, stash, ghbm=True))
+                if nu not in (1, 2):     # three and four controls: the plain, gains-out and any-horizon forms (the masked, MPC
+                    continue             # and training forms spell their pivoted solves out for 1 x 1 and 2 x 2)
                 if not write_k and L0.SLOT_B - 16 * L0.nchunk_b >= 256:   # room for the flag dwords in the slot padding
                     out.append(gen_kernel(nx, nu, write_k, stash, masked=True))
                 if write_k and not stash and L0.SLOT_B - 16 * L0.nchunk_b >= 256:
