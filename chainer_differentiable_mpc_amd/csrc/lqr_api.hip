@@ -232,6 +232,19 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
       if (masked) DMPC_LAUNCH(true, kSolve, true, lds_gain);
       else DMPC_LAUNCH(false, kSolve, true, lds_gain);
     } else {
+      if constexpr (L == 16) {
+        // long horizon: the LDS-DMA kernel with its gain rows through the workspace (its rings alone fit a CU's LDS at any
+        // horizon).  Measured against lqr_kernel (profiles/r04/khbm_vs_lqr_kernel.txt): behind it while the gains still fit
+        // LDS ((8,4) T = 50: 96 against 84 us - hence only here), level at T = 100, ahead at T = 200 ((4,4): 221 against 267 us)
+        using LayK = LqrDmaLayout<NX, NU, kDmaDepthB, kDmaDepthF, true>;
+        if (!masked && a.B >= 4 && a.T >= 2 && a.wsK != nullptr && a.Ks == nullptr && LayK::lds_bytes(a.T) <= kDmaLdsBudget &&
+            !dma_path_disabled()) {
+          const int waves = (a.B + 3) / 4;
+          DMPC_LAUNCH_GGL((lqr_dma_kernel<NX, NU, kDmaDepthB, kDmaDepthF, true>), dim3((waves + 3) / 4), block,
+                             LayK::lds_bytes(a.T), stream, a);
+          return (int)hipGetLastError();
+        }
+      }
       LqrArgs s = a;  // long horizon: gains go through HBM (caller's Ks/ks, else the workspace)
       if (s.Ks == nullptr) { s.Ks = s.wsK; s.ks = s.wsk; }
       if (s.Ks == nullptr) return DMPC_E_WORKSPACE;
@@ -459,7 +472,8 @@ size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
   // gains [T,B,nu,nx] + [T,B,nu], or - the generated stream at long horizons - rows of 12 floats [K_m | 0 | k_m | pad];
   // only touched when they do not fit in LDS (long horizons) or by the generic kernel
-  size_t bytes = (size_t)T * B * nu * (nx + 1 > 12 ? nx + 1 : 12) * sizeof(float);
+  // (rows of nx + nu + 1 floats for the LDS-DMA HIP kernel's workspace form)
+  size_t bytes = (size_t)T * B * nu * (nx + nu + 1 > 12 ? nx + nu + 1 : 12) * sizeof(float);
   // the shapes beyond a wavefront's 64 columns (family 5) keep the matrices of every trajectory behind the gains
   if (lqr_family(nx, nu) == 5) bytes = round_up(bytes, 256) + (size_t)B * tiled_scratch_floats(nx, nu) * sizeof(float);
   return bytes;
@@ -468,7 +482,7 @@ size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
 static float *tiled_scratch_of(void *ws, int T, int B, int nx, int nu) {
   if (ws == nullptr || lqr_family(nx, nu) != 5) return nullptr;
   return reinterpret_cast<float *>(static_cast<char *>(ws) +
-                                   round_up((size_t)T * B * nu * (nx + 1 > 12 ? nx + 1 : 12) * sizeof(float), 256));
+                                   round_up((size_t)T * B * nu * (nx + nu + 1 > 12 ? nx + nu + 1 : 12) * sizeof(float), 256));
 }
 
 int dmpc_lqr_solve(int T, int B, int nx, int nu, const float *C, const float *c, const float *F,

@@ -66,9 +66,13 @@ constexpr int dma_count() {
   return BYTES / 1024 + (BYTES % 1024 ? 1 : 0);
 }
 
-template <int NX, int NU, int DB, int DF>
+// KHBM: the gain rows [K_m | 0 | k_m] of every step go to the caller's workspace ([T,B,NU,NS+1] floats) instead of LDS and
+// come back to the rollout through its ring, with F and f (the generated streams' `ghbm` form in HIP): what lets (8,4) and
+// (12,3) use this kernel at T = 50 - their gain rows alone (166 / 154 KB) left no room for the rings.
+template <int NX, int NU, int DB, int DF, bool KHBM = false>
 struct LqrDmaLayout {
   static constexpr int NS = NX + NU;
+  static constexpr int K_FL = KHBM ? 4 * NU * (NS + 1) : 0;     // gain rows of the wave's four trajectories, one step
   static constexpr int C_FL = 4 * NS * NS, c_FL = 4 * NS, F_FL = 4 * NX * NS, f_FL = 4 * NX;  // floats per wave-step
   static constexpr int OFF_C = 0, OFF_c = OFF_C + C_FL, OFF_F = OFF_c + c_FL, OFF_f = OFF_F + F_FL;
   // Round 4: the slot is filled by per-lane GATHER DMA (dma_gather.hpp; the scheme of costate_dma_kernel and of the generated
@@ -77,19 +81,19 @@ struct LqrDmaLayout {
   // 64-bit scalar pointer step and, for the partial last kilobyte, an exec-mask bracket: ~20 scalar instructions per DMA,
   // 42 % of the (4,4) kernel's instructions (profiles/r04/knobs_4_4.txt).
   static constexpr int CH_B = (OFF_f + f_FL) / 4;          // 16-byte chunks of a backward slot
-  static constexpr int CH_F = (F_FL + f_FL) / 4;           // ... of a forward slot [F | f]
+  static constexpr int CH_F = (F_FL + f_FL + K_FL) / 4;    // ... of a forward slot [F | f] ([F | f | K rows] with KHBM)
   static constexpr int kDmaB = (CH_B + 63) / 64, kDmaF = (CH_F + 63) / 64;
   static constexpr int SLOT_B = kDmaB * 256;   // floats: whole kilobytes (the lanes past the last chunk re-fetch chunk 0)
   static constexpr int SLOT_F = kDmaF * 256;
   static constexpr int RING_FL = (DB * SLOT_B > DF * SLOT_F) ? DB * SLOT_B : DF * SLOT_F;  // per wave
   static constexpr size_t lds_bytes(int T) {
-    return (size_t)4 * RING_FL * 4 + (size_t)16 * T * NU * (NS + 1) * 4;  // rings + gain rows [K_m | 0 | k_m]
+    return (size_t)4 * RING_FL * 4 + (KHBM ? 0 : (size_t)16 * T * NU * (NS + 1) * 4);  // rings + gain rows [K_m | 0 | k_m]
   }
 };
 
-template <int NX, int NU, int DB, int DF>
+template <int NX, int NU, int DB, int DF, bool KHBM = false>
 __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
-  using Lay = LqrDmaLayout<NX, NU, DB, DF>;
+  using Lay = LqrDmaLayout<NX, NU, DB, DF, KHBM>;
   constexpr int NS = NX + NU, L = 16, KROW = NS + 1;  // gain rows share the shape of an [F_i | f_i] row
   static_assert(NS + 1 <= L, "augmented columns must fit a DPP row");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
 
   extern __shared__ float lds[];
   float *ring = lds + wave * Lay::RING_FL;
-  float *kl = lds + 4 * Lay::RING_FL + (size_t)(wave * 4 + r) * T * NU * KROW;  // gains of this trajectory
+  float *kl = lds + 4 * Lay::RING_FL + (size_t)(wave * 4 + r) * T * NU * KROW;  // gains of this trajectory (not KHBM)
+  float *kw = KHBM ? a.wsK + (size_t)b * NU * KROW : nullptr;                   // KHBM: + t * B * NU * KROW in the workspace
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
   const unsigned lane_off = (unsigned)lane64 * 16u;
 
@@ -241,8 +246,14 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
         }
       }
       if (lane <= NS) {  // row m of the gains as [K_m (nx) | 0 (nu) | k_m]: the forward sweep reads it like an F row
+        if constexpr (KHBM) {
+          float *row = kw + (size_t)t * B * (NU * KROW) + lane;
 #pragma unroll
-        for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + lane] = k_lane ? Kt[m] : 0.f;
+          for (int m = 0; m < NU; ++m) row[m * KROW] = k_lane ? Kt[m] : 0.f;
+        } else {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) kl[(t * NU + m) * KROW + lane] = k_lane ? Kt[m] : 0.f;
+        }
       }
       if (k_lane) {
         if (a.Ks != nullptr) {
@@ -289,23 +300,27 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
         }
       });
     }
-    wait_vmcnt<0>();  // the ring memory is reused by the forward sweep
+    wait_vmcnt<0>();  // the ring memory is reused by the forward sweep (KHBM: and this wave's gain rows have reached L2)
+    if constexpr (KHBM) __threadfence();
   }
 
   // ------------------------------------------------------------------ forward rollout (lqr_recursion.py:160-200)
   {
     // gather pointers of the forward slot [F_t | f_t]; the arrays have T-1 slices: beyond that the last one is fetched again
     unsigned long long ptr[Lay::kDmaF], str[Lay::kDmaF];
+    bool kstep[Lay::kDmaF];      // KHBM: lanes that fetch gain rows (T slices: they take the last pointer step alone)
 #pragma unroll
     for (int q = 0; q < Lay::kDmaF; ++q) {
       const int g = q * 64 + lane64;
       const int gg = g < Lay::CH_F ? g : 0;
-      const bool isf = gg >= Lay::F_FL / 4;
-      const char *base = isf ? (const char *)(has_f ? a.f : a.C) : (const char *)(T > 1 ? a.F : a.C);
-      const size_t per = isf ? (size_t)NX * 4 : (size_t)NX * NS * 4;
-      ptr[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)(gg - (isf ? Lay::F_FL / 4 : 0)) * 16 -
-               (unsigned long long)(q % 4) * 1024u;
+      const bool isk = KHBM && gg >= (Lay::F_FL + Lay::f_FL) / 4;      // the wave's gain rows of the step (workspace)
+      const bool isf = !isk && gg >= Lay::F_FL / 4;
+      const char *base = isk ? (const char *)a.wsK : isf ? (const char *)(has_f ? a.f : a.C) : (const char *)(T > 1 ? a.F : a.C);
+      const size_t per = isk ? (size_t)NU * KROW * 4 : isf ? (size_t)NX * 4 : (size_t)NX * NS * 4;
+      const int g0 = isk ? (Lay::F_FL + Lay::f_FL) / 4 : isf ? Lay::F_FL / 4 : 0;
+      ptr[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)(gg - g0) * 16 - (unsigned long long)(q % 4) * 1024u;
       str[q] = (unsigned long long)(B * per);
+      kstep[q] = isk;
     }
     int ti = 0;
     auto issue_next = [&](int slot) {
@@ -320,6 +335,10 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
 #pragma unroll
         for (int q = 0; q < Lay::kDmaF; ++q) ptr[q] += str[q];
         ++ti;
+      } else if (KHBM && ti == T - 2) {   // the gain rows have a slice T-1: their lanes step once more
+#pragma unroll
+        for (int q = 0; q < Lay::kDmaF; ++q) ptr[q] += kstep[q] ? str[q] : 0ull;
+        ++ti;
       }
     };
     // Lane i < NX owns row i of [F_t | f_t] (ring slot), lane NX+m owns row m of [K_t | 0 | k_t] (gain rows in
@@ -333,10 +352,12 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
     const int m_own = row_u ? lane - NX : 0;
     const float *xbase = ring + r * NX * NS + lane_x * NS;           // + slot * SLOT_F : row lane_x of F_t
     const float *xaff = ring + Lay::F_FL + r * NX + lane_x;          // + slot * SLOT_F : f_t[lane_x]
-    const float *ubase = kl + m_own * KROW;                          // + t * NU * KROW : row m of the gains
+    const float *ubase = KHBM ? ring + Lay::F_FL + Lay::f_FL + (r * NU + m_own) * KROW   // + slot * SLOT_F: row m of the gains
+                              : kl + m_own * KROW;                                      // + t * NU * KROW
     auto read_rows = [&](int t, int slot, float (&Mn)[NS + 1]) {
-      const float *row = row_u ? ubase + (size_t)t * (NU * KROW) : xbase + slot * Lay::SLOT_F;
-      const float *aff = row_u ? ubase + (size_t)t * (NU * KROW) + NS : xaff + slot * Lay::SLOT_F;
+      const float *urow = KHBM ? ubase + slot * Lay::SLOT_F : ubase + (size_t)t * (NU * KROW);
+      const float *row = row_u ? urow : xbase + slot * Lay::SLOT_F;
+      const float *aff = row_u ? urow + NS : xaff + slot * Lay::SLOT_F;
 #pragma unroll
       for (int j = 0; j < NS; ++j) Mn[j] = row[j];
       Mn[NS] = aff[0];

@@ -32,7 +32,7 @@ WS = {}
 
 
 def run(fn, d, x, u, B):
-    need = T * B * nu * max(nx + 1, 12) * 4   # dmpc_lqr_workspace_bytes: wide shapes / long horizons pass their gains through it
+    need = T * B * nu * max(nx + nu + 1, 12) * 4   # dmpc_lqr_workspace_bytes: wide shapes / long horizons pass their gains through it
     if B not in WS:
         WS.clear()
         WS[B] = torch.empty(need, dtype=torch.uint8, device=dev)
