@@ -7,7 +7,7 @@
 //     (`dmpc_lqr_f64_path` says which; DMPC_NO_F64_ROW=1 takes it out);
 //   * the kernels below: one lane per trajectory, every matrix of the trajectory in a caller workspace laid out
 //     element-major / trajectory-minor (`ws[e * B + b]`, so the 64 lanes of a wavefront touch one run of HBM per access),
-//     runtime dimensions, no cross-lane traffic - any shape with nx + nu + 1 <= 64; the completeness path.
+//     runtime dimensions, no cross-lane traffic - any shape at all; the completeness path.
 // Same algorithm and operation order as the float32 kernels' runtime-dimension version (lqr_generic.hpp) and the oracle:
 //   solve      lqr/lqr_recursion.py:69-209 (LqrRecursion.backward + .forward; LQR_active with `mask`,
 //              mpc/active_constrained_lqr.py:110-145), LU with partial pivoting in LAPACK getf2 order for F.batch_inv
@@ -323,7 +323,6 @@ extern "C" {
 
 int dmpc_lqr_f64_path(int nx, int nu) {
   if (nx <= 0 || nu <= 0) return DMPC_E_BADARG;
-  if (nx + nu + 1 > 64) return DMPC_E_UNSUPPORTED;
   if (!f64_row_off()) {
 #define X(NX_, NU_, L_) if (nx == NX_ && nu == NU_) return L_ == 16 ? 1 : 2;
     DMPC_F64_ROW_SHAPES(X)

@@ -245,7 +245,9 @@ def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False,
     # gains stay in LDS unless the horizon is long or the shape runs on the generic kernel
     need = lib.dmpc_lqr_workspace_bytes(T, B, nx, nu)
     per_traj_lds = T * nu * (nx + 1) * 4
-    if not want_gains and (per_traj_lds * 16 > 60 * 1024 or lib.dmpc_lqr_kernel_family(nx, nu) != 1):
+    family = lib.dmpc_lqr_kernel_family(nx, nu)
+    # (family 5 - beyond 64 columns - keeps every trajectory's matrices in the workspace, whoever receives the gains)
+    if family == 5 or (not want_gains and (per_traj_lds * 16 > 60 * 1024 or family != 1)):
         ws = _workspace(need, dev)
         ws_bytes = need
     with _lib.guard(dev):

@@ -156,7 +156,7 @@ int dmpc_lqr_kkt_grad_saved(int T, int B, int nx, int nu, const float *C, const 
  *      (lqr/differentiable_lqr.py:169-172, numpy's default), these return outputs at its precision.  Two families:
  *      register-resident kernels in double for the shapes with an instantiation ((1,1) ... (12,3) at 16 lanes per trajectory,
  *      (16,4), (16,8), (32,8) at a wavefront per trajectory; plain and clamped) - the fast path - and, for every other shape
- *      with nx + nu + 1 <= 64, one lane per trajectory with runtime dimensions and every matrix of a trajectory in `ws`
+ *      (any size), one lane per trajectory with runtime dimensions and every matrix of a trajectory in `ws`
  *      (dmpc_lqr_f64_workspace_bytes, required in both cases).  dmpc_lqr_f64_path: 1 = 16-lane kernel, 2 = wavefront kernel,
  *      0 = one lane per trajectory.  Arrays are the float64 twins of dmpc_lqr_solve's / dmpc_lqr_kkt_grad's, same shapes;
  *      Ks_out / ks_out may be NULL (both). */

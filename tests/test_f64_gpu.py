@@ -80,7 +80,8 @@ def test_register_resident_float64_kernels_against_the_oracle(dims):
     assert _lib.load().dmpc_lqr_f64_path(nx, nu) == (1 if nx + nu + 1 <= 16 else 2)
     assert _lib.load().dmpc_lqr_f64_path(6, 3) == 0 and _lib.load().dmpc_lqr_f64_path(20, 6) == 0     # the one-lane family
     long_T = 1 + (160 * 1024) // ((256 // (16 if nx + nu + 1 <= 16 else 64)) * nu * (nx + 1) * 8)
-    for (B, T, with_f, masked) in ((7, 9, True, False), (21, 6, False, True), (5, min(long_T, 400), True, False)):
+    for (B, T, with_f, masked) in ((7, 9, True, False), (21, 6, False, True), (5, min(long_T, 400), True, False), (3, 1, True, False),
+                                   (6, 2, False, False)):
         if nx >= 16 and T > 60:
             T = 60 if (256 // 64) * 60 * nu * (nx + 1) * 8 > 160 * 1024 else T      # (keep the wide shapes' share small)
         p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7 * nx + nu, with_f=with_f)
@@ -92,7 +93,8 @@ def test_register_resident_float64_kernels_against_the_oracle(dims):
             Ksr, ksr = olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu)
             xr, ur = olqr.lqr_forward(Ksr, ksr, p["x_init"], p["F"], p["f"], T, nx, nu)
         for want_gains in (True, False):
-            x, u, Ks, ks = solve_device_f64(dev64(p["C"]), dev64(p["c"]), dev64(p["F"]), dev64(p["f"]), dev64(p["x_init"]),
+            x, u, Ks, ks = solve_device_f64(dev64(p["C"]), dev64(p["c"]), dev64(p["F"]) if T > 1 else None,
+                                            dev64(p["f"]) if T > 1 else None, dev64(p["x_init"]),
                                             None if mask is None else torch.as_tensor(mask).cuda().to(torch.uint8).contiguous(),
                                             T, nx, nu, want_gains=want_gains)
             tol = 1e-6 if masked else TOL64         # (the 1e-8 regulariser against the reference's explicit inverse, see above)
@@ -265,6 +267,31 @@ def test_float32_paths_against_the_float64_kernels_over_the_shape_space(case):
     assert_close(u.cpu().numpy(), u64.cpu().numpy(), tol, "u")
     assert_close(Ks.cpu().numpy(), Ks64.cpu().numpy(), tol, "Ks")
     assert_close(ks.cpu().numpy(), ks64.cpu().numpy(), tol, "ks")
+    if masked:
+        assert bool((u[mask.bool()] == 0).all())
+
+
+@pytest.mark.parametrize("case", [(3, 4, 65, 1, True, False), (2, 5, 48, 20, False, False), (3, 3, 90, 7, True, True), (2, 6, 33, 31, True, False),
+                                  (4, 3, 120, 2, False, True)],
+                         ids=lambda c: "B%d_T%d_%dx%d_%s%s" % (c[0], c[1], c[2], c[3], "f" if c[4] else "nof", "_masked" if c[5] else ""))
+def test_any_size_float32_kernels_against_the_float64_kernels(case):
+    """beyond a wavefront's 64 columns (kernel family 5, lqr_tiled.hpp: a workgroup per trajectory) against the float64
+    one-lane kernels (runtime dimensions, any size) on identical inputs - solution and gains at the contract's 1e-4"""
+    from chainer_differentiable_mpc_amd import _lib
+    from chainer_differentiable_mpc_amd.lqr_recursion import solve_device, solve_device_f64
+    from tests.helpers import TOL_PRIMAL, assert_close
+    B, T, nx, nu, with_f, masked = case
+    assert _lib.load().dmpc_lqr_kernel_family(nx, nu) == 5
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=B * 1000 + T * 10 + nx, with_f=with_f)
+    d32 = {k: torch.as_tensor(v, dtype=torch.float32).cuda() for k, v in p.items() if isinstance(v, np.ndarray)}
+    d64 = {k: v.double() for k, v in d32.items()}
+    mask = None
+    if masked:
+        mask = torch.as_tensor(np.random.RandomState(B + T).rand(T, B, nu) < 0.35).cuda().to(torch.uint8).contiguous()
+    x, u, Ks, ks = solve_device(d32["C"], d32["c"], d32["F"], d32.get("f"), d32["x_init"], mask, T, nx, nu, want_gains=True)
+    x64, u64, Ks64, ks64 = solve_device_f64(d64["C"], d64["c"], d64["F"], d64.get("f"), d64["x_init"], mask, T, nx, nu, want_gains=True)
+    for got, want, key in ((x, x64, "x"), (u, u64, "u"), (Ks, Ks64, "Ks"), (ks, ks64, "ks")):
+        assert_close(got.cpu().numpy(), want.cpu().numpy(), TOL_PRIMAL, key)
     if masked:
         assert bool((u[mask.bool()] == 0).all())
 
