@@ -307,6 +307,33 @@ def test_shapes_beyond_8_controls_or_64_columns_against_the_oracle(shape):
         coupled.forward((dev(x0[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
 
 
+def test_tiled_mpc_step_without_recentring_and_with_an_affine_model():
+    """the any-size MPC kernels with `need_expand=False` (the Taylor model is used as given: c_hat and a non-zero f_hat enter
+    the sweep, mpc_step.py:110-116) at 9 controls - one more than the register-resident QP holds"""
+    B, T, nx, nu, bound = 5, 6, 7, 9, 0.25
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=17, with_f=True)
+    lo, hi = -bound * np.ones((T, B, nu)), bound * np.ones((T, B, nu))
+    u0 = np.clip(0.2 * np.random.RandomState(1).randn(T, B, nu), -bound, bound).astype(np.float32).astype(np.float64)
+    xs = [p["x_init"]]
+    for t in range(T - 1):
+        xs.append(np.einsum("bij,bj->bi", p["F"][t], np.concatenate((xs[t], u0[t]), axis=1)) + p["f"][t])
+    x0 = np.stack(xs).astype(np.float32).astype(np.float64)
+    xr, ur, bo, fo, Ksr, ksr = ompc.mpc_forward(p["C"], p["c"], p["F"], p["f"], u0, x0, lo, hi,
+                                                ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"]), 0.2, 5,
+                                                T, nx, nu, need_expand=False, batch_coupled=False)
+    step = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(p["C"]), dev(p["c"])),
+                   LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x, u = step.forward((dev(x0[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    assert_close(npy(step.ks), ksr, TOL, "ks")
+    assert_close(npy(step.Ks), Ksr, TOL, "Ks")
+    assert_close(npy(u), ur, TOL, "u")
+    assert_close(npy(x), xr, TOL, "x")
+    assert_close(npy(step.for_out.costs), fo.costs, TOL, "costs")
+    assert int(step.back_out.n_total_qp_iter) >= T
+
+
 def test_batch_coupled_needs_the_batch_resident_and_says_so():
     """the grid-wide termination needs every workgroup resident (cooperative launch): a batch that cannot be is
     refused with DMPC_E_UNSUPPORTED instead of deadlocking; per-trajectory termination takes any batch"""
