@@ -11,6 +11,7 @@
 #include "mpc_asm_kernel.hpp"
 #include "mpc_dma_kernels.hpp"
 #include "mpc_fwd_asm_kernel.hpp"
+#include "mpc_step_fused_kernel.hpp"
 #include "lqr_wave_api.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_tiled.hpp"
@@ -367,6 +368,30 @@ struct MpcWs {
   size_t c_back, neg, x0, dx, du, mask, sync, tiled, lqr, total;
 };
 constexpr int kSyncQpIterMax = 64;   // the workspace queries do not know n_qp_iter_max: sized for up to this many
+// Both generated streams in one launch (mpc_step_fused_kernel.hpp) when each of them would have been chosen on its own:
+// the conditions of launch_mpc_back's and launch_mpc_fwd's stream branches.  DMPC_NO_MPC_FUSED=1: two launches (A/B).
+static int launch_mpc_step_fused(int nx, int nu, const MpcBackArgs &ba, const MpcFwdArgs &fa, hipStream_t stream) {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_FUSED"); return e && e[0] == '1'; }();
+  if (off || mpc_asm_disabled() || !mpc_back_dma_ok(ba) || ba.T < 2 || !(ba.states == nullptr || ba.f == nullptr))
+    return DMPC_E_UNSUPPORTED;
+  if (!(fa.dyn_kind == 0 && fa.ls_cap > 0 &&
+        aligned16(fa.C, fa.c, fa.F, fa.f, fa.Ks, fa.ks, fa.controls, fa.lower, fa.upper, fa.states)))
+    return DMPC_E_UNSUPPORTED;
+  const dim3 grid((ba.B + 15) / 16), block(256);
+  const int variant = ba.states != nullptr ? 2 : (ba.f != nullptr ? 1 : 0);   // re-centring / with f_hat / plain
+#define A(NX_, NU_)                                                                                              \
+  if (nx == NX_ && nu == NU_) {                                                                                  \
+    constexpr size_t lds = mpc_step_fused_lds_bytes<NX_, NU_>();                                                 \
+    if (variant == 2) DMPC_LAUNCH_GGL((mpc_step_fused_asm_kernel<NX_, NU_, false, true>), grid, block, lds, stream, ba, fa); \
+    else if (variant == 1) DMPC_LAUNCH_GGL((mpc_step_fused_asm_kernel<NX_, NU_, true, false>), grid, block, lds, stream, ba, fa); \
+    else DMPC_LAUNCH_GGL((mpc_step_fused_asm_kernel<NX_, NU_, false, false>), grid, block, lds, stream, ba, fa); \
+    return (int)hipGetLastError();                                                                               \
+  }
+  A(8, 2) A(3, 1) A(4, 2) A(2, 2) A(1, 1) A(2, 1) A(3, 2)
+#undef A
+  return DMPC_E_UNSUPPORTED;
+}
+
 static MpcWs mpc_layout(int T, int B, int nx, int nu) {
   const size_t ns = nx + nu;
   MpcWs w;
@@ -577,10 +602,14 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                  n_qp_iter, info, nullptr, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
                  need_expand ? states : nullptr};
   if (mpc_needs_tiles(nx, nu)) ba.tiled_scratch = reinterpret_cast<float *>(base + w.tiled);
-  int rc = launch_mpc_back(nx, nu, ba, stream);
-  if (rc != 0) return rc;
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
                 max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info};
+  {
+    const int rc = launch_mpc_step_fused(nx, nu, ba, fa, stream);
+    if (rc != DMPC_E_UNSUPPORTED) return rc;
+  }
+  int rc = launch_mpc_back(nx, nu, ba, stream);
+  if (rc != 0) return rc;
   return launch_mpc_fwd(nx, nu, fa, stream);
 }
 

@@ -16,7 +16,7 @@ constexpr size_t mpc_fwd_asm_lds_bytes() {
 }
 
 template <int NX, int NU>
-__global__ __launch_bounds__(256) void mpc_forward_asm_kernel(const MpcFwdArgs a) {
+__device__ __forceinline__ void mpc_forward_asm_body(const MpcFwdArgs &a, const int block) {
   using G = MpcFwdAsm<NX, NU>;
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void mpc_forward_asm_kernel(const MpcFwdArgs a
   const int lane64 = threadIdx.x & 63;
   const int r = lane64 >> 4;  // trajectory within the wave
   const int lane = lane64 & 15;
-  const int b0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.x * 4 + wave) * 4);
+  const int b0 = __builtin_amdgcn_readfirstlane((block * 4 + wave) * 4);
   if (b0 >= a.B) return;      // whole wavefront (B % 4 == 0); the stream has no workgroup barrier
   const int b = b0 + r;
 
@@ -104,6 +104,11 @@ __global__ __launch_bounds__(256) void mpc_forward_asm_kernel(const MpcFwdArgs a
     a.n_ls[b] = nls;
     if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
   }
+}
+
+template <int NX, int NU>
+__global__ __launch_bounds__(256) void mpc_forward_asm_kernel(const MpcFwdArgs a) {
+  mpc_forward_asm_body<NX, NU>(a, blockIdx.x);
 }
 
 }  // namespace dmpc

@@ -96,7 +96,7 @@ import numpy as np, torch
 sys.path.insert(0, sys.argv[1])
 from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost
 from tests.test_mpc_paths_gpu import problem, dev
-B, T, nx, nu, bound, need_expand = 64, 12, 8, 2, 0.25, sys.argv[3] == "1"
+B, T, nx, nu, bound, need_expand = (int(sys.argv[4]) if len(sys.argv) > 4 else 64), 12, 8, 2, 0.25, sys.argv[3] == "1"
 p, lo, hi, u0, x0 = problem(B, T, nx, nu, bound, seed=5)
 step = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(p["C"]), dev(p["c"])),
                LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=need_expand)
@@ -131,6 +131,23 @@ def test_the_kernel_families_agree_with_each_other(tmp_path, need_expand):
         assert int(o["nqp"]) == int(ref["nqp"]), (name, int(o["nqp"]), int(ref["nqp"]))
     np.testing.assert_array_equal(outs["dma"]["Ks"], ref["Ks"])          # the two HIP families: the same arithmetic
     np.testing.assert_array_equal(outs["dma"]["u"], ref["u"])
+
+
+@pytest.mark.parametrize("need_expand,B", [(True, 64), (False, 64), (True, 36)], ids=["recentring", "with_f", "ragged_workgroup"])
+def test_the_step_as_one_launch_is_the_two_launches_bit_for_bit(tmp_path, need_expand, B):
+    """`dmpc_mpc_step_forward` runs both generated streams in one launch (mpc_step_fused_kernel.hpp); with
+    DMPC_NO_MPC_FUSED=1 it is the two launches of before.  Same instruction streams, so everything returned is identical to
+    the bit - also when the last workgroup holds fewer than four wavefronts (B = 36: they leave before the barrier)."""
+    outs = {}
+    for name, env in (("one", {}), ("two", {"DMPC_NO_MPC_FUSED": "1"})):
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", _RUNNER, ROOT, out, "1" if need_expand else "0", str(B)],
+                           env=dict(os.environ, **env), cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    for key in ("x", "u", "Ks", "ks", "costs", "nqp"):
+        np.testing.assert_array_equal(outs["one"][key], outs["two"][key], err_msg=key)
+    assert np.isfinite(outs["one"]["x"]).all()
 
 
 _RUNNER_LS = r"""
