@@ -29,7 +29,7 @@ OUT = os.path.join(HERE, "dpp_blocks_gen.hpp")
 
 # (nx, nu) with nx + nu + 1 <= 16 that get asm blocks (DMPC_LQR_SHAPES with L = 16 and DMPC_LQR_CONTAINERS of lqr_api.hip)
 SHAPES = [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (4, 2), (6, 2), (8, 2), (4, 4), (8, 4), (12, 3),
-          (14, 1), (13, 2), (11, 4), (10, 5), (9, 6), (8, 7), (7, 8)]      # from (14,1) on: containers only (lqr_api.hip DMPC_LQR_CONTAINERS)
+          (14, 1), (13, 2), (11, 4), (5, 5), (10, 5), (9, 6), (8, 7), (7, 8)]      # from (14,1) on: containers only (lqr_api.hip DMPC_LQR_CONTAINERS)
 MAX_OPERANDS = 30
 # float64 variant (gen_dpp_blocks_f64.py -> dpp_blocks_f64_gen.hpp, `RiccatiBlocks64<NX, NU, 16>`): gfx90a+ has the DPP form
 # of the double-precision FMA as well - `v_fmac_f64_dpp ... row_newbcast:k` (the only dpp_ctrl a 64-bit DPP takes), operands

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
 #define DMPC_COSTATE_WAVE_CONTAINERS(X)
 #else
 #define DMPC_COSTATE_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)
-#define DMPC_COSTATE_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
+#define DMPC_COSTATE_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(5, 5) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
 #endif
 
 static bool costate_dma_disabled() {  // DMPC_NO_COSTATE_DMA=1: register-prefetch co-state kernel (A/B timing, debugging)

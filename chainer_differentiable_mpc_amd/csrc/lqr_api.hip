@@ -287,7 +287,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #else
 // (round 4: five to eight controls too - the gain solve on the rows needs no NU x NU LU per lane; before, (5,5) ran a
 // wavefront per trajectory inside the (16,8) matrix-core kernel at 0.03 of the roof)
-#define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
+#define DMPC_LQR_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(5, 5) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
 #endif
 
 // ... and the wavefront-per-trajectory kernels take what is larger, up to 32 states and 8 controls

@@ -27,6 +27,7 @@ Files written:
   imitation_step_1024_it1.npz          the same step from the iterate after ONE box-DDP iteration (most rows have a resolvable margin)
   imitation_loop_16.npz                config 4's loop: three RMSprop updates with the evaluation pass's warm-start carry-over
   pnqp_n8_b256.npz                     PNQP n=8, B=256: the batch whose rows fork under the batch-global termination
+  mpcnet_experiment.npz                the reference's experiment_mpc/MpcNet.py, first training iteration at its own sizes ((3,3), B=128, T=5)
 """
 import io
 import os
@@ -578,6 +579,51 @@ def gen_imitation_loop(ref):
         out["learn_p_%d" % (K - 1)]))
 
 
+def gen_mpcnet_experiment(ref):
+    """The first training iteration of the reference's own experiment experiment_mpc/MpcNet.py:24-120 at its own sizes -
+    T=5, (3,3), B=128, bounds +-10, expert_seed 42, train_seed 1: expert BoxDDP under the true (A, B), the learner's
+    MpcNet_dx, the imitation loss (:80-90) and d loss / d(A, B) - plus a tighter box (+-0.6: the clamped sets matter)."""
+    import importlib
+    ch = ref.chainer
+    V, F, U = ch.Variable, ch.functions, ref.util
+    mpc_net = importlib.import_module("mpc_net")          # (mpc/ is on the path once the reference is loaded)
+    T, nx, nu, B, alpha = 5, 3, 3, 128, 0.2
+    ns = nx + nu
+    out = {}
+    for tag, bound in (("wide", 10.0), ("tight", 0.6)):
+        np.random.seed(42)                                               # expert_seed (:49-50)
+        pvec = np.random.randn(ns)
+        A_exp = np.eye(nx) + alpha * np.random.randn(nx, nx)
+        B_exp = np.random.randn(nx, nu)
+        F_exp = U.expand_time_batch(F.concat((V(A_exp), V(B_exp)), axis=1), T - 1, B)
+        f_exp = V(np.zeros((T - 1, B, nx)))
+        C = U.expand_time_batch(V(np.eye(ns)), T, B)
+        c = U.expand_time_batch(V(pvec), T, B)
+        lo = U.expand_time_batch(-bound * np.ones(nu), T, B)
+        hi = U.expand_time_batch(bound * np.ones(nu), T, B)
+        true_cost, true_dx = U.QuadCost(C, c), U.LinDx(F_exp, f_exp)
+        buf = io.StringIO()
+        with warnings.catch_warnings(), redirect_stdout(buf):
+            warnings.simplefilter("ignore")
+            net = mpc_net.MpcNet_dx(T, lo, hi, B, nx, nu, 1, u_init=None, max_iter=10, verbose=False)   # train_seed = 1
+            x_init = V(_f32(np.random.randn(B, nx)))                      # (:108; float32-representable for the GPU path)
+            expert = ref.box_ddp.BoxDDP(T, lo, hi, B, nx, nu, None)
+            x_true, u_true, _ = expert.forward((x_init.array, true_cost, true_dx))
+            x_pred, u_pred, _ = net((x_init, true_cost))
+        x_true, u_true = arr(x_true), arr(u_true)
+        loss = F.mean((u_true - u_pred) ** 2) + F.mean((x_true - x_pred) ** 2)   # (:86-89)
+        gA, gB = ch.grad([loss], [net.A, net.B])
+        sat = float(((np.abs(arr(u_pred)) >= bound - 1e-8)).mean())
+        out.update({tag + "_bound": bound, tag + "_x_init": x_init.array, tag + "_A0": arr(net.A), tag + "_B0": arr(net.B),
+                    tag + "_A_exp": A_exp, tag + "_B_exp": B_exp, tag + "_p": pvec,
+                    tag + "_x_true": x_true, tag + "_u_true": u_true, tag + "_x_pred": arr(x_pred), tag + "_u_pred": arr(u_pred),
+                    tag + "_loss": arr(loss), tag + "_gA": arr(gA), tag + "_gB": arr(gB), tag + "_stdout": buf.getvalue()})
+        print("mpcnet experiment (%s): loss %.6f sat %.2f |gA| %.3e |gB| %.3e %s" % (
+            tag, float(arr(loss)), sat, np.abs(arr(gA)).max(), np.abs(arr(gB)).max(), buf.getvalue().strip().replace("\n", " | ")[-160:]))
+    np.savez_compressed(os.path.join(HERE, "mpcnet_experiment.npz"), T=T, nx=nx, nu=nu, B=B, **out)
+    print("wrote mpcnet_experiment.npz")
+
+
 def gen_pnqp_fork(ref):
     """PNQP n=8, B=256: batch-global convergence / Armijo tests make rows fork from their batch-of-one
     answers.  Batched run recorded in full; per-row answers for comparison."""
@@ -619,6 +665,7 @@ def main():
     gen_imitation_early(ref)
     gen_imitation_loop(ref)
     gen_pnqp_fork(ref)
+    gen_mpcnet_experiment(ref)
 
 
 if __name__ == "__main__":

@@ -209,6 +209,46 @@ def test_mpcnet_gradient_flows_to_dynamics_parameters():
         assert np.isfinite(got).all() and np.abs(got).max() > 0
 
 
+@pytest.mark.parametrize("tag", ["wide", "tight"])
+def test_the_reference_mpcnet_experiment_first_training_iteration(tag):
+    """experiment_mpc/MpcNet.py:24-120 at its own sizes - T=5, three states, three controls, B=128, expert_seed 42,
+    train_seed 1 - against what the unmodified reference returned (tests/golden/mpcnet_experiment.npz): the expert's
+    BoxDDP solve under the true (A, B), the learner's MpcNet_dx solve, the imitation loss (:80-90) and d loss / d(A, B).
+    `wide`: the experiment's own +-10 box (never reached); `tight`: +-0.6, a quarter of the controls on the box."""
+    g = np.load(os.path.join(GOLDEN, "mpcnet_experiment.npz"))
+    T, B, nx, nu = int(g["T"]), int(g["B"]), int(g["nx"]), int(g["nu"])
+    ns, bound = nx + nu, float(g[tag + "_bound"])
+    lo, hi = torch.full((T, B, nu), -bound, dtype=torch.float64), torch.full((T, B, nu), bound, dtype=torch.float64)
+    net = MpcNet_dx(T, lo, hi, B, nx, nu, 1, u_init=None, max_iter=10, quiet=True).cuda()
+    np.testing.assert_array_equal(npy(net.A), g[tag + "_A0"])       # the same draws as the reference (mpc_net.py:59-64)
+    np.testing.assert_array_equal(npy(net.B), g[tag + "_B0"])
+    C = dev(np.tile(np.eye(ns), (T, B, 1, 1)), torch.float64)
+    c = dev(np.tile(g[tag + "_p"], (T, B, 1)), torch.float64)
+    F_exp = dev(np.tile(np.concatenate((g[tag + "_A_exp"], g[tag + "_B_exp"]), axis=1), (T - 1, B, 1, 1)), torch.float64)
+    f_exp = torch.zeros((T - 1, B, nx), dtype=torch.float64, device="cuda")
+    x_init = dev(g[tag + "_x_init"], torch.float64)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.no_grad():
+            expert = BoxDDP(T, lo, hi, B, nx, nu, None, quiet=True)
+            x_true, u_true, _ = expert((x_init, QuadCost(C, c), LinDx(F_exp, f_exp)))
+        x_pred, u_pred, _ = net((x_init, QuadCost(C, c)))
+    assert expert.status == "Converged" and net.mpc_layer.status == "Converged"      # as the reference printed
+    assert_close(npy(x_true), g[tag + "_x_true"], TOL_PRIMAL, "expert x")
+    assert_close(npy(u_true), g[tag + "_u_true"], TOL_PRIMAL, "expert u")
+    assert_close(npy(x_pred), g[tag + "_x_pred"], TOL_PRIMAL, "learner x")
+    assert_close(npy(u_pred), g[tag + "_u_pred"], TOL_PRIMAL, "learner u")
+    if tag == "tight":
+        on_box = np.abs(np.abs(g[tag + "_u_pred"]) - bound) <= 1e-8
+        assert 0.1 < on_box.mean() < 0.5
+        np.testing.assert_array_equal(np.abs(np.abs(npy(u_pred)) - bound) <= 1e-6, on_box)     # the same clamped set
+    loss = ((u_true - u_pred) ** 2).mean() + ((x_true - x_pred) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[tag + "_loss"])) <= TOL_PRIMAL * max(1.0, abs(float(g[tag + "_loss"])))
+    assert_close(npy(net.A.grad), g[tag + "_gA"], TOL_COSTATE, "d loss / dA")
+    assert_close(npy(net.B.grad), g[tag + "_gB"], TOL_COSTATE, "d loss / dB")
+
+
 def test_fused_pendulum_rollout_and_linearisation():
     """dmpc_pendulum_rollout_linearize against the torch restatement of env_dx/pendulum.py:84-98 and its analytic
     Jacobian (PendulumDx.forward / .linearize, themselves pinned to the oracle by the BoxDDP tests above), incl.

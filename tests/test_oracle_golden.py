@@ -256,6 +256,36 @@ def test_box_ddp_trace_golden():
     np.testing.assert_allclose(costs, g["costs"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["wide", "tight"])
+def test_mpcnet_experiment_golden(tag):
+    """The reference's experiment_mpc/MpcNet.py (first training iteration, its own sizes: T=5, (3,3), B=128): the oracle's
+    box-DDP under the expert's and the learner's (A, B), the imitation loss (:80-90), and d loss / d(A, B) as the sum over
+    time and batch of the final no-op node's dF (box_ddp.py:247-259, mpc_step.py:330-460) - against the reference's run."""
+    from oracle import box_ddp
+    g = load("mpcnet_experiment.npz")
+    T, B, nx, nu = int(g["T"]), int(g["B"]), int(g["nx"]), int(g["nu"])
+    ns, bound = nx + nu, float(g[tag + "_bound"])
+    cost = mpc.QuadCost(np.tile(np.eye(ns), (T, B, 1, 1)), np.tile(g[tag + "_p"], (T, B, 1)))
+    res = {}
+    for who, A, Bm in (("true", g[tag + "_A_exp"], g[tag + "_B_exp"]), ("pred", g[tag + "_A0"], g[tag + "_B0"])):
+        Fm = np.tile(np.concatenate((A, Bm), axis=1), (T - 1, B, 1, 1))
+        x, u, costs, status, *_ = box_ddp.box_ddp(g[tag + "_x_init"], cost, mpc.LinDx(Fm, np.zeros((T - 1, B, nx))),
+                                                  T, -bound, bound, nx, nu)
+        assert status == "Converged"
+        np.testing.assert_allclose(x, g[tag + "_x_" + who], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(u, g[tag + "_u_" + who], rtol=2e-5, atol=2e-6)
+        res[who] = (x, u, Fm)
+    (xt, ut, _), (xp, up, Fm) = res["true"], res["pred"]
+    loss = np.mean((ut - up) ** 2) + np.mean((xt - xp) ** 2)
+    assert abs(loss - float(g[tag + "_loss"])) < 1e-5
+    lo, hi = np.full((T, B, nu), -bound), np.full((T, B, nu), bound)
+    out = mpc.mpc_backward(g[tag + "_x_init"], cost.C, cost.c, Fm, np.zeros((T - 1, B, nx)), xp, up, lo, hi,
+                           -2.0 * (xt - xp) / xp.size, -2.0 * (ut - up) / up.size, T, nx, nu)
+    dAB = out[3].sum(axis=(0, 1))
+    np.testing.assert_allclose(dAB[:, :nx], g[tag + "_gA"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(dAB[:, nx:], g[tag + "_gB"], rtol=2e-4, atol=2e-6)
+
+
 def test_pendulum_jacobian_matches_finite_differences():
     from oracle import box_ddp
     rng = np.random.RandomState(0)
