@@ -34,7 +34,8 @@ BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-slp-
 FLAGS = BASE_FLAGS + ["-I" + os.path.join(ROOT, "include")]
 HASHED_FLAGS = BASE_FLAGS + ["-Iinclude"]     # what the hashes see: the same in every checkout path
 GENERATED = {"lqr_asm_gen.hpp": "gen_lqr_asm.py", "dpp_blocks_gen.hpp": "gen_dpp_blocks.py",
-             "mpc_fwd_asm_gen.hpp": "gen_mpc_fwd_asm.py", "dpp_blocks_f64_gen.hpp": "gen_dpp_blocks_f64.py"}
+             "mpc_fwd_asm_gen.hpp": "gen_mpc_fwd_asm.py", "dpp_blocks_f64_gen.hpp": "gen_dpp_blocks_f64.py",
+             "dpp_blocks_wide_gen.hpp": "gen_dpp_blocks_wide.py"}
 HASH_TU = "lu_api.hip"      # the translation unit that defines dmpc_source_hash()
 
 

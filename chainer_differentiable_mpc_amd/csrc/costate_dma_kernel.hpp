@@ -196,6 +196,8 @@ __global__ __launch_bounds__(256) void costate_dma_kernel(const CostateArgs a) {
   static_for<0, DB>([&](auto j) { issue_next(j.value); });
   wait_vmcnt<(DB - 1) * Lay::kDma>();
   read_slot(ring, sa);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // these reads are in before the loop's first fetch refills their slot (round 4:
+  // a cache-resident refill was seen to overtake them in lqr_wide_kernel - tiny problems, wrong rows at the first step)
   for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
     static_for<0, DB>([&](auto j) {
       const int t = t0 - j.value;

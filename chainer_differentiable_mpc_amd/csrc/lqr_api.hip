@@ -13,6 +13,7 @@
 #include "lqr_tiled.hpp"
 #include "lqr_kernels.hpp"
 #include "lqr_wave_api.hpp"
+#include "lqr_wide_kernel.hpp"
 
 namespace dmpc {
 
@@ -298,6 +299,50 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #define DMPC_LQR_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)
 #endif
 
+// 17 to 32 augmented columns with at most 16 states: the wide 16-lane row kernel (lqr_wide_kernel.hpp; two registers per
+// matrix row, four trajectories per wavefront) for the plain fused solve of exactly these shapes - round 4; before, a
+// wavefront per trajectory inside the (16,8) matrix-core instance.  DMPC_NO_WIDE=1: that path (A/B timing).
+#if (defined(DMPC_EXPERIMENT_ONLY_32_8) || defined(DMPC_EXPERIMENT_ONLY_8_2) || defined(DMPC_EXPERIMENT_ONLY_4_4) || \
+     defined(DMPC_EXPERIMENT_ONLY_8_4)) && !defined(DMPC_EXPERIMENT_WITH_WIDE)
+#define DMPC_LQR_WIDE_SHAPES(X)
+#else
+#define DMPC_LQR_WIDE_SHAPES(X) X(16, 4) X(16, 8) X(12, 4) X(12, 8)
+#endif
+static bool wide_disabled() {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
+  return off;
+}
+static bool wide_shape(int nx, int nu) {
+#define X(NX_, NU_) \
+  if (nx == NX_ && nu == NU_) return true;
+  DMPC_LQR_WIDE_SHAPES(X)
+#undef X
+  return false;
+}
+// can the wide kernel take this solve?  (whole wavefronts of four trajectories, a horizon with an F, 32-bit time strides;
+// the gain rows travel through the caller's workspace)
+static bool wide_ok(int mode, int nx, int nu, const LqrArgs &a) {
+  return mode == kSolve && wide_shape(nx, nu) && !wide_disabled() && a.mask == nullptr && a.wsK != nullptr && a.B >= 4 &&
+         a.T >= 2 && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
+}
+static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
+  const dim3 grid((a.B + 15) / 16), block(256);
+#define X(NX_, NU_)                                                                                        \
+  if (nx == NX_ && nu == NU_) {                                                                            \
+    constexpr int DB = 2, DF = 2;                                                                          \
+    constexpr size_t lds = LqrWideLayout<NX_, NU_, DB, DF>::lds_bytes();                                   \
+    static_assert(lds <= 160 * 1024, "rings beyond a CU's LDS");                                           \
+    if (lds > 64 * 1024)                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF>), grid, block, lds, stream, a);                     \
+    return (int)hipGetLastError();                                                                         \
+  }
+  DMPC_LQR_WIDE_SHAPES(X)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
 static bool has_container(int nx, int nu) {
 #define X(NX_, NU_) \
   if (nx <= NX_ && nu <= NU_) return true;
@@ -380,6 +425,7 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
   if (a.c_u != nullptr || a.Ks_in != nullptr || a.Vv_in != nullptr || a.Quu_out != nullptr ||
       (a.x_init == nullptr && a.x != nullptr))
     return DMPC_E_UNSUPPORTED;
+  if (wide_ok(mode, nx, nu, a)) return launch_lqr_wide(nx, nu, a, stream);
   if (lqr_family(nx, nu) == 4 && !container_disabled()) {
 #define X(NX_, NU_) \
   if (nx <= NX_ && nu <= NU_) return launch_lqr_container<NX_, NU_>(mode, nx, nu, a, stream);
@@ -454,6 +500,7 @@ int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   if (nx == NX_ && nu == NU_) return solve_path<NX_, NU_, L_>(T, B);
   DMPC_LQR_SHAPES(X)
 #undef X
+  if (wide_shape(nx, nu) && !wide_disabled() && B >= 4 && T >= 2) return 9;   // lqr_wide_kernel (given the workspace)
   if (lqr_family(nx, nu) == 4 && !container_disabled()) return 7;   // a container kernel (lqr_kernel<..., PAD>)
   if (lqr_family(nx, nu) == 5) return 8;                              // lqr_tiled_kernel: any size
   return (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) ? 0 : DMPC_E_UNSUPPORTED;

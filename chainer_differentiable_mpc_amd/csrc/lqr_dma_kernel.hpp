@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
     static_for<0, DB>([&](auto j) { issue_next(j.value); });
     wait_vmcnt<(DB - 1) * Lay::kDmaB>();
     read_slot(ring, QA, FA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // these reads are in before the loop's first fetch refills their slot (round 4:
+    // a cache-resident refill was seen to overtake them in lqr_wide_kernel - tiny problems, wrong rows at the first step)
 #ifdef DMPC_TIMING_SKIP_BWD
     for (int t0 = -1; t0 >= 0; t0 -= DB) {
 #else
@@ -381,6 +383,8 @@ __global__ __launch_bounds__(256) void lqr_dma_kernel(const LqrArgs a) {
     static_for<0, DF>([&](auto j) { issue_next(j.value); });
     wait_vmcnt<(DF - 1) * Lay::kDmaF>();
     read_rows(0, 0, MA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // these reads are in before the loop's first fetch refills their slot (round 4:
+    // a cache-resident refill was seen to overtake them in lqr_wide_kernel - tiny problems, wrong rows at the first step)
 #ifdef DMPC_TIMING_SKIP_FWD
     for (int t0 = T; t0 < T; t0 += DF) {
 #else

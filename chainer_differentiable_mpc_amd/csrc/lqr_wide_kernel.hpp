@@ -1,0 +1,388 @@
+// lqr_wide_kernel.hpp - the fused LQR solve (LqrRecursion.solve_recursion, lqr/lqr_recursion.py:69-209) for problems whose
+// augmented matrices have 17 to 32 columns (nx <= 16, 16 <= nx + nu <= 31), on the 16-lane row layout with TWO registers per
+// matrix row: register [i][h] of lane j holds M[i][16 h + j].
+//
+// A trajectory keeps ONE DPP row of 16 lanes - four trajectories per wavefront, the products stay chains of
+// `v_fmac_f32_dpp ... row_newbcast` (dpp_blocks_wide_gen.hpp) - where these shapes used to take a whole wavefront each on
+// the matrix-core kernel of the (32,8) class (inside its (16,8) instance, lqr_wave_mfma.hpp): ~2,000 instructions per
+// trajectory and step there, ~1,700 per FOUR trajectories here.  Everything else is lqr_dma_kernel.hpp's scheme: the wave's four
+// consecutive trajectories make every input array one contiguous run per timestep, fetched into an LDS ring by per-lane
+// gather DMA (16 bytes per lane), the registers filled by ds_read with per-lane indices, counted vmcnt waits, no barrier.
+// The gain rows [K_m | 0 | k_m] go to the caller's workspace ([T,B,NU,NS+1] floats, the KHBM form) and come back to the
+// rollout through its ring with F and f: at these sizes they do not fit next to the rings.
+//
+// Same arithmetic as lqr_kernel / lqr_dma_kernel with the row Gauss-Jordan of riccati_blocks.hpp (LAPACK's pivot choice).
+// Needs B >= 4, 16-byte aligned arrays, the workspace.  Plain solve only: LQR_active, the separate sweeps and the co-state
+// kernels of these shapes stay where they were (containers).
+#pragma once
+#include "colwise.hpp"
+#include "dma_gather.hpp"
+#include "dpp_blocks_wide_gen.hpp"
+#include "lqr_dma_kernel.hpp"
+#include "lqr_kernels.hpp"
+
+namespace dmpc {
+
+template <int NX, int NU, int DB, int DF>
+struct LqrWideLayout {
+  static constexpr int NS = NX + NU, KROW = NS + 1;
+  static constexpr int C_FL = 4 * NS * NS, c_FL = 4 * NS, F_FL = 4 * NX * NS, f_FL = 4 * NX, K_FL = 4 * NU * KROW;
+  static constexpr int OFF_C = 0, OFF_c = OFF_C + C_FL, OFF_F = OFF_c + c_FL, OFF_f = OFF_F + F_FL;
+  static constexpr int CH_B = (OFF_f + f_FL) / 4;          // 16-byte chunks of a backward slot [C | c | F | f]
+  static constexpr int CH_F = (F_FL + f_FL + K_FL) / 4;    // ... of a forward slot [F | f | gain rows]
+  static constexpr int kDmaB = (CH_B + 63) / 64, kDmaF = (CH_F + 63) / 64;
+  static constexpr int SLOT_B = kDmaB * 256, SLOT_F = kDmaF * 256;   // floats: whole kilobytes
+  static constexpr int RING_FL = (DB * SLOT_B > DF * SLOT_F) ? DB * SLOT_B : DF * SLOT_F;   // per wave
+  static constexpr size_t lds_bytes() { return (size_t)4 * RING_FL * 4; }
+};
+
+// Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie (gauss_jordan_rows of riccati_blocks.hpp, two registers per
+// row): the multiplier of row i at pivot k is column NX + k of it - lane (NX + k) % 16 of register (NX + k) / 16.
+template <int NX, int NU>
+__device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][2]) {
+  using G = Group<16>;
+  bool singular = false;
+  static_for<0, NU>([&](auto kc) {
+    constexpr int k = kc.value, kb = (NX + k) / 16, kl = (NX + k) % 16;
+    float p = G::template bcast<kl>(Kr[k][kb]);
+    float li[NU];
+    float mx = 0.f;
+    static_for<k + 1, NU>([&](auto ic) {
+      li[ic.value] = G::template bcast<kl>(Kr[ic.value][kb]);
+      mx = fmaxf(mx, fabsf(li[ic.value]));
+    });
+    if (k + 1 < NU && any_lane(mx > fabsf(p))) {   // rare: LAPACK's row interchange (the first largest entry)
+      float best = fabsf(p);
+      int pr = k;
+      static_for<k + 1, NU>([&](auto ic) {
+        const bool gt = fabsf(li[ic.value]) > best;
+        best = gt ? fabsf(li[ic.value]) : best;
+        pr = gt ? ic.value : pr;
+      });
+      static_for<k + 1, NU>([&](auto ic) {
+        const bool sw = pr == ic.value;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float rk = Kr[k][h], ri = Kr[ic.value][h];
+          Kr[k][h] = sw ? ri : rk;
+          Kr[ic.value][h] = sw ? rk : ri;
+        }
+        const float pl = li[ic.value];
+        li[ic.value] = sw ? p : pl;
+        p = sw ? pl : p;
+      });
+    }
+    singular = singular || (p == 0.f);
+    const float r = fast_rcp(p);
+    Kr[k][0] *= r;
+    Kr[k][1] *= r;
+    static_for<0, NU>([&](auto ic) {
+      constexpr int i = ic.value;
+      if constexpr (i != k) {
+        float l;
+        if constexpr (i > k) l = li[i];
+        else l = G::template bcast<kl>(Kr[i][kb]);
+        Kr[i][0] = fmaf(-l, Kr[k][0], Kr[i][0]);
+        Kr[i][1] = fmaf(-l, Kr[k][1], Kr[i][1]);
+      }
+    });
+  });
+  return singular;
+}
+
+template <int NX, int NU, int DB, int DF>
+__global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
+  using Lay = LqrWideLayout<NX, NU, DB, DF>;
+  using Blk = RiccatiBlocksWide<NX, NU>;
+  using G = Group<16>;
+  constexpr int NS = NX + NU, KROW = NS + 1;
+  constexpr int AB = NS / 16, AL = NS % 16;   // the affine column: register AB, lane AL
+  static_assert(Blk::kAvailable, "no generated blocks for this shape (gen_dpp_blocks_wide.py SHAPES)");
+  static_assert(NX <= 16 && NS >= 16 && NS <= 31, "17 to 32 augmented columns, state columns in the first register");
+  static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
+  static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
+  static_assert((DB - 1) * Lay::kDmaB + 2 * NU <= 63, "counted wait out of range");
+
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const bool has_f = a.f != nullptr;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r = lane64 >> 4;   // trajectory within the wave
+  const int lane = lane64 & 15;
+  int b0 = ((int)blockIdx.x * 4 + wave) * 4;  // first trajectory of this wave
+  if (b0 > a.B - 4) b0 = a.B - 4;             // the last wave overlaps its neighbour instead of running ragged
+  b0 = __builtin_amdgcn_readfirstlane(b0);
+  const int b = b0 + r;
+
+  extern __shared__ float lds[];
+  float *ring = lds + wave * Lay::RING_FL;
+  float *kw = a.wsK + (size_t)b * NU * KROW;    // + t * B * NU * KROW: this trajectory's gain rows in the workspace
+  const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+
+  const int col1 = 16 + lane;                   // this lane's column in the second register
+  const bool aff1 = col1 == NS;                 // ... is the affine column
+  const bool real1 = col1 < NS;                 // ... is a column of C / F
+  int info_bits = 0;
+
+  // ------------------------------------------------------------------ backward Riccati sweep
+  {
+    // gather pointers (lqr_dma_kernel.hpp): chunk 64 q + lane64 of the slot [C | c | F | f] from its own address; every array
+    // steps BACK one timestep per fetch (32-bit strides: the launcher checks B * ns^2 * 4 < 2^31); F and f have no slice
+    // T-1: their lanes (`dyn`) start at T-2 and sit out the first step
+    unsigned long long ptr[Lay::kDmaB];
+    unsigned str[Lay::kDmaB], dyn = 0;
+#pragma unroll
+    for (int q = 0; q < Lay::kDmaB; ++q) {
+      const int g = q * 64 + lane64;
+      const int gg = g < Lay::CH_B ? g : 0;
+      const char *base;
+      size_t per;
+      int g0;
+      bool d = false;
+      if (gg < Lay::OFF_c / 4) { base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = 0; }
+      else if (gg < Lay::OFF_F / 4) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::OFF_c / 4; }
+      else if (gg < Lay::OFF_f / 4) { base = (const char *)(T > 1 ? a.F : a.C); per = (size_t)NX * NS * 4; g0 = Lay::OFF_F / 4; d = true; }
+      else { base = (const char *)(has_f ? a.f : a.c); per = (size_t)NX * 4; g0 = Lay::OFF_f / 4; d = true; }
+      const int t0 = d ? (T > 1 ? T - 2 : 0) : T - 1;
+      ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 -
+               (unsigned long long)(q % 4) * 1024u;
+      str[q] = (unsigned)(B * per);
+      dyn |= d ? (1u << q) : 0u;
+    }
+    int ti = T - 1;
+    auto issue_next = [&](int slot) __attribute__((always_inline)) {
+      const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT_B * 4);
+      static_for<0, Lay::kDmaB>([&](auto q) {
+        if constexpr (q.value % 4 == 0) set_m0(dst + (unsigned)q.value * 1024u);
+        dma16_gather<(q.value % 4) * 1024>(ptr[q.value]);
+      });
+      if (ti > 0) {
+        if (ti == T - 1) {
+#pragma unroll
+          for (int q = 0; q < Lay::kDmaB; ++q) ptr[q] -= ((dyn >> q) & 1u) ? 0ull : (unsigned long long)str[q];
+        } else {
+#pragma unroll
+          for (int q = 0; q < Lay::kDmaB; ++q) ptr[q] -= (unsigned long long)str[q];
+        }
+        --ti;
+      }
+    };
+    // per-lane LDS indices (floats, relative to a slot): the first register reads column `lane`, the second column 16 + lane
+    // of C / F - or c / f in the affine column's lane (row stride 1 there), or anything finite past it (never broadcast)
+    const int q0 = Lay::OFF_C + r * NS * NS + lane, f0 = Lay::OFF_F + r * NX * NS + lane;
+    const int q1 = aff1 ? Lay::OFF_c + r * NS : Lay::OFF_C + r * NS * NS + (real1 ? col1 : 0);
+    const int f1 = aff1 ? Lay::OFF_f + r * NX : Lay::OFF_F + r * NX * NS + (real1 ? col1 : 0);
+    const int s1 = aff1 ? 1 : NS;
+    auto read_slot = [&](const float *slot, float (&Qn)[NS][2], float (&Fn)[NX][2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        Qn[i][0] = slot[q0 + i * NS];
+        Qn[i][1] = slot[q1 + i * s1];
+      }
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        Fn[k][0] = slot[f0 + k * NS];
+        Fn[k][1] = slot[f1 + k * s1];
+      }
+    };
+
+    float V[NX][2];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) V[i][0] = V[i][1] = 0.f;
+
+    auto step = [&](int t, float (&Q)[NS][2], float (&Fc)[NX][2]) __attribute__((always_inline)) {
+      const size_t tb = (size_t)t * B + b;
+      if (t < T - 1) {
+        if (!has_f) {
+#pragma unroll
+          for (int k = 0; k < NX; ++k) Fc[k][1] = aff1 ? 0.f : Fc[k][1];
+        }
+        float W[NX][2];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          W[i][0] = 0.f;
+          W[i][1] = aff1 ? V[i][1] : 0.f;    // + v in the affine column
+        }
+        Blk::vf(W, V, Fc);    // lqr_recursion.py:89,96
+        Blk::ftw(Q, Fc, W);
+      }
+      // K~ = -Quu^-1 [Qux | Quu | qu] on the rows (:112-120)
+      float Qu[NU][2], Kt[NU][2], R[NU][2];
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        Qu[m][0] = Kt[m][0] = Q[NX + m][0];
+        Qu[m][1] = Kt[m][1] = Q[NX + m][1];
+      }
+      if (gauss_jordan_rows_wide<NX, NU>(Kt)) info_bits |= 1;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) {
+        Kt[m][0] = -Kt[m][0];
+        Kt[m][1] = -Kt[m][1];
+      }
+      // gain rows [K_m | 0 | k_m] to the workspace (the rollout reads them like rows of F), and to the caller
+      {
+        float *row = kw + (size_t)t * B * (NU * KROW);
+        if (lane < NX) {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) row[m * KROW + lane] = Kt[m][0];
+        }
+        if (aff1) {
+#pragma unroll
+          for (int m = 0; m < NU; ++m) row[m * KROW + NS] = Kt[m][1];
+        }
+        if (a.Ks != nullptr) {
+          if (lane < NX) {
+#pragma unroll
+            for (int m = 0; m < NU; ++m) a.Ks[(tb * NU + m) * NX + lane] = Kt[m][0];
+          }
+          if (aff1) {
+#pragma unroll
+            for (int m = 0; m < NU; ++m) a.ks[tb * NU + m] = Kt[m][1];
+          }
+        }
+      }
+      if (t > 0) {  // value update, :151-152
+#pragma unroll
+        for (int m = 0; m < NU; ++m) {
+          R[m][0] = Qu[m][0];
+          R[m][1] = Qu[m][1];
+        }
+        Blk::rk(R, Qu, Kt);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          V[i][0] = Q[i][0];
+          V[i][1] = Q[i][1];
+        }
+        Blk::vupd(V, Q, Kt, R);
+      }
+    };
+
+    // ONE register set (two would not fit next to V and W): at the top of step t its slot is waited for and read, then -
+    // once the reads are in - refilled with step t - DB, and the step is computed while DB - 1 fetches are in flight.  The
+    // gain-row stores of a step are younger than its refill and retire in order with it (one counter): the counted wait
+    // allows for the 2 NU a step always issues.
+    float Q[NS][2], Fc[NX][2];
+    static_for<0, DB>([&](auto j) { issue_next(j.value); });
+    for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
+      static_for<0, DB>([&](auto j) {
+        const int t = t0 - j.value;
+        if (t >= 0) {
+          if (t == T - 1) wait_vmcnt<(DB - 1) * Lay::kDmaB>();
+          else wait_vmcnt<(DB - 1) * Lay::kDmaB + 2 * NU>();
+          read_slot(ring + j.value * Lay::SLOT_B, Q, Fc);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads are in before it is refilled
+          issue_next(j.value);
+          step(t, Q, Fc);
+        }
+      });
+    }
+    wait_vmcnt<0>();   // the ring is reused by the rollout, and this wave's gain rows have reached L2
+    __threadfence();
+  }
+
+  // ------------------------------------------------------------------ forward rollout (lqr_recursion.py:160-200)
+  {
+    unsigned long long ptr[Lay::kDmaF], str[Lay::kDmaF];
+    bool kstep[Lay::kDmaF];      // lanes that fetch gain rows (T slices: they take the last pointer step alone)
+#pragma unroll
+    for (int q = 0; q < Lay::kDmaF; ++q) {
+      const int g = q * 64 + lane64;
+      const int gg = g < Lay::CH_F ? g : 0;
+      const bool isk = gg >= (Lay::F_FL + Lay::f_FL) / 4;
+      const bool isf = !isk && gg >= Lay::F_FL / 4;
+      const char *base = isk ? (const char *)a.wsK : isf ? (const char *)(has_f ? a.f : a.C) : (const char *)(T > 1 ? a.F : a.C);
+      const size_t per = isk ? (size_t)NU * KROW * 4 : isf ? (size_t)NX * 4 : (size_t)NX * NS * 4;
+      const int g0 = isk ? (Lay::F_FL + Lay::f_FL) / 4 : isf ? Lay::F_FL / 4 : 0;
+      ptr[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)(gg - g0) * 16 - (unsigned long long)(q % 4) * 1024u;
+      str[q] = (unsigned long long)(B * per);
+      kstep[q] = isk;
+    }
+    int ti = 0;
+    auto issue_next = [&](int slot) __attribute__((always_inline)) {
+      const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT_F * 4);
+      static_for<0, Lay::kDmaF>([&](auto q) {
+        if constexpr (q.value % 4 == 0) set_m0(dst + (unsigned)q.value * 1024u);
+        dma16_gather<(q.value % 4) * 1024>(ptr[q.value]);
+      });
+      if (ti < T - 2) {
+#pragma unroll
+        for (int q = 0; q < Lay::kDmaF; ++q) ptr[q] += str[q];
+        ++ti;
+      } else if (ti == T - 2) {
+#pragma unroll
+        for (int q = 0; q < Lay::kDmaF; ++q) ptr[q] += kstep[q] ? str[q] : 0ull;
+        ++ti;
+      }
+    };
+    // lane i < NX owns row i of [F_t | f_t]; lane m < NU ALSO owns row m of the gains [K_t | . | k_t]:
+    //     u[m]   = k[m] + sum_j K[m][j] x[j]                        (lanes m < NU; x[j] broadcast from lane j)
+    //     x'[i]  = f[i] + sum_j F[i][j] x[j] + sum_m F[i][NX+m] u[m]  (lanes i < NX; u[m] broadcast from lane m)
+    const int lane_x = lane < NX ? lane : NX - 1, lane_u = lane < NU ? lane : NU - 1;
+    const int xrow = r * NX * NS + lane_x * NS, xaff = Lay::F_FL + r * NX + lane_x;
+    const int urow = Lay::F_FL + Lay::f_FL + (r * NU + lane_u) * KROW;
+    auto read_rows = [&](int slot, float (&Fr)[NS + 1], float (&Kr)[NX + 1]) __attribute__((always_inline)) {
+      const float *s = ring + slot * Lay::SLOT_F;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) Fr[j] = s[xrow + j];
+      Fr[NS] = s[xaff];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) Kr[j] = s[urow + j];
+      Kr[NX] = s[urow + NS];
+    };
+    float xv = lane < NX ? a.x_init[(size_t)b * NX + lane] : 0.f;
+    auto fstep = [&](int t, const float (&Fr)[NS + 1], const float (&Kr)[NX + 1]) __attribute__((always_inline)) {
+      const size_t tb = (size_t)t * B + b;
+      float ua = Kr[NX], ub = 0.f;
+      static_for<0, NX>([&](auto j) {
+        const float xj = G::template bcast<j.value>(xv);
+        if constexpr (j.value % 2 == 0) ua = fmaf(xj, Kr[j.value], ua);
+        else ub = fmaf(xj, Kr[j.value], ub);
+      });
+      const float uv = ua + ub;
+      if (lane < NX) a.x[tb * NX + lane] = xv;
+      if (lane < NU) a.u[tb * NU + lane] = uv;
+      float xa = has_f ? Fr[NS] : 0.f, xb = 0.f;   // (for t = T-1 this consumes a re-fetched F_{T-2}: never used)
+      static_for<0, NX>([&](auto j) {
+        const float xj = G::template bcast<j.value>(xv);
+        if constexpr (j.value % 2 == 0) xa = fmaf(xj, Fr[j.value], xa);
+        else xb = fmaf(xj, Fr[j.value], xb);
+      });
+      static_for<0, NU>([&](auto m) {
+        const float um = G::template bcast<m.value>(uv);
+        if constexpr (m.value % 2 == 0) xa = fmaf(um, Fr[NX + m.value], xa);
+        else xb = fmaf(um, Fr[NX + m.value], xb);
+      });
+      xv = xa + xb;
+    };
+    float FA[NS + 1], KA[NX + 1], FB[NS + 1], KB[NX + 1];
+    static_for<0, DF>([&](auto j) { issue_next(j.value); });
+    wait_vmcnt<(DF - 1) * Lay::kDmaF>();
+    read_rows(0, FA, KA);
+    for (int t0 = 0; t0 < T; t0 += DF) {
+      static_for<0, DF>([&](auto j) {
+        const int t = t0 + j.value;
+        if (t < T) {
+          constexpr int nslot = (j.value + 1) % DF;
+          // the rows read out of this slot (a step ago; for t = 0: just now) are in before it is refilled - a
+          // cache-resident refill was seen to overtake the prologue's reads (wrong rows of F at the first step)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          issue_next(j.value);
+          wait_vmcnt<(DF - 1) * Lay::kDmaF>();
+          if constexpr (j.value % 2 == 0) {
+            read_rows(nslot, FB, KB);
+            fstep(t, FA, KA);
+          } else {
+            read_rows(nslot, FA, KA);
+            fstep(t, FB, KB);
+          }
+        }
+      });
+    }
+    wait_vmcnt<0>();
+    if (!is_finite(xv)) info_bits |= 2;   // NaN / Inf propagate through the recursion
+  }
+  if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+}
+
+}  // namespace dmpc

@@ -691,6 +691,8 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_kernel(const MpcFwdArgs a
       static_for<0, DB>([&](auto j) { issue_next(j.value); });
       wait_vmcnt<(DB - 1) * Lay::kDma>();
       read_slot(ring, sa);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // these reads are in before the loop's first fetch refills their slot (round 4:
+      // a cache-resident refill was seen to overtake them in lqr_wide_kernel - tiny problems, wrong rows at the first step)
       xh = is_x ? sa.xt : 0.f;
       for (int t0 = 0; t0 < T; t0 += DB) {
         static_for<0, DB>([&](auto j) {
@@ -957,6 +959,8 @@ __device__ __forceinline__ void mpc_forward_rec_pendulum_spec_body(const MpcFwdA
       static_for<0, DB>([&](auto j) { issue_next(j.value); });
       wait_vmcnt<DB - 1>();
       read_slot(ring, sa);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // these reads are in before the loop's first fetch refills their slot (round 4:
+      // a cache-resident refill was seen to overtake them in lqr_wide_kernel - tiny problems, wrong rows at the first step)
       for (int t0 = 0; t0 < T; t0 += DB) {
         static_for<0, DB>([&](auto j) {
           const int t = t0 + j.value;

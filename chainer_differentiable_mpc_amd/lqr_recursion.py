@@ -247,7 +247,9 @@ def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False,
     per_traj_lds = T * nu * (nx + 1) * 4
     family = lib.dmpc_lqr_kernel_family(nx, nu)
     # (family 5 - beyond 64 columns - keeps every trajectory's matrices in the workspace, whoever receives the gains)
-    if family == 5 or (not want_gains and (per_traj_lds * 16 > 60 * 1024 or family != 1)):
+    # (... and the wide row kernel - solve path 9 - sends its gain rows through it on their way to the rollout)
+    wide = lib.dmpc_lqr_solve_path(T, B, nx, nu) == 9
+    if family == 5 or wide or (not want_gains and (per_traj_lds * 16 > 60 * 1024 or family != 1)):
         ws = _workspace(need, dev)
         ws_bytes = need
     with _lib.guard(dev):

@@ -139,6 +139,7 @@ def test_container_shapes_against_oracle(dims):
     assert np.all(npy(u)[act] == 0)
 
 
+WIDE_ROW_SHAPES = [(16, 4), (16, 8), (12, 4), (12, 8)]     # lqr_wide_kernel.hpp: two registers per matrix row
 WAVE_CONTAINER_SHAPES = [(5, 5), (3, 8), (12, 4), (16, 4), (10, 6), (16, 8), (15, 7), (20, 6), (24, 8), (31, 7), (17, 1), (32, 3)]
 
 
@@ -149,7 +150,8 @@ def test_wide_container_shapes_against_oracle(dims):
     nx, nu = dims
     B, T = 7, 6
     lib = _lib.load()
-    assert lib.dmpc_lqr_kernel_family(nx, nu) == 4 and lib.dmpc_lqr_solve_path(T, B, nx, nu) == 7
+    assert lib.dmpc_lqr_kernel_family(nx, nu) == 4
+    assert lib.dmpc_lqr_solve_path(T, B, nx, nu) == (9 if dims in WIDE_ROW_SHAPES else 7)   # (9: the fused solve only)
     for with_f in (True, False):
         p = synthetic.make_lqr_problem(B, T, nx, nu, seed=200 + nx, with_f=with_f)
         xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
@@ -173,6 +175,36 @@ def test_wide_container_shapes_against_oracle(dims):
     assert_close(npy(x), xr, TOL_PRIMAL, "x active")
     assert_close(npy(u), ur, TOL_PRIMAL, "u active")
     assert np.all(npy(u)[act] == 0)
+
+
+@pytest.mark.parametrize("dims", WIDE_ROW_SHAPES, ids=["%dx%d" % d for d in WIDE_ROW_SHAPES])
+def test_wide_row_kernel_against_oracle(dims):
+    """17 to 32 augmented columns, at most 16 states: the fused solve on the wide 16-lane row layout (lqr_wide_kernel.hpp; four
+    trajectories per wavefront, gain rows through the workspace) - whole and ragged batches, two steps to a horizon that
+    wraps its rings many times, with and without f, with and without the gains handed out; and the same solve on the
+    path these shapes took before (DMPC_NO_WIDE is read once per process, so: the separate sweeps, which never take it)."""
+    nx, nu = dims
+    lib = _lib.load()
+    for (B, T, with_f, want_gains, seed) in ((64, 13, True, False, 1), (37, 7, False, True, 2), (4, 2, True, True, 3),
+                                            (5, 41, True, False, 4)):
+        assert lib.dmpc_lqr_solve_path(T, B, nx, nu) == 9
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=300 + seed + nx, with_f=with_f)
+        xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        d = to_dev(p)
+        x, u, Ks, ks = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, want_gains=want_gains)
+        assert _lib.last_kernel_name().startswith("void dmpc::lqr_wide_kernel<%d, %d" % dims)
+        assert_close(npy(x), xr, TOL_PRIMAL, "x")
+        assert_close(npy(u), ur, TOL_PRIMAL, "u")
+        if want_gains:
+            Ksr, ksr = olqr.lqr_backward(p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+            assert_close(npy(Ks), Ksr, TOL_PRIMAL, "Ks")
+            assert_close(npy(ks), ksr, TOL_PRIMAL, "ks")
+        rec = LqrRecursion(d["x_init"], d["C"], d["c"], d["F"], d["f"], T, nx, nu)
+        x2, u2 = rec.forward(*rec.backward())          # the container kernels (the path of rounds 2-4)
+        assert_close(npy(x), npy(x2), 2e-5, "x against the separate sweeps")
+        assert_close(npy(u), npy(u2), 2e-5, "u against the separate sweeps")
+    # a batch below one wavefront of four trajectories does not take it
+    assert lib.dmpc_lqr_solve_path(6, 3, nx, nu) == 7
 
 
 @pytest.mark.parametrize("dims", [(6, 3), (13, 2)])
