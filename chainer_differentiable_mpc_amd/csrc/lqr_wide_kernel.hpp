@@ -2,10 +2,14 @@
 // augmented matrices have 17 to 32 columns (nx <= 16, 16 <= nx + nu <= 31), on the 16-lane row layout with TWO registers per
 // matrix row: register [i][h] of lane j holds M[i][16 h + j].
 //
-// A trajectory keeps ONE DPP row of 16 lanes - four trajectories per wavefront, the products stay chains of
-// `v_fmac_f32_dpp ... row_newbcast` (dpp_blocks_wide_gen.hpp) - where these shapes used to take a whole wavefront each on
-// the matrix-core kernel of the (32,8) class (inside its (16,8) instance, lqr_wave_mfma.hpp): ~2,000 instructions per
-// trajectory and step there, ~1,700 per FOUR trajectories here.  Everything else is lqr_dma_kernel.hpp's scheme: the wave's four
+// A trajectory keeps ONE DPP row of 16 lanes - four trajectories per wavefront - where these shapes used to take a whole
+// wavefront each on the matrix-core kernel of the (32,8) class (inside its (16,8) instance, lqr_wave_mfma.hpp: ~2,000
+// instructions per trajectory and step).  The products of the A^T B shape - G = V^T F~, Q~ += G^T F~ (the reference's own
+// association (F^T V) F, lqr_recursion.py:89,96) and K~^T R of the value update - are outer products of registers and run on
+// the matrix cores: `v_mfma_f32_4x4x1_16b_f32` with cbsz:2 takes four lanes (rows 4I..4I+3) of a trajectory's A register
+// against all 16 lanes of its B register, one instruction per 4 x 16 block and inner index (the (8,2) stream's scheme,
+// gen_lqr_asm.py).  The A B shapes (Qxu K~, Quu K~, v^T F~) stay chains of `v_fmac_f32_dpp ... row_newbcast`
+// (dpp_blocks_wide_gen.hpp).  ~1,100 instructions per step and FOUR trajectories.  Everything else is lqr_dma_kernel.hpp's scheme: the wave's four
 // consecutive trajectories make every input array one contiguous run per timestep, fetched into an LDS ring by per-lane
 // gather DMA (16 bytes per lane), the registers filled by ds_read with per-lane indices, counted vmcnt waits, no barrier.
 // The gain rows [K_m | 0 | k_m] go to the caller's workspace ([T,B,NU,NS+1] floats, the KHBM form) and come back to the
@@ -22,6 +26,14 @@
 #include "lqr_kernels.hpp"
 
 namespace dmpc {
+
+typedef float f4w __attribute__((ext_vector_type(4)));
+// D[c] (lane l) += A[lane 16 (l / 16) + 4 I + c] * B[lane l], c < 4: rows 4I..4I+3 of an outer product, per 16-lane trajectory
+template <int I>
+__device__ __forceinline__ f4w mfma_rows(float a, float b, f4w c) {
+  static_assert(I >= 0 && I < 4, "block of four lanes inside a 16-lane row");
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 2, I, 0);
+}
 
 template <int NX, int NU, int DB, int DF>
 struct LqrWideLayout {
@@ -96,9 +108,11 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   using Blk = RiccatiBlocksWide<NX, NU>;
   using G = Group<16>;
   constexpr int NS = NX + NU, KROW = NS + 1;
-  constexpr int AB = NS / 16, AL = NS % 16;   // the affine column: register AB, lane AL
+  constexpr int AB = NS / 16;                 // the affine column lies in register AB (lane NS % 16)
+  constexpr int NT = NS / 4;                  // tiles of four rows of Q~
   static_assert(Blk::kAvailable, "no generated blocks for this shape (gen_dpp_blocks_wide.py SHAPES)");
   static_assert(NX <= 16 && NS >= 16 && NS <= 31, "17 to 32 augmented columns, state columns in the first register");
+  static_assert(NX % 4 == 0 && NU % 4 == 0, "tiles of four rows");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
   static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
   static_assert((DB - 1) * Lay::kDmaB + 2 * NU <= 63, "counted wait out of range");
@@ -174,12 +188,14 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     const int q1 = aff1 ? Lay::OFF_c + r * NS : Lay::OFF_C + r * NS * NS + (real1 ? col1 : 0);
     const int f1 = aff1 ? Lay::OFF_f + r * NX : Lay::OFF_F + r * NX * NS + (real1 ? col1 : 0);
     const int s1 = aff1 ? 1 : NS;
-    auto read_slot = [&](const float *slot, float (&Qn)[NS][2], float (&Fn)[NX][2]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        Qn[i][0] = slot[q0 + i * NS];
-        Qn[i][1] = slot[q1 + i * s1];
-      }
+    auto read_slot = [&](const float *slot, f4w (&Qn)[NT][2], float (&Fn)[NX][2]) __attribute__((always_inline)) {
+      static_for<0, NT>([&](auto I) {
+        static_for<0, 4>([&](auto cc) {
+          constexpr int i = 4 * I.value + cc.value;
+          Qn[I.value][0][cc.value] = slot[q0 + i * NS];
+          Qn[I.value][1][cc.value] = slot[q1 + i * s1];
+        });
+      });
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
         Fn[k][0] = slot[f0 + k * NS];
@@ -187,33 +203,53 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
       }
     };
 
-    float V[NX][2];
+    float V[NX][2];          // [V | v] of the later step: row i = registers [i][0..1]
 #pragma unroll
     for (int i = 0; i < NX; ++i) V[i][0] = V[i][1] = 0.f;
+    const float eaff = aff1 ? 1.f : 0.f;     // unit vector of the affine column (in register AB)
 
-    auto step = [&](int t, float (&Q)[NS][2], float (&Fc)[NX][2]) __attribute__((always_inline)) {
+    auto step = [&](int t, f4w (&Q4)[NT][2], float (&Fc)[NX][2]) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
       if (t < T - 1) {
         if (!has_f) {
 #pragma unroll
           for (int k = 0; k < NX; ++k) Fc[k][1] = aff1 ? 0.f : Fc[k][1];
         }
-        float W[NX][2];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          W[i][0] = 0.f;
-          W[i][1] = aff1 ? V[i][1] : 0.f;    // + v in the affine column
-        }
-        Blk::vf(W, V, Fc);    // lqr_recursion.py:89,96
-        Blk::ftw(Q, Fc, W);
+        // Q~ += F~^T V^ F~ + [0 | F~^T v] as (V^T F~)^T F~ - two chains of outer products (lqr_recursion.py:89,96):
+        //   G[b][j] = sum_a V[a][b] F~[a][j]        rows b = the state columns of V: tiles of 4, A = V[a] lanes 4I..4I+3
+        //   g1[j]   = sum_a v[a] F~[a][j]           (broadcast-FMAs: v[a] is one lane of V[a])
+        //   Q~[i][j] += sum_b G[b][i] F~[b][j]  and  Q~[i][aff] += g1[i]
+        f4w G4[NX / 4][2];
+        static_for<0, NX / 4>([&](auto I) { G4[I.value][0] = G4[I.value][1] = f4w{0.f, 0.f, 0.f, 0.f}; });
+        static_for<0, NX>([&](auto a_) {
+          static_for<0, NX / 4>([&](auto I) {
+            G4[I.value][0] = mfma_rows<I.value>(V[a_.value][0], Fc[a_.value][0], G4[I.value][0]);
+            G4[I.value][1] = mfma_rows<I.value>(V[a_.value][0], Fc[a_.value][1], G4[I.value][1]);
+          });
+        });
+        float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f};
+        Blk::g1(ga, gb, V, Fc);
+        const float g1[2] = {ga[0] + gb[0], ga[1] + gb[1]};
+        static_for<0, NX>([&](auto b_) {
+          static_for<0, NT>([&](auto I) {
+            constexpr int ib = (4 * I.value) / 16, il = ((4 * I.value) % 16) / 4;   // rows 4I..: register ib, lanes 4 il..
+            const float gcol = G4[b_.value / 4][ib][b_.value % 4];                   // row b of G, the register with columns 4I..
+            Q4[I.value][0] = mfma_rows<il>(gcol, Fc[b_.value][0], Q4[I.value][0]);
+            Q4[I.value][1] = mfma_rows<il>(gcol, Fc[b_.value][1], Q4[I.value][1]);
+          });
+        });
+        static_for<0, NT>([&](auto I) {
+          constexpr int ib = (4 * I.value) / 16, il = ((4 * I.value) % 16) / 4;
+          Q4[I.value][AB] = mfma_rows<il>(g1[ib], eaff, Q4[I.value][AB]);
+        });
       }
       // K~ = -Quu^-1 [Qux | Quu | qu] on the rows (:112-120)
       float Qu[NU][2], Kt[NU][2], R[NU][2];
-#pragma unroll
-      for (int m = 0; m < NU; ++m) {
-        Qu[m][0] = Kt[m][0] = Q[NX + m][0];
-        Qu[m][1] = Kt[m][1] = Q[NX + m][1];
-      }
+      static_for<0, NU>([&](auto m) {
+        constexpr int i = NX + m.value;
+        Qu[m.value][0] = Kt[m.value][0] = Q4[i / 4][0][i % 4];
+        Qu[m.value][1] = Kt[m.value][1] = Q4[i / 4][1][i % 4];
+      });
       if (gauss_jordan_rows_wide<NX, NU>(Kt)) info_bits |= 1;
 #pragma unroll
       for (int m = 0; m < NU; ++m) {
@@ -242,19 +278,32 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
           }
         }
       }
-      if (t > 0) {  // value update, :151-152
+      if (t > 0) {  // V = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~), :151-152
 #pragma unroll
         for (int m = 0; m < NU; ++m) {
           R[m][0] = Qu[m][0];
           R[m][1] = Qu[m][1];
         }
         Blk::rk(R, Qu, Kt);
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          V[i][0] = Q[i][0];
-          V[i][1] = Q[i][1];
-        }
-        Blk::vupd(V, Q, Kt, R);
+        f4w V4[NX / 4][2];
+        static_for<0, NX / 4>([&](auto I) {
+          V4[I.value][0] = Q4[I.value][0];
+          V4[I.value][1] = Q4[I.value][1];
+        });
+        static_for<0, NU>([&](auto m) {            // K~^T R: A = K~[m] lanes 4I..4I+3 (the state columns: first register)
+          static_for<0, NX / 4>([&](auto I) {
+            V4[I.value][0] = mfma_rows<I.value>(Kt[m.value][0], R[m.value][0], V4[I.value][0]);
+            V4[I.value][1] = mfma_rows<I.value>(Kt[m.value][0], R[m.value][1], V4[I.value][1]);
+          });
+        });
+        float Qx[NX][2];
+        static_for<0, NX>([&](auto i) {
+          V[i.value][0] = V4[i.value / 4][0][i.value % 4];
+          V[i.value][1] = V4[i.value / 4][1][i.value % 4];
+          Qx[i.value][0] = Q4[i.value / 4][0][i.value % 4];
+          Qx[i.value][1] = Q4[i.value / 4][1][i.value % 4];
+        });
+        Blk::vq(V, Qx, Kt);                         // + Qxu K~
       }
     };
 
@@ -262,7 +311,8 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     // once the reads are in - refilled with step t - DB, and the step is computed while DB - 1 fetches are in flight.  The
     // gain-row stores of a step are younger than its refill and retire in order with it (one counter): the counted wait
     // allows for the 2 NU a step always issues.
-    float Q[NS][2], Fc[NX][2];
+    f4w Q[NT][2];
+    float Fc[NX][2];
     static_for<0, DB>([&](auto j) { issue_next(j.value); });
     for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
       static_for<0, DB>([&](auto j) {
