@@ -69,7 +69,11 @@ int dmpc_lqr_kernel_family(int nx, int nu);
  *   6 lqr_asm_kernel, ring, gain rows through the workspace (horizons whose gain rows do not fit in LDS: T > 74 at
  *     (8,2); needs `ws`)
  *   7 a container: lqr_kernel<..., PAD> of a larger shape, or lqr_wave_mfma_backward<..., PAD> + the forward-only
- *     container kernel (needs `ws` unless the caller takes the gains)        <0 unsupported */
+ *     container kernel (needs `ws` unless the caller takes the gains)
+ *   8 lqr_tiled_kernel (any size: a workgroup per trajectory, matrices in `ws`)
+ *   9 lqr_wide_kernel (17 to 32 augmented columns, at most 16 states - (16,4), (16,8), (12,4), (12,8): four trajectories
+ *     per wavefront, two registers per matrix row, outer products on the matrix cores; needs `ws` - without it, a masked
+ *     solve or B < 4 takes path 7)                                          <0 unsupported */
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
 
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active
@@ -202,7 +206,10 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
  *   outputs: x_out [T,B,nx], u_out [T,B,nu], Ks_out/ks_out (NULL ok), costs [B], old_costs [B]
  *   (NULL ok), alphas [B], objs [T,B] (NULL ok), u_first [T,B,nu] (NULL ok) = the controls of the first
  *   (alpha = 1) line-search pass, from which the reference derives full_du_norm (mpc_step.py:260-263),
- *   n_qp_iter [B] int32 = sum_t (1 + i_t), n_ls_iter [B] int32 = line-search passes run.          */
+ *   n_qp_iter [B] int32 = sum_t (1 + i_t), n_ls_iter [B] int32 = line-search passes run.
+ *   Where both halves have a generated instruction stream ((8,2), (3,1), (4,2), (2,2), (1,1), (2,1), (3,2); B % 4 == 0,
+ *   per-trajectory termination) they run in ONE launch - a wavefront goes from its sweep straight into its line search
+ *   (DMPC_NO_MPC_FUSED=1: two launches, bit-identical results).                                    */
 size_t dmpc_mpc_step_workspace_bytes(int T, int B, int nx, int nu);
 int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, const float *c_hat,
                           const float *F_hat, const float *f_hat, const float *controls, const float *states,

@@ -52,4 +52,4 @@ if __name__ == "__main__":
         for env in ({}, {"DMPC_NO_MPC_FUSED": "1"}, {}, {"DMPC_NO_MPC_FUSED": "1"}):
             e = dict(os.environ); e.update(env)
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=e, capture_output=True, text=True, timeout=300)
-            print("one launch " if not env else "two launches", r.stdout.strip()[-400:], r.stderr.strip()[-300:], flush=True)
+            print("one launch " if not env else "two launches", r.stdout.strip()[-400:], "" if r.returncode == 0 else r.stderr.strip()[-300:], flush=True)
