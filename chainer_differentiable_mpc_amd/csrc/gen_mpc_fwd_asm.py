@@ -38,6 +38,8 @@ X_NO_DMA = os.environ.get("GEN_FWD_NO_DMA") == "1"
 X_NO_LDS = os.environ.get("GEN_FWD_NO_LDS") == "1"
 X_NO_COST = os.environ.get("GEN_FWD_NO_COST") == "1"
 X_NO_ADV = os.environ.get("GEN_FWD_NO_ADV") == "1"
+# later passes fetch only the chunks of the trajectories that still search (round 4; GEN_FWD_ROW_MASK=0: every pass fetches all)
+X_ROW_MASK = os.environ.get("GEN_FWD_ROW_MASK", "1") == "1"
 X_NT = os.environ.get("GEN_FWD_NT") == "1"      # nt cache policy on the input DMAs (measured, not a default: the search re-reads C and F)
 
 
@@ -90,6 +92,9 @@ def gen_fwd(nx, nu):
     S_CAP, S_WOBJ, S_UFW = "s91", "s92", "s93"
     S_XM, S_UM, S_SM, S_SRCH, S_ST, S_W, S_T0, S_ROW0 = ("s[72:73]", "s[74:75]", "s[76:77]", "s[78:79]", "s[80:81]",
                                                          "s[82:83]", "s[84:85]", "s[86:87]")
+    # exec masks of the DMA instructions during a pass (S_W and S_T0 are only used between passes)
+    S_DM = ["s[82:83]", "s[84:85]", "s[96:97]", "s[94:95]"]
+    assert KD <= len(S_DM)
 
     def mask64(lanes):
         m16 = sum(1 << l for l in lanes)
@@ -107,7 +112,13 @@ def gen_fwd(nx, nu):
         for q in range(KD):
             off = (" offset:%d" % (q * 1024)) if q else ""
             if not (X_NO_DMA and in_body[0]):
+                if X_ROW_MASK:   # only the chunks a searching trajectory needs (lane 0 always: the instruction is never empty,
+                    P.raw("s_mov_b64 exec, %s" % S_DM[q])      # the counted waits stay exact)
+                    P.raw("s_nop 0")
                 P.raw("global_load_lds_dwordx4 %s, off%s%s" % (v2(PTR[q]), off, " nt" if X_NT else ""))
+        if X_ROW_MASK and not (X_NO_DMA and in_body[0]):
+            P.raw("s_mov_b64 exec, -1")
+            P.exec_written()
 
     slow = []   # (label, return label): the one advance of a pass that must leave the F / f lanes where they are
 
@@ -269,6 +280,24 @@ def gen_fwd(nx, nu):
     P.raw("s_mov_b64 %s, -1" % S_SRCH)
     # =============================================================== one pass of the line search
     P.label("Lpass_%=")
+    if X_ROW_MASK:
+        # A later pass is run for the trajectories that still search; the others' chunks of the slot are not fetched again
+        # (their lanes compute on whatever the ring holds - finite leftovers - and commit nothing): rb = the searching
+        # rows as four bits, S_DM[q] = the lanes whose chunk of DMA q holds data of a searching row (a chunk can straddle rows)
+        P.raw("s_and_b32 s94, s78, 1")
+        P.raw("s_bfe_u32 s95, s78, 0x10010")
+        P.raw("s_lshl_b32 s95, s95, 1")
+        P.raw("s_or_b32 s94, s94, s95")
+        P.raw("s_and_b32 s95, s79, 1")
+        P.raw("s_lshl_b32 s95, s95, 2")
+        P.raw("s_or_b32 s94, s94, s95")
+        P.raw("s_bfe_u32 s95, s79, 0x10010")
+        P.raw("s_lshl_b32 s95, s95, 3")
+        P.raw("s_or_b32 s94, s94, s95")
+        for q in range(KD):      # (the last one overwrites s[94:95]: rb has been consumed by then)
+            P.v("v_bfe_u32 %s, %%[dmrow], %d, 4" % (T1, 4 * q), writes=(T1,))
+            P.v("v_and_b32_e32 %s, s94, %s" % (T1, T1), writes=(T1,), reads=(T1,))
+            P.v("v_cmp_ne_u32_e64 %s, 0, %s" % (S_DM[q], T1), reads=(T1,))
     for q in range(KD):
         a = int(PTR[q][0][1:])
         P.v("v_mov_b32_e32 v%d, %s" % (a, ptr0[q].replace("]", "_lo]")), writes=("v%d" % a,))
@@ -293,8 +322,8 @@ def gen_fwd(nx, nu):
     # the body of the pass, once per combination of stores (see fstep)
     P.raw("s_cmp_lg_u32 %s, 0" % S_PASS)
     P.raw("s_cselect_b32 %s, 0, %s" % (S_TMP, S_UFW))          # u_first: first pass only, when wanted
-    P.raw("s_lshl_b32 s84, %s, 1" % S_WOBJ)                   # (s84: low half of the S_T0 pair, free here)
-    P.raw("s_or_b32 %s, %s, s84" % (S_TMP, S_TMP))
+    P.raw("s_lshl_b32 vcc_lo, %s, 1" % S_WOBJ)                # (vcc is free here)
+    P.raw("s_or_b32 %s, %s, vcc_lo" % (S_TMP, S_TMP))
     for idx in (1, 2, 3):
         P.raw("s_cmp_eq_u32 %s, %d" % (S_TMP, idx))
         P.raw("s_cbranch_scc1 Lbody%d_%%=" % idx)
@@ -365,11 +394,11 @@ def gen_fwd(nx, nu):
         ins.append((name + "_lo", '"v"((unsigned)in.%s)' % name))
         ins.append((name + "_hi", '"v"((unsigned)(in.%s >> 32))' % name))
     for name in ("a_row", "a_row2", "a_aff", "a_crow", "a_caff", "a_hat", "a_lb", "dst", "dobj", "decay", "cap", "want_objs",
-                 "uf_mask"):
+                 "uf_mask", "dmrow"):
         ins.append((name, '"v"(in.%s)' % name))
     for name in ("ring", "T"):
         ins.append((name, '"s"(in.%s)' % name))
-    clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"s%d"' % i for i in ([70] + list(range(72, 96)))] + \
+    clob = ['"v%d"' % i for i in range(VBASE, last_vgpr + 1)] + ['"s%d"' % i for i in ([70] + list(range(72, 98)))] + \
         ['"vcc"', '"scc"', '"memory"']
     o = []
     o.append("// (%d,%d): %d instructions: set-up, pass prologue and epilogue, four pass bodies of %d unrolled steps\n"
@@ -413,6 +442,8 @@ struct MpcFwdAsmIn {
   int T;
   int cap, want_objs;                 // (VGPR operands, same in every lane)
   unsigned uf_mask;                   // all ones: u_first wanted, 0: not
+  unsigned dmrow;                     // per lane, 4 bits per DMA instruction q (bits 4q..4q+3): the trajectories of the wave whose
+                                      // data this lane's chunk of instruction q holds (all four: always fetched)
 };
 
 template <int NX, int NU>

@@ -61,6 +61,16 @@ __device__ __forceinline__ void mpc_forward_asm_body(const MpcFwdArgs &a, const 
     else if (g < G::CH_hi) { base = (const char *)a.lower; per = (size_t)NU * 4; g0 = G::CH_lo; }
     else if (g < G::CH_x) { base = (const char *)a.upper; per = (size_t)NU * 4; g0 = G::CH_hi; }
     else if (g < G::CH_END) { base = (const char *)a.states; per = (size_t)NX * 4; g0 = G::CH_x; }
+    {  // the trajectories (of the wave's four) whose data this chunk holds: a later line-search pass fetches it only while
+       // one of them still searches.  Padding / absent arrays and lane 0 (the instruction is never empty): always.
+      unsigned rows = 0xfu;
+      if (per != 0 && lane64 != 0) {
+        const unsigned r0 = (unsigned)((size_t)(g - g0) * 16 / per), r1 = (unsigned)(((size_t)(g - g0) * 16 + 15) / per);
+        rows = 0;
+        for (unsigned rr = (r0 < 4 ? r0 : 3); rr <= (r1 < 4 ? r1 : 3); ++rr) rows |= 1u << rr;   // (a chunk of 4-byte rows spans all four)
+      }
+      in.dmrow |= rows << (4 * q);
+    }
     in.ptr0[q] = reinterpret_cast<uint64_t>(base) + (size_t)b0 * per + (size_t)(g - g0) * 16 - (uint64_t)q * 1024u;
     in.str[q] = (uint64_t)(B * per);
     in.strl[q] = isF ? 0 : in.str[q];   // there is no F_{T-1}: the step t = T-1 fetches slice T-2 again (never consumed)
