@@ -308,6 +308,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #else
 #define DMPC_LQR_WIDE_SHAPES(X) X(16, 4) X(16, 8) X(12, 4) X(12, 8)
 #endif
+#define DMPC_LQR_WIDE_CONTAINERS(X) X(12, 4) X(16, 4) X(12, 8) X(16, 8)   /* fewest columns first */
 static bool wide_disabled() {
   static const bool off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
   return off;
@@ -319,10 +320,16 @@ static bool wide_shape(int nx, int nu) {
 #undef X
   return false;
 }
+// ... and, padded by its reads (lqr_wide_kernel<..., PAD>), of every other shape with at most 16 states and 8 controls that has
+// no 16-lane container (nx + nu >= 16): smallest instance first.  Before, all of them took a wavefront per trajectory.
+static bool wide_container_shape(int nx, int nu) {
+  return nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && nx + nu >= 16 && !wide_shape(nx, nu);
+}
 // can the wide kernel take this solve?  (whole wavefronts of four trajectories, a horizon with an F, 32-bit time strides;
-// the gain rows travel through the caller's workspace)
+// the gain rows travel through the caller's workspace, rows of the INSTANCE's width - dmpc_lqr_workspace_bytes allows for it)
 static bool wide_ok(int mode, int nx, int nu, const LqrArgs &a) {
-  return mode == kSolve && wide_shape(nx, nu) && !wide_disabled() && a.mask == nullptr && a.wsK != nullptr && a.B >= 4 &&
+  const bool exact = wide_shape(nx, nu), padded = wide_container_shape(nx, nu) && a.B % 4 == 0 && !container_disabled();
+  return mode == kSolve && (exact || padded) && !wide_disabled() && a.mask == nullptr && a.wsK != nullptr && a.B >= 4 &&
          a.T >= 2 && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
 }
 static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
@@ -339,6 +346,21 @@ static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream)
     return (int)hipGetLastError();                                                                         \
   }
   DMPC_LQR_WIDE_SHAPES(X)
+#undef X
+  LqrArgs p = a;
+  p.nx_log = nx;
+  p.nu_log = nu;
+#define X(NX_, NU_)                                                                                        \
+  if (nx <= NX_ && nu <= NU_) {                                                                            \
+    constexpr int DB = 2, DF = 2;                                                                          \
+    constexpr size_t lds = LqrWideLayout<NX_, NU_, DB, DF>::lds_bytes();                                   \
+    if (lds > 64 * 1024)                                                                                   \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true>),  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, true>), grid, block, lds, stream, p);               \
+    return (int)hipGetLastError();                                                                         \
+  }
+  DMPC_LQR_WIDE_CONTAINERS(X)
 #undef X
   return DMPC_E_UNSUPPORTED;
 }
@@ -501,6 +523,7 @@ int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   DMPC_LQR_SHAPES(X)
 #undef X
   if (wide_shape(nx, nu) && !wide_disabled() && B >= 4 && T >= 2) return 9;   // lqr_wide_kernel (given the workspace)
+  if (wide_container_shape(nx, nu) && !wide_disabled() && !container_disabled() && B >= 4 && B % 4 == 0 && T >= 2) return 9;
   if (lqr_family(nx, nu) == 4 && !container_disabled()) return 7;   // a container kernel (lqr_kernel<..., PAD>)
   if (lqr_family(nx, nu) == 5) return 8;                              // lqr_tiled_kernel: any size
   return (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) ? 0 : DMPC_E_UNSUPPORTED;
@@ -521,6 +544,8 @@ size_t dmpc_lqr_workspace_bytes(int T, int B, int nx, int nu) {
   // only touched when they do not fit in LDS (long horizons) or by the generic kernel
   // (rows of nx + nu + 1 floats for the LDS-DMA HIP kernel's workspace form)
   size_t bytes = (size_t)T * B * nu * (nx + nu + 1 > 12 ? nx + nu + 1 : 12) * sizeof(float);
+  // (a shape padded inside an instance of the wide row kernel: gain rows of the INSTANCE's width - at most 8 rows of 25)
+  if (wide_container_shape(nx, nu)) bytes = (size_t)T * B * 8 * 25 * sizeof(float);
   // the shapes beyond a wavefront's 64 columns (family 5) keep the matrices of every trajectory behind the gains
   if (lqr_family(nx, nu) == 5) bytes = round_up(bytes, 256) + (size_t)B * tiled_scratch_floats(nx, nu) * sizeof(float);
   return bytes;

@@ -102,7 +102,11 @@ __device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][2]) {
   return singular;
 }
 
-template <int NX, int NU, int DB, int DF>
+// PAD: the kernel is a CONTAINER for a smaller problem (a.nx_log <= NX states, a.nu_log <= NU controls; what lqr_kernel<..., PAD>
+// is to the 16-lane shapes): the arrays in HBM keep the problem's own strides and come into the slot as they are; the reads
+// place state i at row / column i and control m at NX + m, everything else of [C|c] and [F|f] is 0 and the unused controls
+// get a unit diagonal in Quu (their gain rows come out exactly 0, LAPACK's pivot choice is unchanged).  Needs B % 4 == 0.
+template <int NX, int NU, int DB, int DF, bool PAD = false>
 __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   using Lay = LqrWideLayout<NX, NU, DB, DF>;
   using Blk = RiccatiBlocksWide<NX, NU>;
@@ -138,6 +142,11 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   const bool aff1 = col1 == NS;                 // ... is the affine column
   const bool real1 = col1 < NS;                 // ... is a column of C / F
   int info_bits = 0;
+  // the problem's own dimensions, and where container row / column c lies in its arrays (-1: padding)
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int c) -> int { return c < NX ? (c < nx ? c : -1) : (c - NX < nu ? nx + (c - NX) : -1); };
+  const int lc0 = PAD ? logical(lane) : lane;                         // this lane's column of C / F: first register
+  const int lc1 = real1 ? (PAD ? logical(col1) : col1) : -1;          // ... second register (when it holds one)
 
   // ------------------------------------------------------------------ backward Riccati sweep
   {
@@ -151,15 +160,17 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
       const int g = q * 64 + lane64;
       const int gg = g < Lay::CH_B ? g : 0;
       const char *base;
-      size_t per;
+      size_t per;          // bytes per trajectory and timestep (PAD: the problem's own)
       int g0;
       bool d = false;
-      if (gg < Lay::OFF_c / 4) { base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = 0; }
-      else if (gg < Lay::OFF_F / 4) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::OFF_c / 4; }
-      else if (gg < Lay::OFF_f / 4) { base = (const char *)(T > 1 ? a.F : a.C); per = (size_t)NX * NS * 4; g0 = Lay::OFF_F / 4; d = true; }
-      else { base = (const char *)(has_f ? a.f : a.c); per = (size_t)NX * 4; g0 = Lay::OFF_f / 4; d = true; }
+      if (gg < Lay::OFF_c / 4) { base = (const char *)a.C; per = (size_t)ns * ns * 4; g0 = 0; }
+      else if (gg < Lay::OFF_F / 4) { base = (const char *)a.c; per = (size_t)ns * 4; g0 = Lay::OFF_c / 4; }
+      else if (gg < Lay::OFF_f / 4) { base = (const char *)(T > 1 ? a.F : a.C); per = (size_t)nx * ns * 4; g0 = Lay::OFF_F / 4; d = true; }
+      else { base = (const char *)(has_f ? a.f : a.c); per = (size_t)nx * 4; g0 = Lay::OFF_f / 4; d = true; }
       const int t0 = d ? (T > 1 ? T - 2 : 0) : T - 1;
-      ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 -
+      // (PAD: every array sits at the start of its container-sized region; the chunks behind its end fetch its chunk 0 again)
+      const int gc = (!PAD || (size_t)(gg - g0) * 16 < 4 * per) ? gg - g0 : 0;
+      ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)gc * 16 -
                (unsigned long long)(q % 4) * 1024u;
       str[q] = (unsigned)(B * per);
       dyn |= d ? (1u << q) : 0u;
@@ -184,22 +195,39 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     };
     // per-lane LDS indices (floats, relative to a slot): the first register reads column `lane`, the second column 16 + lane
     // of C / F - or c / f in the affine column's lane (row stride 1 there), or anything finite past it (never broadcast)
-    const int q0 = Lay::OFF_C + r * NS * NS + lane, f0 = Lay::OFF_F + r * NX * NS + lane;
-    const int q1 = aff1 ? Lay::OFF_c + r * NS : Lay::OFF_C + r * NS * NS + (real1 ? col1 : 0);
-    const int f1 = aff1 ? Lay::OFF_f + r * NX : Lay::OFF_F + r * NX * NS + (real1 ? col1 : 0);
-    const int s1 = aff1 ? 1 : NS;
+    const int q0 = Lay::OFF_C + r * ns * ns + (lc0 >= 0 ? lc0 : 0), f0 = Lay::OFF_F + r * nx * ns + (lc0 >= 0 ? lc0 : 0);
+    const int q1 = aff1 ? Lay::OFF_c + r * ns : Lay::OFF_C + r * ns * ns + (lc1 >= 0 ? lc1 : 0);
+    const int f1 = aff1 ? Lay::OFF_f + r * nx : Lay::OFF_F + r * nx * ns + (lc1 >= 0 ? lc1 : 0);
+    const int s1 = aff1 ? 1 : ns;
+    const bool ok0 = lc0 >= 0, ok1 = aff1 || lc1 >= 0;      // PAD: this lane's columns belong to the problem
     auto read_slot = [&](const float *slot, f4w (&Qn)[NT][2], float (&Fn)[NX][2]) __attribute__((always_inline)) {
       static_for<0, NT>([&](auto I) {
         static_for<0, 4>([&](auto cc) {
           constexpr int i = 4 * I.value + cc.value;
-          Qn[I.value][0][cc.value] = slot[q0 + i * NS];
-          Qn[I.value][1][cc.value] = slot[q1 + i * s1];
+          if constexpr (PAD) {
+            const int li = logical(i);   // uniform
+            const float v0 = slot[q0 + (li >= 0 ? li : 0) * ns], v1 = slot[q1 + (li >= 0 ? li : 0) * s1];
+            // outside the problem: 0, and 1 on the diagonal of the unused controls (column i: lane i % 16 of register i / 16)
+            const float d0 = (i >= NX && i < 16 && lane == i) ? 1.f : 0.f, d1 = (i >= NX && i >= 16 && col1 == i) ? 1.f : 0.f;
+            Qn[I.value][0][cc.value] = (li >= 0 && ok0) ? v0 : (li < 0 ? d0 : 0.f);
+            Qn[I.value][1][cc.value] = (li >= 0 && ok1) ? v1 : (li < 0 ? d1 : 0.f);
+          } else {
+            Qn[I.value][0][cc.value] = slot[q0 + i * NS];
+            Qn[I.value][1][cc.value] = slot[q1 + i * s1];
+          }
         });
       });
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
-        Fn[k][0] = slot[f0 + k * NS];
-        Fn[k][1] = slot[f1 + k * s1];
+        if constexpr (PAD) {
+          const bool row = k < nx;   // uniform
+          const float v0 = slot[f0 + (row ? k : 0) * ns], v1 = slot[f1 + (row ? k : 0) * s1];
+          Fn[k][0] = (row && ok0) ? v0 : 0.f;
+          Fn[k][1] = (row && ok1) ? v1 : 0.f;
+        } else {
+          Fn[k][0] = slot[f0 + k * NS];
+          Fn[k][1] = slot[f1 + k * s1];
+        }
       }
     };
 
@@ -268,13 +296,15 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
           for (int m = 0; m < NU; ++m) row[m * KROW + NS] = Kt[m][1];
         }
         if (a.Ks != nullptr) {
-          if (lane < NX) {
+          if (lane < nx) {
 #pragma unroll
-            for (int m = 0; m < NU; ++m) a.Ks[(tb * NU + m) * NX + lane] = Kt[m][0];
+            for (int m = 0; m < NU; ++m)
+              if (!PAD || m < nu) a.Ks[(tb * nu + m) * nx + lane] = Kt[m][0];
           }
           if (aff1) {
 #pragma unroll
-            for (int m = 0; m < NU; ++m) a.ks[tb * NU + m] = Kt[m][1];
+            for (int m = 0; m < NU; ++m)
+              if (!PAD || m < nu) a.ks[tb * nu + m] = Kt[m][1];
           }
         }
       }
@@ -342,9 +372,10 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
       const bool isk = gg >= (Lay::F_FL + Lay::f_FL) / 4;
       const bool isf = !isk && gg >= Lay::F_FL / 4;
       const char *base = isk ? (const char *)a.wsK : isf ? (const char *)(has_f ? a.f : a.C) : (const char *)(T > 1 ? a.F : a.C);
-      const size_t per = isk ? (size_t)NU * KROW * 4 : isf ? (size_t)NX * 4 : (size_t)NX * NS * 4;
+      const size_t per = isk ? (size_t)NU * KROW * 4 : isf ? (size_t)nx * 4 : (size_t)nx * ns * 4;   // (the gain rows: container layout)
       const int g0 = isk ? (Lay::F_FL + Lay::f_FL) / 4 : isf ? Lay::F_FL / 4 : 0;
-      ptr[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)(gg - g0) * 16 - (unsigned long long)(q % 4) * 1024u;
+      const int gc = (!PAD || (size_t)(gg - g0) * 16 < 4 * per) ? gg - g0 : 0;     // PAD: behind the array's end, its chunk 0 again
+      ptr[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)gc * 16 - (unsigned long long)(q % 4) * 1024u;
       str[q] = (unsigned long long)(B * per);
       kstep[q] = isk;
     }
@@ -368,19 +399,26 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     // lane i < NX owns row i of [F_t | f_t]; lane m < NU ALSO owns row m of the gains [K_t | . | k_t]:
     //     u[m]   = k[m] + sum_j K[m][j] x[j]                        (lanes m < NU; x[j] broadcast from lane j)
     //     x'[i]  = f[i] + sum_j F[i][j] x[j] + sum_m F[i][NX+m] u[m]  (lanes i < NX; u[m] broadcast from lane m)
-    const int lane_x = lane < NX ? lane : NX - 1, lane_u = lane < NU ? lane : NU - 1;
-    const int xrow = r * NX * NS + lane_x * NS, xaff = Lay::F_FL + r * NX + lane_x;
+    const int lane_x = lane < nx ? lane : nx - 1, lane_u = lane < NU ? lane : NU - 1;
+    const int xrow = r * nx * ns + lane_x * ns, xaff = Lay::F_FL + r * nx + lane_x;
     const int urow = Lay::F_FL + Lay::f_FL + (r * NU + lane_u) * KROW;
     auto read_rows = [&](int slot, float (&Fr)[NS + 1], float (&Kr)[NX + 1]) __attribute__((always_inline)) {
       const float *s = ring + slot * Lay::SLOT_F;
-#pragma unroll
-      for (int j = 0; j < NS; ++j) Fr[j] = s[xrow + j];
+      static_for<0, NS>([&](auto j) {
+        if constexpr (PAD) {
+          const int lj = logical(j.value);   // uniform
+          const float v = s[xrow + (lj >= 0 ? lj : 0)];
+          Fr[j.value] = lj >= 0 ? v : 0.f;
+        } else {
+          Fr[j.value] = s[xrow + j.value];
+        }
+      });
       Fr[NS] = s[xaff];
 #pragma unroll
       for (int j = 0; j < NX; ++j) Kr[j] = s[urow + j];
       Kr[NX] = s[urow + NS];
     };
-    float xv = lane < NX ? a.x_init[(size_t)b * NX + lane] : 0.f;
+    float xv = lane < nx ? a.x_init[(size_t)b * nx + lane] : 0.f;
     auto fstep = [&](int t, const float (&Fr)[NS + 1], const float (&Kr)[NX + 1]) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
       float ua = Kr[NX], ub = 0.f;
@@ -390,8 +428,8 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
         else ub = fmaf(xj, Kr[j.value], ub);
       });
       const float uv = ua + ub;
-      if (lane < NX) a.x[tb * NX + lane] = xv;
-      if (lane < NU) a.u[tb * NU + lane] = uv;
+      if (lane < nx) a.x[tb * nx + lane] = xv;
+      if (lane < nu) a.u[tb * nu + lane] = uv;
       float xa = has_f ? Fr[NS] : 0.f, xb = 0.f;   // (for t = T-1 this consumes a re-fetched F_{T-2}: never used)
       static_for<0, NX>([&](auto j) {
         const float xj = G::template bcast<j.value>(xv);
@@ -403,7 +441,7 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
         if constexpr (m.value % 2 == 0) xa = fmaf(um, Fr[NX + m.value], xa);
         else xb = fmaf(um, Fr[NX + m.value], xb);
       });
-      xv = xa + xb;
+      xv = (!PAD || lane < nx) ? xa + xb : 0.f;    // (PAD: the unused state lanes stay an exact 0 - they are broadcast)
     };
     float FA[NS + 1], KA[NX + 1], FB[NS + 1], KB[NX + 1];
     static_for<0, DF>([&](auto j) { issue_next(j.value); });

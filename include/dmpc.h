@@ -71,9 +71,10 @@ int dmpc_lqr_kernel_family(int nx, int nu);
  *   7 a container: lqr_kernel<..., PAD> of a larger shape, or lqr_wave_mfma_backward<..., PAD> + the forward-only
  *     container kernel (needs `ws` unless the caller takes the gains)
  *   8 lqr_tiled_kernel (any size: a workgroup per trajectory, matrices in `ws`)
- *   9 lqr_wide_kernel (17 to 32 augmented columns, at most 16 states - (16,4), (16,8), (12,4), (12,8): four trajectories
- *     per wavefront, two registers per matrix row, outer products on the matrix cores; needs `ws` - without it, a masked
- *     solve or B < 4 takes path 7)                                          <0 unsupported */
+ *   9 lqr_wide_kernel (17 to 32 augmented columns, at most 16 states - (16,4), (16,8), (12,4), (12,8), and padded inside
+ *     them every shape with nx <= 16, nu <= 8, nx + nu >= 16 when B % 4 == 0: four trajectories per wavefront, two
+ *     registers per matrix row, outer products on the matrix cores; needs `ws` - without it, a masked solve or B < 4
+ *     takes path 7)                                                         <0 unsupported */
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
 
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active

@@ -177,7 +177,11 @@ def test_wide_container_shapes_against_oracle(dims):
     assert np.all(npy(u)[act] == 0)
 
 
-@pytest.mark.parametrize("dims", WIDE_ROW_SHAPES, ids=["%dx%d" % d for d in WIDE_ROW_SHAPES])
+# ... and what runs padded inside them (at most 16 states, 8 controls, nx + nu >= 16: no 16-lane container)
+WIDE_ROW_PADDED = [(13, 3), (15, 1), (14, 2), (10, 6), (8, 8), (9, 8), (15, 7), (16, 7), (16, 1), (12, 5), (11, 5)]
+
+
+@pytest.mark.parametrize("dims", WIDE_ROW_SHAPES + WIDE_ROW_PADDED, ids=["%dx%d" % d for d in WIDE_ROW_SHAPES + WIDE_ROW_PADDED])
 def test_wide_row_kernel_against_oracle(dims):
     """17 to 32 augmented columns, at most 16 states: the fused solve on the wide 16-lane row layout (lqr_wide_kernel.hpp; four
     trajectories per wavefront, gain rows through the workspace) - whole and ragged batches, two steps to a horizon that
@@ -185,14 +189,16 @@ def test_wide_row_kernel_against_oracle(dims):
     path these shapes took before (DMPC_NO_WIDE is read once per process, so: the separate sweeps, which never take it)."""
     nx, nu = dims
     lib = _lib.load()
-    for (B, T, with_f, want_gains, seed) in ((64, 13, True, False, 1), (37, 7, False, True, 2), (4, 2, True, True, 3),
-                                            (5, 41, True, False, 4)):
+    padded = dims in WIDE_ROW_PADDED          # (the padded form wants whole wavefronts: B % 4 == 0)
+    inst = dims if not padded else next(c for c in ((12, 4), (16, 4), (12, 8), (16, 8)) if nx <= c[0] and nu <= c[1])
+    for (B, T, with_f, want_gains, seed) in ((64, 13, True, False, 1), (36 if padded else 37, 7, False, True, 2),
+                                            (4, 2, True, True, 3), (8 if padded else 5, 41, True, False, 4)):
         assert lib.dmpc_lqr_solve_path(T, B, nx, nu) == 9
         p = synthetic.make_lqr_problem(B, T, nx, nu, seed=300 + seed + nx, with_f=with_f)
         xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
         d = to_dev(p)
         x, u, Ks, ks = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, want_gains=want_gains)
-        assert _lib.last_kernel_name().startswith("void dmpc::lqr_wide_kernel<%d, %d" % dims)
+        assert _lib.last_kernel_name().startswith("void dmpc::lqr_wide_kernel<%d, %d" % inst)
         assert_close(npy(x), xr, TOL_PRIMAL, "x")
         assert_close(npy(u), ur, TOL_PRIMAL, "u")
         if want_gains:
@@ -203,8 +209,10 @@ def test_wide_row_kernel_against_oracle(dims):
         x2, u2 = rec.forward(*rec.backward())          # the container kernels (the path of rounds 2-4)
         assert_close(npy(x), npy(x2), 2e-5, "x against the separate sweeps")
         assert_close(npy(u), npy(u2), 2e-5, "u against the separate sweeps")
-    # a batch below one wavefront of four trajectories does not take it
+    # a batch below one wavefront of four trajectories does not take it (padded: nor a ragged one)
     assert lib.dmpc_lqr_solve_path(6, 3, nx, nu) == 7
+    if padded:
+        assert lib.dmpc_lqr_solve_path(6, 7, nx, nu) == 7
 
 
 @pytest.mark.parametrize("dims", [(6, 3), (13, 2)])
