@@ -307,6 +307,7 @@ static int launch_lqr(int mode, const LqrArgs &a, hipStream_t stream) {
 #define DMPC_LQR_WIDE_SHAPES(X)
 #else
 #define DMPC_LQR_WIDE_SHAPES(X) X(16, 4) X(16, 8) X(12, 4) X(12, 8)
+/* ((8,4) as a one-register instance of the same kernel - the template takes it - measured 94 us against lqr_kernel's 84: not used) */
 #endif
 #define DMPC_LQR_WIDE_CONTAINERS(X) X(12, 4) X(16, 4) X(12, 8) X(16, 8)   /* fewest columns first */
 static bool wide_disabled() {
@@ -329,8 +330,10 @@ static bool wide_container_shape(int nx, int nu) {
 // the gain rows travel through the caller's workspace, rows of the INSTANCE's width - dmpc_lqr_workspace_bytes allows for it)
 static bool wide_ok(int mode, int nx, int nu, const LqrArgs &a) {
   const bool exact = wide_shape(nx, nu), padded = wide_container_shape(nx, nu) && a.B % 4 == 0 && !container_disabled();
-  return mode == kSolve && (exact || padded) && !wide_disabled() && a.mask == nullptr && a.wsK != nullptr && a.B >= 4 &&
-         a.T >= 2 && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
+  // (the generated streams' own argument forms - c in two arrays, saved gains, x_init = 0 - are not its business)
+  const bool plain = a.c_u == nullptr && a.Ks_in == nullptr && a.Vv_in == nullptr && a.Quu_out == nullptr && a.x_init != nullptr;
+  return mode == kSolve && plain && (exact || padded) && !wide_disabled() && a.mask == nullptr && a.wsK != nullptr &&
+         a.B >= 4 && a.T >= 2 && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
 }
 static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
   const dim3 grid((a.B + 15) / 16), block(256);
@@ -439,6 +442,7 @@ static int launch_lqr_container(int mode, int nx, int nu, const LqrArgs &a0, hip
 }
 
 static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t stream) {
+  if (wide_ok(mode, nx, nu, a)) return launch_lqr_wide(nx, nu, a, stream);
 #define X(NX_, NU_, L_) \
   if (nx == NX_ && nu == NU_) return launch_lqr<NX_, NU_, L_>(mode, a, stream);
   DMPC_LQR_SHAPES(X)
@@ -447,7 +451,6 @@ static int dispatch_lqr(int mode, int nx, int nu, const LqrArgs &a, hipStream_t 
   if (a.c_u != nullptr || a.Ks_in != nullptr || a.Vv_in != nullptr || a.Quu_out != nullptr ||
       (a.x_init == nullptr && a.x != nullptr))
     return DMPC_E_UNSUPPORTED;
-  if (wide_ok(mode, nx, nu, a)) return launch_lqr_wide(nx, nu, a, stream);
   if (lqr_family(nx, nu) == 4 && !container_disabled()) {
 #define X(NX_, NU_) \
   if (nx <= NX_ && nu <= NU_) return launch_lqr_container<NX_, NU_>(mode, nx, nu, a, stream);
@@ -518,11 +521,11 @@ int dmpc_lqr_kernel_family(int nx, int nu) { return lqr_family(nx, nu); }
 
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0) return DMPC_E_BADARG;
+  if (wide_shape(nx, nu) && !wide_disabled() && B >= 4 && T >= 2) return 9;   // lqr_wide_kernel (given the workspace)
 #define X(NX_, NU_, L_) \
   if (nx == NX_ && nu == NU_) return solve_path<NX_, NU_, L_>(T, B);
   DMPC_LQR_SHAPES(X)
 #undef X
-  if (wide_shape(nx, nu) && !wide_disabled() && B >= 4 && T >= 2) return 9;   // lqr_wide_kernel (given the workspace)
   if (wide_container_shape(nx, nu) && !wide_disabled() && !container_disabled() && B >= 4 && B % 4 == 0 && T >= 2) return 9;
   if (lqr_family(nx, nu) == 4 && !container_disabled()) return 7;   // a container kernel (lqr_kernel<..., PAD>)
   if (lqr_family(nx, nu) == 5) return 8;                              // lqr_tiled_kernel: any size

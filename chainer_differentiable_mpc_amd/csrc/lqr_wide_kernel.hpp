@@ -1,6 +1,7 @@
 // lqr_wide_kernel.hpp - the fused LQR solve (LqrRecursion.solve_recursion, lqr/lqr_recursion.py:69-209) for problems whose
 // augmented matrices have 17 to 32 columns (nx <= 16, 16 <= nx + nu <= 31), on the 16-lane row layout with TWO registers per
-// matrix row: register [i][h] of lane j holds M[i][16 h + j].
+// matrix row: register [i][h] of lane j holds M[i][16 h + j].  (The template also takes shapes of the plain 16-lane layout
+// with four-row tiles - NR = 1, one register per row; (8,4) that way: 94 us against lqr_kernel's 84, not instantiated.)
 //
 // A trajectory keeps ONE DPP row of 16 lanes - four trajectories per wavefront - where these shapes used to take a whole
 // wavefront each on the matrix-core kernel of the (32,8) class (inside its (16,8) instance, lqr_wave_mfma.hpp: ~2,000
@@ -50,8 +51,8 @@ struct LqrWideLayout {
 
 // Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie (gauss_jordan_rows of riccati_blocks.hpp, two registers per
 // row): the multiplier of row i at pivot k is column NX + k of it - lane (NX + k) % 16 of register (NX + k) / 16.
-template <int NX, int NU>
-__device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][2]) {
+template <int NX, int NU, int NR>
+__device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][NR]) {
   using G = Group<16>;
   bool singular = false;
   static_for<0, NU>([&](auto kc) {
@@ -74,7 +75,7 @@ __device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][2]) {
       static_for<k + 1, NU>([&](auto ic) {
         const bool sw = pr == ic.value;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NR; ++h) {
           const float rk = Kr[k][h], ri = Kr[ic.value][h];
           Kr[k][h] = sw ? ri : rk;
           Kr[ic.value][h] = sw ? rk : ri;
@@ -86,16 +87,16 @@ __device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][2]) {
     }
     singular = singular || (p == 0.f);
     const float r = fast_rcp(p);
-    Kr[k][0] *= r;
-    Kr[k][1] *= r;
+#pragma unroll
+    for (int h = 0; h < NR; ++h) Kr[k][h] *= r;
     static_for<0, NU>([&](auto ic) {
       constexpr int i = ic.value;
       if constexpr (i != k) {
         float l;
         if constexpr (i > k) l = li[i];
         else l = G::template bcast<kl>(Kr[i][kb]);
-        Kr[i][0] = fmaf(-l, Kr[k][0], Kr[i][0]);
-        Kr[i][1] = fmaf(-l, Kr[k][1], Kr[i][1]);
+#pragma unroll
+        for (int h = 0; h < NR; ++h) Kr[i][h] = fmaf(-l, Kr[k][h], Kr[i][h]);
       }
     });
   });
@@ -112,10 +113,11 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   using Blk = RiccatiBlocksWide<NX, NU>;
   using G = Group<16>;
   constexpr int NS = NX + NU, KROW = NS + 1;
+  constexpr int NR = NS + 1 <= 16 ? 1 : 2;    // registers per matrix row
   constexpr int AB = NS / 16;                 // the affine column lies in register AB (lane NS % 16)
   constexpr int NT = NS / 4;                  // tiles of four rows of Q~
   static_assert(Blk::kAvailable, "no generated blocks for this shape (gen_dpp_blocks_wide.py SHAPES)");
-  static_assert(NX <= 16 && NS >= 16 && NS <= 31, "17 to 32 augmented columns, state columns in the first register");
+  static_assert(NX <= 16 && NS <= 31 && AB < NR, "at most 32 augmented columns, state columns in the first register");
   static_assert(NX % 4 == 0 && NU % 4 == 0, "tiles of four rows");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
   static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
@@ -138,15 +140,21 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   float *kw = a.wsK + (size_t)b * NU * KROW;    // + t * B * NU * KROW: this trajectory's gain rows in the workspace
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
 
-  const int col1 = 16 + lane;                   // this lane's column in the second register
-  const bool aff1 = col1 == NS;                 // ... is the affine column
-  const bool real1 = col1 < NS;                 // ... is a column of C / F
   int info_bits = 0;
   // the problem's own dimensions, and where container row / column c lies in its arrays (-1: padding)
   const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
   auto logical = [&](int c) -> int { return c < NX ? (c < nx ? c : -1) : (c - NX < nu ? nx + (c - NX) : -1); };
-  const int lc0 = PAD ? logical(lane) : lane;                         // this lane's column of C / F: first register
-  const int lc1 = real1 ? (PAD ? logical(col1) : col1) : -1;          // ... second register (when it holds one)
+  // register h of this lane holds column 16 h + lane: a column of C / F (lc[h]: where it lies in the arrays, -1: none), the
+  // affine column, or nothing
+  int lc[NR];
+  bool aff[NR];
+#pragma unroll
+  for (int h = 0; h < NR; ++h) {
+    const int col = 16 * h + lane;
+    aff[h] = col == NS;
+    lc[h] = col < NS ? (PAD ? logical(col) : col) : -1;
+  }
+  const bool affl = aff[AB];                    // this lane holds the affine column (in its register AB)
 
   // ------------------------------------------------------------------ backward Riccati sweep
   {
@@ -195,75 +203,87 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     };
     // per-lane LDS indices (floats, relative to a slot): the first register reads column `lane`, the second column 16 + lane
     // of C / F - or c / f in the affine column's lane (row stride 1 there), or anything finite past it (never broadcast)
-    const int q0 = Lay::OFF_C + r * ns * ns + (lc0 >= 0 ? lc0 : 0), f0 = Lay::OFF_F + r * nx * ns + (lc0 >= 0 ? lc0 : 0);
-    const int q1 = aff1 ? Lay::OFF_c + r * ns : Lay::OFF_C + r * ns * ns + (lc1 >= 0 ? lc1 : 0);
-    const int f1 = aff1 ? Lay::OFF_f + r * nx : Lay::OFF_F + r * nx * ns + (lc1 >= 0 ? lc1 : 0);
-    const int s1 = aff1 ? 1 : ns;
-    const bool ok0 = lc0 >= 0, ok1 = aff1 || lc1 >= 0;      // PAD: this lane's columns belong to the problem
-    auto read_slot = [&](const float *slot, f4w (&Qn)[NT][2], float (&Fn)[NX][2]) __attribute__((always_inline)) {
+    int qb[NR], fb[NR], sh[NR];
+    bool ok[NR];                 // PAD: this lane's column belongs to the problem
+#pragma unroll
+    for (int h = 0; h < NR; ++h) {
+      qb[h] = aff[h] ? Lay::OFF_c + r * ns : Lay::OFF_C + r * ns * ns + (lc[h] >= 0 ? lc[h] : 0);
+      fb[h] = aff[h] ? Lay::OFF_f + r * nx : Lay::OFF_F + r * nx * ns + (lc[h] >= 0 ? lc[h] : 0);
+      sh[h] = aff[h] ? 1 : ns;   // c / f: consecutive entries; a column of C / F: a row apart
+      ok[h] = aff[h] || lc[h] >= 0;
+    }
+    auto read_slot = [&](const float *slot, f4w (&Qn)[NT][NR], float (&Fn)[NX][NR]) __attribute__((always_inline)) {
       static_for<0, NT>([&](auto I) {
         static_for<0, 4>([&](auto cc) {
           constexpr int i = 4 * I.value + cc.value;
+          static_for<0, NR>([&](auto h) {
+            if constexpr (PAD) {
+              const int li = logical(i);   // uniform
+              const float v = slot[qb[h.value] + (li >= 0 ? li : 0) * sh[h.value]];
+              // outside the problem: 0, and 1 on the diagonal of the unused controls (column i: lane i % 16 of register i / 16)
+              const float d = (i >= NX && i / 16 == h.value && lane == i % 16) ? 1.f : 0.f;
+              Qn[I.value][h.value][cc.value] = (li >= 0 && ok[h.value]) ? v : (li < 0 ? d : 0.f);
+            } else {
+              Qn[I.value][h.value][cc.value] = slot[qb[h.value] + i * sh[h.value]];
+            }
+          });
+        });
+      });
+      static_for<0, NX>([&](auto k) {
+        static_for<0, NR>([&](auto h) {
           if constexpr (PAD) {
-            const int li = logical(i);   // uniform
-            const float v0 = slot[q0 + (li >= 0 ? li : 0) * ns], v1 = slot[q1 + (li >= 0 ? li : 0) * s1];
-            // outside the problem: 0, and 1 on the diagonal of the unused controls (column i: lane i % 16 of register i / 16)
-            const float d0 = (i >= NX && i < 16 && lane == i) ? 1.f : 0.f, d1 = (i >= NX && i >= 16 && col1 == i) ? 1.f : 0.f;
-            Qn[I.value][0][cc.value] = (li >= 0 && ok0) ? v0 : (li < 0 ? d0 : 0.f);
-            Qn[I.value][1][cc.value] = (li >= 0 && ok1) ? v1 : (li < 0 ? d1 : 0.f);
+            const bool row = k.value < nx;   // uniform
+            const float v = slot[fb[h.value] + (row ? k.value : 0) * sh[h.value]];
+            Fn[k.value][h.value] = (row && ok[h.value]) ? v : 0.f;
           } else {
-            Qn[I.value][0][cc.value] = slot[q0 + i * NS];
-            Qn[I.value][1][cc.value] = slot[q1 + i * s1];
+            Fn[k.value][h.value] = slot[fb[h.value] + k.value * sh[h.value]];
           }
         });
       });
-#pragma unroll
-      for (int k = 0; k < NX; ++k) {
-        if constexpr (PAD) {
-          const bool row = k < nx;   // uniform
-          const float v0 = slot[f0 + (row ? k : 0) * ns], v1 = slot[f1 + (row ? k : 0) * s1];
-          Fn[k][0] = (row && ok0) ? v0 : 0.f;
-          Fn[k][1] = (row && ok1) ? v1 : 0.f;
-        } else {
-          Fn[k][0] = slot[f0 + k * NS];
-          Fn[k][1] = slot[f1 + k * s1];
-        }
-      }
     };
 
-    float V[NX][2];          // [V | v] of the later step: row i = registers [i][0..1]
+    float V[NX][NR];         // [V | v] of the later step: row i = registers [i][0..NR-1]
 #pragma unroll
-    for (int i = 0; i < NX; ++i) V[i][0] = V[i][1] = 0.f;
-    const float eaff = aff1 ? 1.f : 0.f;     // unit vector of the affine column (in register AB)
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int h = 0; h < NR; ++h) V[i][h] = 0.f;
+    const float eaff = affl ? 1.f : 0.f;     // unit vector of the affine column (in register AB)
 
-    auto step = [&](int t, f4w (&Q4)[NT][2], float (&Fc)[NX][2]) __attribute__((always_inline)) {
+    auto step = [&](int t, f4w (&Q4)[NT][NR], float (&Fc)[NX][NR]) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
       if (t < T - 1) {
         if (!has_f) {
 #pragma unroll
-          for (int k = 0; k < NX; ++k) Fc[k][1] = aff1 ? 0.f : Fc[k][1];
+          for (int k = 0; k < NX; ++k) Fc[k][AB] = affl ? 0.f : Fc[k][AB];
         }
         // Q~ += F~^T V^ F~ + [0 | F~^T v] as (V^T F~)^T F~ - two chains of outer products (lqr_recursion.py:89,96):
         //   G[b][j] = sum_a V[a][b] F~[a][j]        rows b = the state columns of V: tiles of 4, A = V[a] lanes 4I..4I+3
         //   g1[j]   = sum_a v[a] F~[a][j]           (broadcast-FMAs: v[a] is one lane of V[a])
         //   Q~[i][j] += sum_b G[b][i] F~[b][j]  and  Q~[i][aff] += g1[i]
-        f4w G4[NX / 4][2];
-        static_for<0, NX / 4>([&](auto I) { G4[I.value][0] = G4[I.value][1] = f4w{0.f, 0.f, 0.f, 0.f}; });
+        f4w G4[NX / 4][NR];
+        static_for<0, NX / 4>([&](auto I) {
+          static_for<0, NR>([&](auto h) { G4[I.value][h.value] = f4w{0.f, 0.f, 0.f, 0.f}; });
+        });
         static_for<0, NX>([&](auto a_) {
           static_for<0, NX / 4>([&](auto I) {
-            G4[I.value][0] = mfma_rows<I.value>(V[a_.value][0], Fc[a_.value][0], G4[I.value][0]);
-            G4[I.value][1] = mfma_rows<I.value>(V[a_.value][0], Fc[a_.value][1], G4[I.value][1]);
+            static_for<0, NR>([&](auto h) {
+              G4[I.value][h.value] = mfma_rows<I.value>(V[a_.value][0], Fc[a_.value][h.value], G4[I.value][h.value]);
+            });
           });
         });
-        float ga[2] = {0.f, 0.f}, gb[2] = {0.f, 0.f};
+        float ga[NR], gb[NR], g1[NR];
+#pragma unroll
+        for (int h = 0; h < NR; ++h) ga[h] = gb[h] = 0.f;
         Blk::g1(ga, gb, V, Fc);
-        const float g1[2] = {ga[0] + gb[0], ga[1] + gb[1]};
+#pragma unroll
+        for (int h = 0; h < NR; ++h) g1[h] = ga[h] + gb[h];
         static_for<0, NX>([&](auto b_) {
           static_for<0, NT>([&](auto I) {
             constexpr int ib = (4 * I.value) / 16, il = ((4 * I.value) % 16) / 4;   // rows 4I..: register ib, lanes 4 il..
             const float gcol = G4[b_.value / 4][ib][b_.value % 4];                   // row b of G, the register with columns 4I..
-            Q4[I.value][0] = mfma_rows<il>(gcol, Fc[b_.value][0], Q4[I.value][0]);
-            Q4[I.value][1] = mfma_rows<il>(gcol, Fc[b_.value][1], Q4[I.value][1]);
+            static_for<0, NR>([&](auto h) {
+              Q4[I.value][h.value] = mfma_rows<il>(gcol, Fc[b_.value][h.value], Q4[I.value][h.value]);
+            });
           });
         });
         static_for<0, NT>([&](auto I) {
@@ -272,18 +292,16 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
         });
       }
       // K~ = -Quu^-1 [Qux | Quu | qu] on the rows (:112-120)
-      float Qu[NU][2], Kt[NU][2], R[NU][2];
+      float Qu[NU][NR], Kt[NU][NR], R[NU][NR];
       static_for<0, NU>([&](auto m) {
         constexpr int i = NX + m.value;
-        Qu[m.value][0] = Kt[m.value][0] = Q4[i / 4][0][i % 4];
-        Qu[m.value][1] = Kt[m.value][1] = Q4[i / 4][1][i % 4];
+        static_for<0, NR>([&](auto h) { Qu[m.value][h.value] = Kt[m.value][h.value] = Q4[i / 4][h.value][i % 4]; });
       });
-      if (gauss_jordan_rows_wide<NX, NU>(Kt)) info_bits |= 1;
+      if (gauss_jordan_rows_wide<NX, NU, NR>(Kt)) info_bits |= 1;
 #pragma unroll
-      for (int m = 0; m < NU; ++m) {
-        Kt[m][0] = -Kt[m][0];
-        Kt[m][1] = -Kt[m][1];
-      }
+      for (int m = 0; m < NU; ++m)
+#pragma unroll
+        for (int h = 0; h < NR; ++h) Kt[m][h] = -Kt[m][h];
       // gain rows [K_m | 0 | k_m] to the workspace (the rollout reads them like rows of F), and to the caller
       {
         float *row = kw + (size_t)t * B * (NU * KROW);
@@ -291,9 +309,9 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
 #pragma unroll
           for (int m = 0; m < NU; ++m) row[m * KROW + lane] = Kt[m][0];
         }
-        if (aff1) {
+        if (affl) {
 #pragma unroll
-          for (int m = 0; m < NU; ++m) row[m * KROW + NS] = Kt[m][1];
+          for (int m = 0; m < NU; ++m) row[m * KROW + NS] = Kt[m][AB];
         }
         if (a.Ks != nullptr) {
           if (lane < nx) {
@@ -301,37 +319,36 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
             for (int m = 0; m < NU; ++m)
               if (!PAD || m < nu) a.Ks[(tb * nu + m) * nx + lane] = Kt[m][0];
           }
-          if (aff1) {
+          if (affl) {
 #pragma unroll
             for (int m = 0; m < NU; ++m)
-              if (!PAD || m < nu) a.ks[tb * nu + m] = Kt[m][1];
+              if (!PAD || m < nu) a.ks[tb * nu + m] = Kt[m][AB];
           }
         }
       }
       if (t > 0) {  // V = Q~x. + Qxu K~ + K~^T (Q~u. + Quu K~), :151-152
 #pragma unroll
-        for (int m = 0; m < NU; ++m) {
-          R[m][0] = Qu[m][0];
-          R[m][1] = Qu[m][1];
-        }
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+          for (int h = 0; h < NR; ++h) R[m][h] = Qu[m][h];
         Blk::rk(R, Qu, Kt);
-        f4w V4[NX / 4][2];
+        f4w V4[NX / 4][NR];
         static_for<0, NX / 4>([&](auto I) {
-          V4[I.value][0] = Q4[I.value][0];
-          V4[I.value][1] = Q4[I.value][1];
+          static_for<0, NR>([&](auto h) { V4[I.value][h.value] = Q4[I.value][h.value]; });
         });
         static_for<0, NU>([&](auto m) {            // K~^T R: A = K~[m] lanes 4I..4I+3 (the state columns: first register)
           static_for<0, NX / 4>([&](auto I) {
-            V4[I.value][0] = mfma_rows<I.value>(Kt[m.value][0], R[m.value][0], V4[I.value][0]);
-            V4[I.value][1] = mfma_rows<I.value>(Kt[m.value][0], R[m.value][1], V4[I.value][1]);
+            static_for<0, NR>([&](auto h) {
+              V4[I.value][h.value] = mfma_rows<I.value>(Kt[m.value][0], R[m.value][h.value], V4[I.value][h.value]);
+            });
           });
         });
-        float Qx[NX][2];
+        float Qx[NX][NR];
         static_for<0, NX>([&](auto i) {
-          V[i.value][0] = V4[i.value / 4][0][i.value % 4];
-          V[i.value][1] = V4[i.value / 4][1][i.value % 4];
-          Qx[i.value][0] = Q4[i.value / 4][0][i.value % 4];
-          Qx[i.value][1] = Q4[i.value / 4][1][i.value % 4];
+          static_for<0, NR>([&](auto h) {
+            V[i.value][h.value] = V4[i.value / 4][h.value][i.value % 4];
+            Qx[i.value][h.value] = Q4[i.value / 4][h.value][i.value % 4];
+          });
         });
         Blk::vq(V, Qx, Kt);                         // + Qxu K~
       }
@@ -341,8 +358,8 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     // once the reads are in - refilled with step t - DB, and the step is computed while DB - 1 fetches are in flight.  The
     // gain-row stores of a step are younger than its refill and retire in order with it (one counter): the counted wait
     // allows for the 2 NU a step always issues.
-    f4w Q[NT][2];
-    float Fc[NX][2];
+    f4w Q[NT][NR];
+    float Fc[NX][NR];
     static_for<0, DB>([&](auto j) { issue_next(j.value); });
     for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
       static_for<0, DB>([&](auto j) {
