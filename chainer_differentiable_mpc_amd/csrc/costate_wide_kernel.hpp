@@ -1,0 +1,228 @@
+// costate_wide_kernel.hpp - the co-state / outer-product kernel (costate_dma_kernel.hpp; DiffLqr.backward,
+// lqr/differentiable_lqr.py:85-134, and MPCstep.backward, mpc/mpc_step.py:383-446) for problems with 17 to 31 elements of
+// tau = [x; u] (nx <= 16): the shapes of lqr_wide_kernel.hpp, which used to take a wavefront per trajectory inside the
+// (16,8) instance of costate_kernel (0.78 ms of the 1.0 ms gradient at (16,4), B = 4096, T = 50).
+//
+// A trajectory keeps ONE DPP row of 16 lanes, four trajectories per wavefront:
+//   lane j        : tau_t[j], dtau_t[j] in register 0 and tau_t[16 + j], dtau_t[16 + j] in register 1
+//   lane i < NX   : row i of C_t[:nx, :], c_t[i], r_t[i], column i of F_t[:, :nx], lambda[i], d_lambda[i]
+//   lambda_t[i]   = c_t[i] + sum_j C_t[i][j] tau_t[j] + sum_k F_t[k][i] lambda_{t+1}[k]           (and d_lambda likewise)
+//   dF_t row k (lane k < NX), dC_t rows i and 16 + i (lane i, two passes): broadcast-multiplies, staged through LDS and stored
+//   as the contiguous run of HBM the wave's four trajectories make (whole 16-byte chunks, 64 lanes wide).
+// Inputs by per-lane gather DMA into a two-slot LDS ring and ONE register set (lqr_wide_kernel.hpp's pipeline).  The kernel
+// moves 6.1 KB per timestep and trajectory at (16,4) for ~600 instructions per FOUR trajectories: it is bound by the memory
+// system, so the products are plain `Group<16>::bcast` code (no generated blocks).  Needs B >= 4, 16-byte aligned arrays;
+// the tiled-cost sums (dC_sum) are not formed here.
+#pragma once
+#include "costate_dma_kernel.hpp"
+
+namespace dmpc {
+
+template <int NX, int NU, int DB>
+struct CostateWideLayout {
+  static constexpr int NS = NX + NU;
+  // 16-byte chunks of one wave-step (four trajectories): [C state rows | c | r | F | x | u | dx | du]
+  static constexpr int nC = NX * NS, nc = NS, nF = NX * NS;
+  static constexpr int CH_C = 0, CH_c = CH_C + nC, CH_r = CH_c + nc, CH_F = CH_r + nc, CH_x = CH_F + nF;
+  static constexpr int CH_u = CH_x + NX, CH_dx = CH_u + NU, CH_du = CH_dx + NX, CH_END = CH_du + NU;
+  static constexpr int OFF_C = CH_C * 4, OFF_c = CH_c * 4, OFF_r = CH_r * 4, OFF_F = CH_F * 4, OFF_x = CH_x * 4;
+  static constexpr int OFF_u = CH_u * 4, OFF_dx = CH_dx * 4, OFF_du = CH_du * 4;   // in floats
+  static constexpr int kDma = (CH_END + 63) / 64;
+  static constexpr int SLOT = kDma * 256;           // floats per wave and timestep (whole 1 KB pieces)
+  static constexpr int SCR = 4 * NS * NS;           // output staging, floats per wave: dF rows, then dC rows (one buffer)
+  static constexpr size_t lds_bytes() { return (size_t)4 * (DB * SLOT + SCR) * 4; }
+  static_assert((NX * NS) % 4 == 0, "a trajectory's state rows of C are whole 16-byte chunks");
+};
+
+template <int NX, int NU, int DB>
+__global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) {
+  using Lay = CostateWideLayout<NX, NU, DB>;
+  using G = Group<16>;
+  constexpr int NS = NX + NU, N1 = NS - 16;      // elements of tau in the second register
+  static_assert(NX <= 16 && NS > 16 && NS <= 31, "tau in two registers, the state rows in the first");
+  static_assert((DB - 1) * Lay::kDma <= 63, "ring too deep for vmcnt");
+
+  const int T = a.T;
+  const size_t B = (size_t)a.B;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane64 = threadIdx.x & 63;
+  const int r = lane64 >> 4;  // trajectory within the wave
+  const int lane = lane64 & 15;
+  int b0 = ((int)blockIdx.x * 4 + wave) * 4;
+  if (b0 > a.B - 4) b0 = a.B - 4;  // the last wave overlaps its neighbour instead of running ragged (same results twice)
+  b0 = __builtin_amdgcn_readfirstlane(b0);
+  const int b = b0 + r;
+
+  extern __shared__ float lds[];
+  float *ring = lds + wave * (DB * Lay::SLOT);
+  float *scr = lds + 4 * (DB * Lay::SLOT) + wave * Lay::SCR;
+  const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+
+  const int rc = a.r_cols ? a.r_cols : NS;   // row length of a.r
+  const bool is_x = lane < NX;
+  const bool is_t1 = lane < N1;              // this lane holds an element of tau in its second register
+  const int lane_x = is_x ? lane : NX - 1;   // clamped: rows / columns re-read by the idle lanes, never used
+  const float wa = 0.5f, wb = a.dC_mode == 0 ? 1.0f : 0.5f;
+
+  // per-lane source pointers of the gather groups (costate_dma_kernel.hpp; 32-bit time strides: the launcher checks them)
+  unsigned long long ptr[Lay::kDma];
+  unsigned str[Lay::kDma], dyn = 0;
+#pragma unroll
+  for (int q = 0; q < Lay::kDma; ++q) {
+    const int g = q * 64 + lane64;
+    const int gg = g >= Lay::CH_END ? 0 : g;
+    const char *base;
+    size_t per;
+    int g0;
+    bool isF = false;
+    size_t skip = 0;   // C, state rows only: trajectory k of the wave starts k * (ns - nx) * ns floats further on
+    if (gg < Lay::CH_c) {
+      base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = Lay::CH_C;
+      skip = (size_t)(gg / (NX * NS / 4)) * ((NS - NX) * NS * 4);
+    }
+    else if (gg < Lay::CH_r) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::CH_c; }
+    else if (gg < Lay::CH_F) {   // r: rows of r_cols floats - the chunks past the wave's 4 rows repeat its chunk 0
+      base = (const char *)a.r; per = (size_t)rc * 4; g0 = gg - Lay::CH_r < rc ? Lay::CH_r : gg;
+    }
+    else if (gg < Lay::CH_x) { base = (const char *)a.F; per = (size_t)NX * NS * 4; g0 = Lay::CH_F; isF = true; }
+    else if (gg < Lay::CH_u) { base = (const char *)a.x; per = (size_t)NX * 4; g0 = Lay::CH_x; }
+    else if (gg < Lay::CH_dx) { base = (const char *)a.u; per = (size_t)NU * 4; g0 = Lay::CH_u; }
+    else if (gg < Lay::CH_du) { base = (const char *)a.dx; per = (size_t)NX * 4; g0 = Lay::CH_dx; }
+    else { base = (const char *)a.du; per = (size_t)NU * 4; g0 = Lay::CH_du; }
+    const int t0 = isF ? T - 2 : T - 1;
+    ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 + skip -
+             (unsigned long long)(q % 4) * 1024u;
+    str[q] = (unsigned)(B * per);
+    dyn |= isF ? (1u << q) : 0u;
+  }
+  int ti = T - 1;  // timesteps still to step back over
+  auto issue_next = [&](int slot) __attribute__((always_inline)) {
+    const unsigned dst = ring_addr + (unsigned)slot * (Lay::SLOT * 4);
+    static_for<0, Lay::kDma>([&](auto q) {
+      if constexpr (q.value % 4 == 0) set_m0(dst + (unsigned)q.value * 1024u);
+      dma16_gather<(q.value % 4) * 1024>(ptr[q.value]);
+    });
+    if (ti > 0) {  // past t = 0 the same blocks are fetched again (never consumed): the count per step stays exact
+      if (ti == T - 1) {   // F has no slice T-1: its lanes start at T-2 and sit out the first step
+#pragma unroll
+        for (int q = 0; q < Lay::kDma; ++q) ptr[q] -= ((dyn >> q) & 1u) ? 0ull : (unsigned long long)str[q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < Lay::kDma; ++q) ptr[q] -= (unsigned long long)str[q];
+      }
+      --ti;
+    }
+  };
+  // per-lane LDS indices (floats, relative to a slot), computed once
+  const int i_tau0 = lane < NX ? Lay::OFF_x + r * NX + lane : Lay::OFF_u + r * NU + (lane - NX);          // element `lane`
+  const int i_dtau0 = lane < NX ? Lay::OFF_dx + r * NX + lane : Lay::OFF_du + r * NU + (lane - NX);
+  const int e1 = is_t1 ? 16 + lane : NS - 1;                                                                  // element 16 + lane
+  const int i_tau1 = e1 < NX ? Lay::OFF_x + r * NX + e1 : Lay::OFF_u + r * NU + (e1 - NX);
+  const int i_dtau1 = e1 < NX ? Lay::OFF_dx + r * NX + e1 : Lay::OFF_du + r * NU + (e1 - NX);
+  const int i_crow = Lay::OFF_C + (r * NX + lane_x) * NS;   // row lane_x of C_t (state rows only in the slot)
+  const int i_c = Lay::OFF_c + r * NS + lane_x, i_r = Lay::OFF_r + r * rc + lane_x;
+  const int i_fcol = Lay::OFF_F + r * NX * NS + lane_x;     // column lane_x of F_t[:, :NX]
+
+  float tau[2], dtau[2], ci, ri, Crow[NS], Fcol[NX];
+  auto read_slot = [&](const float *slot) __attribute__((always_inline)) {
+    tau[0] = slot[i_tau0];
+    dtau[0] = slot[i_dtau0];
+    tau[1] = slot[i_tau1];
+    dtau[1] = slot[i_dtau1];
+    ci = slot[i_c];
+    ri = slot[i_r];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) Crow[j] = slot[i_crow + j];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) Fcol[k] = slot[i_fcol + k * NS];
+  };
+  // row[j] = tau[j] * ca + dtau[j] * cb, j < NS (the elements of tau broadcast from their lanes)
+  auto outer2 = [&](float (&row)[NS], const float ca, const float cb) __attribute__((always_inline)) {
+    static_for<0, NS>([&](auto j) {
+      constexpr int h = j.value / 16, l = j.value % 16;
+      row[j.value] = fmaf(G::template bcast<l>(dtau[h]), cb, G::template bcast<l>(tau[h]) * ca);
+    });
+  };
+
+  float lam = 0.f, dlam = 0.f;  // lambda_{t+1}[lane], d_lambda_{t+1}[lane]  (lanes < NX)
+  auto step = [&](int t) __attribute__((always_inline)) {
+    const size_t tb = (size_t)t * B + b;
+    if (t < T - 1) {                                                          // differentiable_lqr.py:130-133
+      if (a.dF != nullptr) {   // dF_t[k][:] = d_lambda_{t+1}[k] tau + lambda_{t+1}[k] dtau
+        float row[NS];
+        outer2(row, a.out_sign * dlam, a.out_sign * lam);
+        if (is_x) {
+#pragma unroll
+          for (int j = 0; j < NS; ++j) scr[(r * NX + lane) * NS + j] = row[j];
+        }
+        store_chunks<NX * NS>(scr, a.dF + ((size_t)t * B + b0) * (NX * NS), lane64);
+      }
+      if (a.df != nullptr && a.df_shift == 1 && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+    }
+    if (a.dC != nullptr) {                                                    // :128-129: rows `lane` and 16 + lane
+      float row[NS];
+      outer2(row, a.out_sign * wa * dtau[0], a.out_sign * wb * tau[0]);
+#pragma unroll
+      for (int j = 0; j < NS; ++j) scr[(r * NS + lane) * NS + j] = row[j];
+      outer2(row, a.out_sign * wa * dtau[1], a.out_sign * wb * tau[1]);
+      if (is_t1) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) scr[(r * NS + 16 + lane) * NS + j] = row[j];
+      }
+      store_chunks<NS * NS>(scr, a.dC + ((size_t)t * B + b0) * (NS * NS), lane64);
+    }
+    if (a.dc != nullptr) {
+      a.dc[tb * NS + lane] = a.out_sign * dtau[0];
+      if (is_t1) a.dc[tb * NS + 16 + lane] = a.out_sign * dtau[1];
+    }
+    float nl = ci, ndl = a.r_sign * ri;                                       // :92,102 / :115,124
+    float nl2 = 0.f, ndl2 = 0.f;                                              // (two chains each)
+    static_for<0, NS>([&](auto j) {
+      constexpr int h = j.value / 16, l = j.value % 16;
+      const float tj = G::template bcast<l>(tau[h]), dj = G::template bcast<l>(dtau[h]);
+      if constexpr (j.value % 2 == 0) {
+        nl = fmaf(tj, Crow[j.value], nl);
+        ndl = fmaf(dj, Crow[j.value], ndl);
+      } else {
+        nl2 = fmaf(tj, Crow[j.value], nl2);
+        ndl2 = fmaf(dj, Crow[j.value], ndl2);
+      }
+    });
+    if (t < T - 1) {
+      static_for<0, NX>([&](auto k) {
+        const float lk = G::template bcast<k.value>(lam), dk = G::template bcast<k.value>(dlam);
+        if constexpr (k.value % 2 == 0) {
+          nl = fmaf(lk, Fcol[k.value], nl);
+          ndl = fmaf(dk, Fcol[k.value], ndl);
+        } else {
+          nl2 = fmaf(lk, Fcol[k.value], nl2);
+          ndl2 = fmaf(dk, Fcol[k.value], ndl2);
+        }
+      });
+    }
+    lam = nl + nl2;
+    dlam = ndl + ndl2;
+    if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+  };
+
+  // ONE register set (lqr_wide_kernel.hpp): the slot of step t is waited for and read, then - once the reads are in -
+  // refilled with step t - DB, and the step runs while DB - 1 fetches are in flight.  The stores of a step are younger than
+  // its refill: waiting for all but kDma operations is exact for the first step and conservative afterwards.
+  static_for<0, DB>([&](auto j) { issue_next(j.value); });
+  for (int t0 = T - 1; t0 >= 0; t0 -= DB) {
+    static_for<0, DB>([&](auto j) {
+      const int t = t0 - j.value;
+      if (t >= 0) {
+        wait_vmcnt<(DB - 1) * Lay::kDma>();
+        read_slot(ring + j.value * Lay::SLOT);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads are in before it is refilled
+        issue_next(j.value);
+        step(t);
+      }
+    });
+  }
+  wait_vmcnt<0>();
+  if (a.dx0 != nullptr && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
+}
+
+}  // namespace dmpc

@@ -9,6 +9,7 @@
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
 #include "costate_dma_kernel.hpp"
+#include "costate_wide_kernel.hpp"
 #include "costate_kernels.hpp"
 
 namespace dmpc {
@@ -39,8 +40,10 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
 #ifdef DMPC_EXPERIMENT_ONLY_8_2
 #define DMPC_COSTATE_CONTAINERS(X)
 #define DMPC_COSTATE_WAVE_CONTAINERS(X)
+#define DMPC_COSTATE_WIDE_SHAPES(X)
 #else
 #define DMPC_COSTATE_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)
+#define DMPC_COSTATE_WIDE_SHAPES(X) X(16, 4) X(16, 8) X(12, 8)   /* (12,4): 16 elements of tau - the 16-lane kernels' size, no instance yet */
 #define DMPC_COSTATE_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(5, 5) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
 #endif
 
@@ -78,6 +81,26 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
   DMPC_COSTATE_SHAPES(X)
 #undef X
+  // 17 to 31 elements of tau, at most 16 states: four trajectories per wavefront with tau in two registers
+  // (costate_wide_kernel.hpp; before, a wavefront per trajectory inside the (16,8) container).  DMPC_NO_WIDE=1: that path.
+  {
+    static const bool off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
+    if (!off && a.dC_sum == nullptr && a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled() &&
+        (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31)) {
+#define X(NX_, NU_)                                                                                            \
+  if (nx == NX_ && nu == NU_) {                                                                                \
+    using Lay = CostateWideLayout<NX_, NU_, 2>;                                                                \
+    static_assert(Lay::lds_bytes() <= 160 * 1024, "ring and staging beyond a CU's LDS");                      \
+    if (Lay::lds_bytes() > 64 * 1024)                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_wide_kernel<NX_, NU_, 2>),             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+    DMPC_LAUNCH_GGL((costate_wide_kernel<NX_, NU_, 2>), dim3((a.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, a); \
+    return (int)hipGetLastError();                                                                             \
+  }
+      DMPC_COSTATE_WIDE_SHAPES(X)
+#undef X
+    }
+  }
   {   // a problem without a specialisation padded inside the first container that holds it (the lists of lqr_api.hip)
     static const bool off = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
     if (!off && a.dC_sum == nullptr) {

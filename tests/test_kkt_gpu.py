@@ -78,6 +78,30 @@ def test_container_shapes_against_oracle(dims, strict):
         assert_close(npy(got), want, TOLS[key], key)
 
 
+@pytest.mark.parametrize("dims", [(16, 4), (16, 8), (12, 8)], ids=lambda d: "%dx%d" % d)
+@pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
+def test_wide_costate_kernel_against_oracle(dims, strict):
+    """17 to 31 elements of tau, at most 16 states: the gradient's second solve on lqr_wide_kernel and its co-state sweep on
+    costate_wide_kernel (four trajectories per wavefront, tau in two registers) - whole batches (a ragged one takes the
+    wavefront-per-trajectory container: compared with it too), short and ring-wrapping horizons."""
+    from chainer_differentiable_mpc_amd import _lib
+    nx, nu = dims
+    for (B, T, seed) in ((8, 6, 1), (36, 2, 2), (4, 23, 3)):
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=60 + nx + seed)
+        rng = np.random.RandomState(nx * 19 + nu + seed)
+        gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+        gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+        xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+        ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu, strict_math=strict)
+        d = to_dev(p)
+        node = DiffLqr(T, B, nx, nu, strict_math=strict)
+        node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+        out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+        assert _lib.last_kernel_name().startswith("void dmpc::costate_wide_kernel<%d, %d" % dims)
+        for got, want, key in zip(out, ref, KEYS):
+            assert_close(npy(got), want, TOLS[key], key)
+
+
 def test_autograd_through_lqrnet_reproduces_the_notebook_anchor():
     """examples/LQRnet.ipynb:184 - loss 0.661925 at iteration 0, dynamics mse 4.774785 after the first
     RMSprop step - with forward AND backward on the HIP path, driven by torch.autograd."""
