@@ -18,11 +18,15 @@
 
 namespace dmpc {
 
-template <int NX, int NU, int DB>
+// PAD: the kernel is a CONTAINER for a smaller problem (a.nx_log <= NX, a.nu_log <= NU; lqr_wide_kernel<..., PAD>): the arrays
+// come into container-sized regions of the slot as they are (all of C: its state rows are whole chunks only by chance), the
+// reads place element i of tau at lane i (state) or NX + m (control), everything outside the problem is 0, and the output
+// rows are staged at the problem's own strides.  Needs B % 4 == 0.
+template <int NX, int NU, int DB, bool PAD = false>
 struct CostateWideLayout {
   static constexpr int NS = NX + NU;
-  // 16-byte chunks of one wave-step (four trajectories): [C state rows | c | r | F | x | u | dx | du]
-  static constexpr int nC = NX * NS, nc = NS, nF = NX * NS;
+  // 16-byte chunks of one wave-step (four trajectories): [C state rows (PAD: all rows) | c | r | F | x | u | dx | du]
+  static constexpr int nC = (PAD ? NS : NX) * NS, nc = NS, nF = NX * NS;
   static constexpr int CH_C = 0, CH_c = CH_C + nC, CH_r = CH_c + nc, CH_F = CH_r + nc, CH_x = CH_F + nF;
   static constexpr int CH_u = CH_x + NX, CH_dx = CH_u + NU, CH_du = CH_dx + NX, CH_END = CH_du + NU;
   static constexpr int OFF_C = CH_C * 4, OFF_c = CH_c * 4, OFF_r = CH_r * 4, OFF_F = CH_F * 4, OFF_x = CH_x * 4;
@@ -34,9 +38,9 @@ struct CostateWideLayout {
   static_assert((NX * NS) % 4 == 0, "a trajectory's state rows of C are whole 16-byte chunks");
 };
 
-template <int NX, int NU, int DB>
+template <int NX, int NU, int DB, bool PAD = false>
 __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) {
-  using Lay = CostateWideLayout<NX, NU, DB>;
+  using Lay = CostateWideLayout<NX, NU, DB, PAD>;
   using G = Group<16>;
   constexpr int NS = NX + NU, N1 = NS - 16;      // elements of tau in the second register
   static_assert(NX <= 16 && NS > 16 && NS <= 31, "tau in two registers, the state rows in the first");
@@ -58,10 +62,13 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
   float *scr = lds + 4 * (DB * Lay::SLOT) + wave * Lay::SCR;
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
 
-  const int rc = a.r_cols ? a.r_cols : NS;   // row length of a.r
-  const bool is_x = lane < NX;
+  // the problem's own dimensions, and where container element e of tau lies in them (-1: padding)
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int e) -> int { return e < NX ? (e < nx ? e : -1) : (e - NX < nu ? nx + (e - NX) : -1); };
+  const int rc = a.r_cols ? a.r_cols : ns;   // row length of a.r
+  const bool is_x = lane < nx;
   const bool is_t1 = lane < N1;              // this lane holds an element of tau in its second register
-  const int lane_x = is_x ? lane : NX - 1;   // clamped: rows / columns re-read by the idle lanes, never used
+  const int lane_x = is_x ? lane : nx - 1;   // clamped: rows / columns re-read by the idle lanes, never used
   const float wa = 0.5f, wb = a.dC_mode == 0 ? 1.0f : 0.5f;
 
   // per-lane source pointers of the gather groups (costate_dma_kernel.hpp; 32-bit time strides: the launcher checks them)
@@ -76,21 +83,22 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     int g0;
     bool isF = false;
     size_t skip = 0;   // C, state rows only: trajectory k of the wave starts k * (ns - nx) * ns floats further on
+    size_t run;          // bytes of the wave's run of this array in the slot (PAD: what lies behind fetches chunk 0 again)
     if (gg < Lay::CH_c) {
-      base = (const char *)a.C; per = (size_t)NS * NS * 4; g0 = Lay::CH_C;
-      skip = (size_t)(gg / (NX * NS / 4)) * ((NS - NX) * NS * 4);
+      base = (const char *)a.C; per = (size_t)ns * ns * 4; g0 = Lay::CH_C; run = 4 * per;
+      if constexpr (!PAD) skip = (size_t)(gg / (NX * NS / 4)) * ((NS - NX) * NS * 4);
     }
-    else if (gg < Lay::CH_r) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::CH_c; }
-    else if (gg < Lay::CH_F) {   // r: rows of r_cols floats - the chunks past the wave's 4 rows repeat its chunk 0
-      base = (const char *)a.r; per = (size_t)rc * 4; g0 = gg - Lay::CH_r < rc ? Lay::CH_r : gg;
-    }
-    else if (gg < Lay::CH_x) { base = (const char *)a.F; per = (size_t)NX * NS * 4; g0 = Lay::CH_F; isF = true; }
-    else if (gg < Lay::CH_u) { base = (const char *)a.x; per = (size_t)NX * 4; g0 = Lay::CH_x; }
-    else if (gg < Lay::CH_dx) { base = (const char *)a.u; per = (size_t)NU * 4; g0 = Lay::CH_u; }
-    else if (gg < Lay::CH_du) { base = (const char *)a.dx; per = (size_t)NX * 4; g0 = Lay::CH_dx; }
-    else { base = (const char *)a.du; per = (size_t)NU * 4; g0 = Lay::CH_du; }
+    else if (gg < Lay::CH_r) { base = (const char *)a.c; per = (size_t)ns * 4; g0 = Lay::CH_c; run = 4 * per; }
+    else if (gg < Lay::CH_F) { base = (const char *)a.r; per = (size_t)rc * 4; g0 = Lay::CH_r; run = 4 * per; }
+    else if (gg < Lay::CH_x) { base = (const char *)a.F; per = (size_t)nx * ns * 4; g0 = Lay::CH_F; isF = true; run = 4 * per; }
+    else if (gg < Lay::CH_u) { base = (const char *)a.x; per = (size_t)nx * 4; g0 = Lay::CH_x; run = 4 * per; }
+    else if (gg < Lay::CH_dx) { base = (const char *)a.u; per = (size_t)nu * 4; g0 = Lay::CH_u; run = 4 * per; }
+    else if (gg < Lay::CH_du) { base = (const char *)a.dx; per = (size_t)nx * 4; g0 = Lay::CH_dx; run = 4 * per; }
+    else { base = (const char *)a.du; per = (size_t)nu * 4; g0 = Lay::CH_du; run = 4 * per; }
+    // (r: rows of r_cols floats - and, PAD, every array shorter than its region: the chunks past the run repeat its chunk 0)
+    const int gc = (size_t)(gg - g0) * 16 < run || (!PAD && base != (const char *)a.r) ? gg - g0 : 0;
     const int t0 = isF ? T - 2 : T - 1;
-    ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)(gg - g0) * 16 + skip -
+    ptr[q] = (unsigned long long)base + ((size_t)t0 * B + (size_t)b0) * per + (size_t)gc * 16 + skip -
              (unsigned long long)(q % 4) * 1024u;
     str[q] = (unsigned)(B * per);
     dyn |= isF ? (1u << q) : 0u;
@@ -114,14 +122,15 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     }
   };
   // per-lane LDS indices (floats, relative to a slot), computed once
-  const int i_tau0 = lane < NX ? Lay::OFF_x + r * NX + lane : Lay::OFF_u + r * NU + (lane - NX);          // element `lane`
-  const int i_dtau0 = lane < NX ? Lay::OFF_dx + r * NX + lane : Lay::OFF_du + r * NU + (lane - NX);
-  const int e1 = is_t1 ? 16 + lane : NS - 1;                                                                  // element 16 + lane
-  const int i_tau1 = e1 < NX ? Lay::OFF_x + r * NX + e1 : Lay::OFF_u + r * NU + (e1 - NX);
-  const int i_dtau1 = e1 < NX ? Lay::OFF_dx + r * NX + e1 : Lay::OFF_du + r * NU + (e1 - NX);
-  const int i_crow = Lay::OFF_C + (r * NX + lane_x) * NS;   // row lane_x of C_t (state rows only in the slot)
-  const int i_c = Lay::OFF_c + r * NS + lane_x, i_r = Lay::OFF_r + r * rc + lane_x;
-  const int i_fcol = Lay::OFF_F + r * NX * NS + lane_x;     // column lane_x of F_t[:, :NX]
+  const int l0 = PAD ? logical(lane) : lane;                                    // element `lane` of tau: where it lies (-1: none)
+  const int e1 = is_t1 ? 16 + lane : NS - 1;                                    // element 16 + lane (clamped)
+  const int l1 = is_t1 ? (PAD ? logical(e1) : e1) : (PAD ? -1 : e1);
+  auto tau_index = [&](int l, int off_x, int off_u) { return l < nx ? off_x + r * nx + (l >= 0 ? l : 0) : off_u + r * nu + (l - nx); };
+  const int i_tau0 = tau_index(l0, Lay::OFF_x, Lay::OFF_u), i_dtau0 = tau_index(l0, Lay::OFF_dx, Lay::OFF_du);
+  const int i_tau1 = tau_index(l1, Lay::OFF_x, Lay::OFF_u), i_dtau1 = tau_index(l1, Lay::OFF_dx, Lay::OFF_du);
+  const int i_crow = Lay::OFF_C + (r * (PAD ? ns : NX) + lane_x) * ns;   // row lane_x of C_t (not PAD: state rows only in the slot)
+  const int i_c = Lay::OFF_c + r * ns + lane_x, i_r = Lay::OFF_r + r * rc + lane_x;
+  const int i_fcol = Lay::OFF_F + r * nx * ns + lane_x;     // column lane_x of F_t[:, :nx]
 
   float tau[2], dtau[2], ci, ri, Crow[NS], Fcol[NX];
   auto read_slot = [&](const float *slot) __attribute__((always_inline)) {
@@ -131,10 +140,51 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     dtau[1] = slot[i_dtau1];
     ci = slot[i_c];
     ri = slot[i_r];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) Crow[j] = slot[i_crow + j];
-#pragma unroll
-    for (int k = 0; k < NX; ++k) Fcol[k] = slot[i_fcol + k * NS];
+    if constexpr (PAD) {   // elements / rows outside the problem: 0
+      tau[0] = l0 >= 0 ? tau[0] : 0.f;
+      dtau[0] = l0 >= 0 ? dtau[0] : 0.f;
+      tau[1] = l1 >= 0 ? tau[1] : 0.f;
+      dtau[1] = l1 >= 0 ? dtau[1] : 0.f;
+      ci = is_x ? ci : 0.f;
+      ri = is_x ? ri : 0.f;
+    }
+    static_for<0, NS>([&](auto j) {
+      if constexpr (PAD) {
+        const int lj = logical(j.value);   // uniform
+        const float v = slot[i_crow + (lj >= 0 ? lj : 0)];
+        Crow[j.value] = (lj >= 0 && is_x) ? v : 0.f;
+      } else {
+        Crow[j.value] = slot[i_crow + j.value];
+      }
+    });
+    static_for<0, NX>([&](auto k) {
+      if constexpr (PAD) {
+        const bool row = k.value < nx;   // uniform
+        const float v = slot[i_fcol + (row ? k.value : 0) * ns];
+        Fcol[k.value] = (row && is_x) ? v : 0.f;
+      } else {
+        Fcol[k.value] = slot[i_fcol + k.value * NS];
+      }
+    });
+  };
+  // the staged rows -> the wave's contiguous run of HBM: n_chunks 16-byte chunks, a chunk per lane and instruction
+  auto store_run = [&](float *dst, int n_chunks) __attribute__((always_inline)) {
+    if constexpr (PAD) {
+      for (int ch = lane64; ch < n_chunks; ch += 64) reinterpret_cast<float4 *>(dst)[ch] = reinterpret_cast<const float4 *>(scr)[ch];
+    } else {
+      (void)n_chunks;
+    }
+  };
+  // stage row[0..NS) of the problem's row `li` (trajectory r, rows of `ns` floats) at the problem's own strides
+  auto stage_row = [&](const float (&row)[NS], int li, bool on) __attribute__((always_inline)) {
+    static_for<0, NS>([&](auto j) {
+      if constexpr (PAD) {
+        const int lj = logical(j.value);   // uniform
+        if (lj >= 0 && on) scr[(li) * ns + lj] = row[j.value];
+      } else {
+        if (on) scr[li * NS + j.value] = row[j.value];
+      }
+    });
   };
   // row[j] = tau[j] * ca + dtau[j] * cb, j < NS (the elements of tau broadcast from their lanes)
   auto outer2 = [&](float (&row)[NS], const float ca, const float cb) __attribute__((always_inline)) {
@@ -151,29 +201,24 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
       if (a.dF != nullptr) {   // dF_t[k][:] = d_lambda_{t+1}[k] tau + lambda_{t+1}[k] dtau
         float row[NS];
         outer2(row, a.out_sign * dlam, a.out_sign * lam);
-        if (is_x) {
-#pragma unroll
-          for (int j = 0; j < NS; ++j) scr[(r * NX + lane) * NS + j] = row[j];
-        }
-        store_chunks<NX * NS>(scr, a.dF + ((size_t)t * B + b0) * (NX * NS), lane64);
+        stage_row(row, r * nx + lane, is_x);
+        if constexpr (PAD) store_run(a.dF + ((size_t)t * B + b0) * (nx * ns), nx * ns);
+        else store_chunks<NX * NS>(scr, a.dF + ((size_t)t * B + b0) * (NX * NS), lane64);
       }
-      if (a.df != nullptr && a.df_shift == 1 && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+      if (a.df != nullptr && a.df_shift == 1 && is_x) a.df[tb * nx + lane] = a.out_sign * dlam;
     }
     if (a.dC != nullptr) {                                                    // :128-129: rows `lane` and 16 + lane
       float row[NS];
       outer2(row, a.out_sign * wa * dtau[0], a.out_sign * wb * tau[0]);
-#pragma unroll
-      for (int j = 0; j < NS; ++j) scr[(r * NS + lane) * NS + j] = row[j];
+      stage_row(row, r * ns + (l0 >= 0 ? l0 : 0), l0 >= 0);
       outer2(row, a.out_sign * wa * dtau[1], a.out_sign * wb * tau[1]);
-      if (is_t1) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) scr[(r * NS + 16 + lane) * NS + j] = row[j];
-      }
-      store_chunks<NS * NS>(scr, a.dC + ((size_t)t * B + b0) * (NS * NS), lane64);
+      stage_row(row, r * ns + (l1 >= 0 ? l1 : 0), is_t1 && l1 >= 0);
+      if constexpr (PAD) store_run(a.dC + ((size_t)t * B + b0) * (ns * ns), ns * ns);
+      else store_chunks<NS * NS>(scr, a.dC + ((size_t)t * B + b0) * (NS * NS), lane64);
     }
     if (a.dc != nullptr) {
-      a.dc[tb * NS + lane] = a.out_sign * dtau[0];
-      if (is_t1) a.dc[tb * NS + 16 + lane] = a.out_sign * dtau[1];
+      if (l0 >= 0) a.dc[tb * ns + l0] = a.out_sign * dtau[0];
+      if (is_t1 && l1 >= 0) a.dc[tb * ns + l1] = a.out_sign * dtau[1];
     }
     float nl = ci, ndl = a.r_sign * ri;                                       // :92,102 / :115,124
     float nl2 = 0.f, ndl2 = 0.f;                                              // (two chains each)
@@ -202,7 +247,7 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     }
     lam = nl + nl2;
     dlam = ndl + ndl2;
-    if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && is_x) a.df[tb * NX + lane] = a.out_sign * dlam;
+    if (a.df != nullptr && a.df_shift == 0 && t < T - 1 && is_x) a.df[tb * nx + lane] = a.out_sign * dlam;
   };
 
   // ONE register set (lqr_wide_kernel.hpp): the slot of step t is waited for and read, then - once the reads are in -
@@ -222,7 +267,7 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     });
   }
   wait_vmcnt<0>();
-  if (a.dx0 != nullptr && is_x) a.dx0[(size_t)b * NX + lane] = a.out_sign * dlam;
+  if (a.dx0 != nullptr && is_x) a.dx0[(size_t)b * nx + lane] = a.out_sign * dlam;
 }
 
 }  // namespace dmpc

@@ -41,9 +41,11 @@ __global__ __launch_bounds__(256) void concat_tau_kernel(size_t n_rows, int nx, 
 #define DMPC_COSTATE_CONTAINERS(X)
 #define DMPC_COSTATE_WAVE_CONTAINERS(X)
 #define DMPC_COSTATE_WIDE_SHAPES(X)
+#define DMPC_COSTATE_WIDE_CONTAINERS(X)
 #else
 #define DMPC_COSTATE_WAVE_CONTAINERS(X) X(16, 8) X(32, 8)
 #define DMPC_COSTATE_WIDE_SHAPES(X) X(16, 4) X(16, 8) X(12, 8)   /* (12,4): 16 elements of tau - the 16-lane kernels' size, no instance yet */
+#define DMPC_COSTATE_WIDE_CONTAINERS(X) X(16, 4) X(12, 8)
 #define DMPC_COSTATE_CONTAINERS(X) X(3, 1) X(4, 4) X(8, 2) X(5, 5) X(8, 4) X(14, 1) X(13, 2) X(12, 3) X(11, 4) X(10, 5) X(9, 6) X(8, 7) X(7, 8)
 #endif
 
@@ -99,6 +101,27 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
       DMPC_COSTATE_WIDE_SHAPES(X)
 #undef X
+      // ... and padded inside the (16,4) or (12,8) instance: the shapes without a 16-lane container (nx + nu >= 16) that fit one
+      // (the (16,8) instance's ring and staging buffer do not fit a CU's LDS: 13+ states with 5+ controls keep the wavefront
+      // container below)
+      static const bool no_pad = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
+      if (!no_pad && nx + nu >= 16 && nx >= 1 && nu >= 1) {
+        CostateArgs p = a;
+        p.nx_log = nx;
+        p.nu_log = nu;
+#define X(NX_, NU_)                                                                                            \
+  if (nx <= NX_ && nu <= NU_) {                                                                                \
+    using Lay = CostateWideLayout<NX_, NU_, 2, true>;                                                          \
+    static_assert(Lay::lds_bytes() <= 160 * 1024, "ring and staging beyond a CU's LDS");                      \
+    if (Lay::lds_bytes() > 64 * 1024)                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_wide_kernel<NX_, NU_, 2, true>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+    DMPC_LAUNCH_GGL((costate_wide_kernel<NX_, NU_, 2, true>), dim3((p.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, p); \
+    return (int)hipGetLastError();                                                                             \
+  }
+        DMPC_COSTATE_WIDE_CONTAINERS(X)
+#undef X
+      }
     }
   }
   {   // a problem without a specialisation padded inside the first container that holds it (the lists of lqr_api.hip)
