@@ -332,7 +332,7 @@ static bool wide_ok(int mode, int nx, int nu, const LqrArgs &a) {
   const bool exact = wide_shape(nx, nu), padded = wide_container_shape(nx, nu) && a.B % 4 == 0 && !container_disabled();
   // (the generated streams' own argument forms - c in two arrays, saved gains, x_init = 0 - are not its business)
   const bool plain = a.c_u == nullptr && a.Ks_in == nullptr && a.Vv_in == nullptr && a.Quu_out == nullptr && a.x_init != nullptr;
-  return mode == kSolve && plain && (exact || padded) && !wide_disabled() && a.mask == nullptr && a.wsK != nullptr &&
+  return mode == kSolve && plain && (exact || padded) && !wide_disabled() && a.wsK != nullptr &&
          a.B >= 4 && a.T >= 2 && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
 }
 static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
@@ -345,7 +345,14 @@ static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream)
     if (lds > 64 * 1024)                                                                                   \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-    DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF>), grid, block, lds, stream, a);                     \
+    if (a.mask != nullptr) {                                                                               \
+      if (lds > 64 * 1024)                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, false, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+      DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, false, true>), grid, block, lds, stream, a);      \
+    } else {                                                                                               \
+      DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF>), grid, block, lds, stream, a);                   \
+    }                                                                                                      \
     return (int)hipGetLastError();                                                                         \
   }
   DMPC_LQR_WIDE_SHAPES(X)
@@ -360,7 +367,14 @@ static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream)
     if (lds > 64 * 1024)                                                                                   \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
-    DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, true>), grid, block, lds, stream, p);               \
+    if (p.mask != nullptr) {                                                                               \
+      if (lds > 64 * 1024)                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+      DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, true, true>), grid, block, lds, stream, p);       \
+    } else {                                                                                               \
+      DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, true>), grid, block, lds, stream, p);             \
+    }                                                                                                      \
     return (int)hipGetLastError();                                                                         \
   }
   DMPC_LQR_WIDE_CONTAINERS(X)

@@ -107,7 +107,10 @@ __device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][NR]) {
 // is to the 16-lane shapes): the arrays in HBM keep the problem's own strides and come into the slot as they are; the reads
 // place state i at row / column i and control m at NX + m, everything else of [C|c] and [F|f] is 0 and the unused controls
 // get a unit diagonal in Quu (their gain rows come out exactly 0, LAPACK's pivot choice is unchanged).  Needs B % 4 == 0.
-template <int NX, int NU, int DB, int DF, bool PAD = false>
+// MASKED: LQR_active (mpc/active_constrained_lqr.py:110-137): a.mask [T,B,nu] flags the clamped controls of every step - they
+// leave the gain solve (their rows: 1e-8 on the diagonal, 0 elsewhere; their columns of the free rows: 0), so their gain rows
+// come out exactly 0 and the rollout needs no change; the value update keeps the unmasked blocks (:143-145).
+template <int NX, int NU, int DB, int DF, bool PAD = false, bool MASKED = false>
 __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   using Lay = LqrWideLayout<NX, NU, DB, DF>;
   using Blk = RiccatiBlocksWide<NX, NU>;
@@ -297,6 +300,19 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
         constexpr int i = NX + m.value;
         static_for<0, NR>([&](auto h) { Qu[m.value][h.value] = Kt[m.value][h.value] = Q4[i / 4][h.value][i % 4]; });
       });
+      if constexpr (MASKED) {
+        bool act[NU];
+        static_for<0, NU>([&](auto m) { act[m.value] = (!PAD || m.value < nu) && a.mask[tb * nu + (m.value < nu ? m.value : 0)] != 0; });
+        static_for<0, NR>([&](auto h) {
+          const int col = 16 * h.value + lane;
+          bool act_col = false;   // this lane's column is the column of a clamped control
+          static_for<0, NU>([&](auto m) { act_col = act_col || (col == NX + m.value && act[m.value]); });
+          static_for<0, NU>([&](auto m) {
+            const float free_row = act_col ? 0.f : Kt[m.value][h.value];
+            Kt[m.value][h.value] = act[m.value] ? ((col == NX + m.value) ? 1e-8f : 0.f) : free_row;
+          });
+        });
+      }
       if (gauss_jordan_rows_wide<NX, NU, NR>(Kt)) info_bits |= 1;
 #pragma unroll
       for (int m = 0; m < NU; ++m)

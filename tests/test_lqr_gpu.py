@@ -209,6 +209,18 @@ def test_wide_row_kernel_against_oracle(dims):
         x2, u2 = rec.forward(*rec.backward())          # the container kernels (the path of rounds 2-4)
         assert_close(npy(x), npy(x2), 2e-5, "x against the separate sweeps")
         assert_close(npy(u), npy(u2), 2e-5, "u against the separate sweeps")
+    # the clamped variant (LQR_active, mpc/active_constrained_lqr.py:110-137) on the same kernel
+    for (B, T, seed) in ((8, 6, 7), (36, 11, 8)):
+        p = synthetic.make_lqr_problem(B, T, nx, nu, seed=seed, with_f=False)
+        act = np.random.RandomState(nx * 16 + nu + seed).rand(T, B, nu) < 0.4
+        xr, ur = ompc.lqr_active_solve(np.zeros((B, nx)), p["C"], p["c"], p["F"], None, act, T, nx, nu)
+        d = to_dev(p)
+        x, u = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
+                            u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
+        assert _lib.last_kernel_name().startswith("void dmpc::lqr_wide_kernel<%d, %d" % inst) and "true>" in _lib.last_kernel_name()
+        assert_close(npy(x), xr, TOL_PRIMAL, "x active")
+        assert_close(npy(u), ur, TOL_PRIMAL, "u active")
+        assert np.all(npy(u)[act] == 0)
     # a batch below one wavefront of four trajectories does not take it (padded: nor a ragged one)
     assert lib.dmpc_lqr_solve_path(6, 3, nx, nu) == 7
     if padded:
