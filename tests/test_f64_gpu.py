@@ -241,6 +241,15 @@ def _fuzz_cases():
         if nx * T > 900:          # (keep the float64 path's share of the suite small)
             T = max(1, 900 // nx)
         cases.append((B, T, nx, nu, bool(rng.randint(2)), bool(rng.randint(2))))
+    # ... and twenty around the wide row kernel's borders (lqr_wide_kernel.hpp: 8..16 states, nx + nu on either side of 16,
+    # whole and ragged wavefronts - the padded form wants B % 4 == 0 and hands anything else to the wavefront containers)
+    rng = np.random.RandomState(4)
+    for _ in range(20):
+        nx = int(rng.randint(8, 17))
+        nu = int(rng.randint(max(1, 14 - nx), 9))
+        T = int(rng.choice([2, 3, 9, 26, 51]))
+        B = int(rng.choice([4, 8, 12, 36, 37, 64]))
+        cases.append((B, T, nx, nu, bool(rng.randint(2)), bool(rng.randint(2))))
     return cases
 
 
@@ -307,6 +316,11 @@ def _grad_fuzz_cases():
         if nx * T > 600:
             T = max(2, 600 // nx)
         cases.append((B, T, nx, nu, bool(rng.randint(2))))
+    rng = np.random.RandomState(5)      # ... and twelve around the wide kernels' borders (as in _fuzz_cases)
+    for _ in range(12):
+        nx = int(rng.randint(8, 17))
+        nu = int(rng.randint(max(1, 14 - nx), 9))
+        cases.append((int(rng.choice([4, 8, 36, 37])), int(rng.choice([2, 3, 9, 26])), nx, nu, bool(rng.randint(2))))
     return cases
 
 
