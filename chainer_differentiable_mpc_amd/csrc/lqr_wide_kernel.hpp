@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   static_assert(NX % 4 == 0 && NU % 4 == 0, "tiles of four rows");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
   static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
-  static_assert((DB - 1) * Lay::kDmaB + 2 * NU <= 63, "counted wait out of range");
 
   const int T = a.T;
   const size_t B = (size_t)a.B;
@@ -372,8 +371,9 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
 
     // ONE register set (two would not fit next to V and W): at the top of step t its slot is waited for and read, then -
     // once the reads are in - refilled with step t - DB, and the step is computed while DB - 1 fetches are in flight.  The
-    // gain-row stores of a step are younger than its refill and retire in order with it (one counter): the counted wait
-    // allows for the 2 NU a step always issues.
+    // gain-row stores of a step are younger than its refill: waiting for all but (DB - 1) kDmaB operations is exact for the
+    // first step and conservative afterwards (the stores have had a whole step to complete; allowing for them - 2 NU per
+    // step - would rely on stores and loads retiring in one order, and measured no faster).
     f4w Q[NT][NR];
     float Fc[NX][NR];
     static_for<0, DB>([&](auto j) { issue_next(j.value); });
@@ -381,8 +381,7 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
       static_for<0, DB>([&](auto j) {
         const int t = t0 - j.value;
         if (t >= 0) {
-          if (t == T - 1) wait_vmcnt<(DB - 1) * Lay::kDmaB>();
-          else wait_vmcnt<(DB - 1) * Lay::kDmaB + 2 * NU>();
+          wait_vmcnt<(DB - 1) * Lay::kDmaB>();
           read_slot(ring + j.value * Lay::SLOT_B, Q, Fc);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads are in before it is refilled
           issue_next(j.value);
