@@ -15,6 +15,7 @@
 // the tiled-cost sums (dC_sum) are not formed here.
 #pragma once
 #include "costate_dma_kernel.hpp"
+#include "lqr_wide_kernel.hpp"      // padded_read()
 
 namespace dmpc {
 
@@ -34,7 +35,7 @@ struct CostateWideLayout {
   static constexpr int kDma = (CH_END + 63) / 64;
   static constexpr int SLOT = kDma * 256;           // floats per wave and timestep (whole 1 KB pieces)
   static constexpr int SCR = 4 * NS * NS;           // output staging, floats per wave: dF rows, then dC rows (one buffer)
-  static constexpr size_t lds_bytes() { return (size_t)4 * (DB * SLOT + SCR) * 4; }
+  static constexpr size_t lds_bytes() { return (size_t)4 * (DB * SLOT + SCR) * 4 + 64; }   // + a zero per wave (PAD)
   static_assert((NX * NS) % 4 == 0, "a trajectory's state rows of C are whole 16-byte chunks");
 };
 
@@ -61,6 +62,10 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
   float *ring = lds + wave * (DB * Lay::SLOT);
   float *scr = lds + 4 * (DB * Lay::SLOT) + wave * Lay::SCR;
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+  float *zo = lds + 4 * (DB * Lay::SLOT + Lay::SCR) + wave * 4;   // PAD: a zero for the padded reads (this wave's own)
+  if constexpr (PAD) {
+    if (lane64 == 0) zo[0] = 0.f;
+  }
 
   // the problem's own dimensions, and where container element e of tau lies in them (-1: padding)
   const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
@@ -151,8 +156,7 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     static_for<0, NS>([&](auto j) {
       if constexpr (PAD) {
         const int lj = logical(j.value);   // uniform
-        const float v = slot[i_crow + (lj >= 0 ? lj : 0)];
-        Crow[j.value] = (lj >= 0 && is_x) ? v : 0.f;
+        Crow[j.value] = padded_read(slot + i_crow + (lj >= 0 ? lj : 0), lj >= 0 && is_x, zo);
       } else {
         Crow[j.value] = slot[i_crow + j.value];
       }
@@ -160,8 +164,7 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
     static_for<0, NX>([&](auto k) {
       if constexpr (PAD) {
         const bool row = k.value < nx;   // uniform
-        const float v = slot[i_fcol + (row ? k.value : 0) * ns];
-        Fcol[k.value] = (row && is_x) ? v : 0.f;
+        Fcol[k.value] = padded_read(slot + i_fcol + (row ? k.value : 0) * ns, row && is_x, zo);
       } else {
         Fcol[k.value] = slot[i_fcol + k.value * NS];
       }

@@ -29,6 +29,13 @@
 namespace dmpc {
 
 typedef float f4w __attribute__((ext_vector_type(4)));
+// A container's padded read: the element if it belongs to the problem, else a constant kept in LDS (0, or 1 for the diagonal
+// of an unused control) - the ADDRESS is selected, not the value.  (Selecting the value lets hipcc sink the load into the
+// select and wrap every padded element in its own branch: 5,600 instead of 3,100 instructions in
+// lqr_wide_kernel<16, 4, ..., PAD>; pinning the value with an empty asm puts a wait behind every load.)
+__device__ __forceinline__ float padded_read(const float *element, bool valid, const float *constant) {
+  return *(valid ? element : constant);
+}
 // D[c] (lane l) += A[lane 16 (l / 16) + 4 I + c] * B[lane l], c < 4: rows 4I..4I+3 of an outer product, per 16-lane trajectory
 template <int I>
 __device__ __forceinline__ f4w mfma_rows(float a, float b, f4w c) {
@@ -46,7 +53,7 @@ struct LqrWideLayout {
   static constexpr int kDmaB = (CH_B + 63) / 64, kDmaF = (CH_F + 63) / 64;
   static constexpr int SLOT_B = kDmaB * 256, SLOT_F = kDmaF * 256;   // floats: whole kilobytes
   static constexpr int RING_FL = (DB * SLOT_B > DF * SLOT_F) ? DB * SLOT_B : DF * SLOT_F;   // per wave
-  static constexpr size_t lds_bytes() { return (size_t)4 * RING_FL * 4; }
+  static constexpr size_t lds_bytes() { return (size_t)4 * RING_FL * 4 + 64; }   // + [0, 1] per wave (the containers' padding)
 };
 
 // Gauss-Jordan on the rows of [Qux | Quu | qu] where they lie (gauss_jordan_rows of riccati_blocks.hpp, two registers per
@@ -141,6 +148,10 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   float *ring = lds + wave * Lay::RING_FL;
   float *kw = a.wsK + (size_t)b * NU * KROW;    // + t * B * NU * KROW: this trajectory's gain rows in the workspace
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
+  float *zo = lds + 4 * Lay::RING_FL + wave * 4;   // PAD: zo[0] = 0, zo[1] = 1 (written below, read by this wave alone)
+  if constexpr (PAD) {
+    if (lane64 < 2) zo[lane64] = (float)lane64;
+  }
 
   int info_bits = 0;
   // the problem's own dimensions, and where container row / column c lies in its arrays (-1: padding)
@@ -221,10 +232,10 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
           static_for<0, NR>([&](auto h) {
             if constexpr (PAD) {
               const int li = logical(i);   // uniform
-              const float v = slot[qb[h.value] + (li >= 0 ? li : 0) * sh[h.value]];
               // outside the problem: 0, and 1 on the diagonal of the unused controls (column i: lane i % 16 of register i / 16)
-              const float d = (i >= NX && i / 16 == h.value && lane == i % 16) ? 1.f : 0.f;
-              Qn[I.value][h.value][cc.value] = (li >= 0 && ok[h.value]) ? v : (li < 0 ? d : 0.f);
+              const bool diag = li < 0 && i >= NX && i / 16 == h.value && lane == i % 16;
+              Qn[I.value][h.value][cc.value] = padded_read(slot + qb[h.value] + (li >= 0 ? li : 0) * sh[h.value],
+                                                           li >= 0 && ok[h.value], zo + (diag ? 1 : 0));
             } else {
               Qn[I.value][h.value][cc.value] = slot[qb[h.value] + i * sh[h.value]];
             }
@@ -235,8 +246,7 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
         static_for<0, NR>([&](auto h) {
           if constexpr (PAD) {
             const bool row = k.value < nx;   // uniform
-            const float v = slot[fb[h.value] + (row ? k.value : 0) * sh[h.value]];
-            Fn[k.value][h.value] = (row && ok[h.value]) ? v : 0.f;
+            Fn[k.value][h.value] = padded_read(slot + fb[h.value] + (row ? k.value : 0) * sh[h.value], row && ok[h.value], zo);
           } else {
             Fn[k.value][h.value] = slot[fb[h.value] + k.value * sh[h.value]];
           }
@@ -439,8 +449,7 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
       static_for<0, NS>([&](auto j) {
         if constexpr (PAD) {
           const int lj = logical(j.value);   // uniform
-          const float v = s[xrow + (lj >= 0 ? lj : 0)];
-          Fr[j.value] = lj >= 0 ? v : 0.f;
+          Fr[j.value] = padded_read(s + xrow + (lj >= 0 ? lj : 0), lj >= 0, zo);
         } else {
           Fr[j.value] = s[xrow + j.value];
         }
