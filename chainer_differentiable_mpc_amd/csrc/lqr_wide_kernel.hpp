@@ -25,6 +25,7 @@
 #include "dpp_blocks_wide_gen.hpp"
 #include "lqr_dma_kernel.hpp"
 #include "lqr_kernels.hpp"
+#include "pnqp_device.hpp"
 
 namespace dmpc {
 
@@ -117,7 +118,13 @@ __device__ __forceinline__ bool gauss_jordan_rows_wide(float (&Kr)[NU][NR]) {
 // MASKED: LQR_active (mpc/active_constrained_lqr.py:110-137): a.mask [T,B,nu] flags the clamped controls of every step - they
 // leave the gain solve (their rows: 1e-8 on the diagonal, 0 elsewhere; their columns of the free rows: 0), so their gain rows
 // come out exactly 0 and the rollout needs no change; the value update keeps the unmasked blocks (:143-145).
-template <int NX, int NU, int DB, int DF, bool PAD = false, bool MASKED = false>
+// MPC: MPCstep.backward_rec (mpc/mpc_step.py:70-173) - the sweep alone, with the feed-forward term k_t the solution of the box
+// QP on (Quu, qu), lower - u <= k <= upper - u (projected Newton, mpc/pnqp.py:37-201, per-trajectory termination, warm start
+// from the later step: pnqp_solve_rows in every lane on broadcast Quu, qu - mpc_kernels.hpp's scheme), K_t from the QP's
+// own last factorisation with the clamped rows zeroed (:147-157), the value update from the unmasked blocks (:165-166);
+// with a.mpc_states the re-centring c_hat = C [x_t; u_t] + c (need_expand, :305-317) happens on the slot's rows.  Gains to
+// a.Ks / a.ks, sum_t (1 + i_t) to a.mpc_n_qp_total; no rollout.  (Before: the runtime-dimension kernel, 2.0 ms at (12,4).)
+template <int NX, int NU, int DB, int DF, bool PAD = false, bool MASKED = false, bool MPC = false>
 __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   using Lay = LqrWideLayout<NX, NU, DB, DF>;
   using Blk = RiccatiBlocksWide<NX, NU>;
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   static_assert(NX % 4 == 0 && NU % 4 == 0, "tiles of four rows");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
   static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
+  static_assert(!MPC || (!PAD && !MASKED && NR == 2), "the MPC sweep: exact two-register shapes");
 
   const int T = a.T;
   const size_t B = (size_t)a.B;
@@ -260,9 +268,50 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
 #pragma unroll
       for (int h = 0; h < NR; ++h) V[i][h] = 0.f;
     const float eaff = affl ? 1.f : 0.f;     // unit vector of the affine column (in register AB)
+    // MPC: the step's controls and bounds (the same in the 16 lanes of a trajectory) and this lane's elements of [x_t; u_t],
+    // loaded one step ahead (older than the slot's refill: the counted wait lets that one fly)
+    struct MpcIn {
+      float uc[NU], lb[NU], ub[NU], tau[NR];
+    };
+    MpcIn mcur, mnxt;
+    float kprev[NU];
+    int n_total = 0;
+    auto mpc_load = [&](int t, MpcIn &m) __attribute__((always_inline)) {
+      if constexpr (MPC) {
+        const size_t tbm = (size_t)(t < 0 ? 0 : t) * B + b;
+#pragma unroll
+        for (int q = 0; q < NU; ++q) {
+          m.uc[q] = a.mpc_controls[tbm * NU + q];
+          m.lb[q] = a.mpc_lower[tbm * NU + q];
+          m.ub[q] = a.mpc_upper[tbm * NU + q];
+        }
+#pragma unroll
+        for (int h = 0; h < NR; ++h) {
+          const int col = 16 * h + lane;
+          m.tau[h] = 0.f;
+          if (a.mpc_states != nullptr && col < NS) m.tau[h] = col < NX ? a.mpc_states[tbm * NX + col] : a.mpc_controls[tbm * NU + (col - NX)];
+        }
+      }
+    };
+    if constexpr (MPC) {
+#pragma unroll
+      for (int q = 0; q < NU; ++q) kprev[q] = 0.f;
+      mpc_load(T - 1, mcur);
+    }
 
     auto step = [&](int t, f4w (&Q4)[NT][NR], float (&Fc)[NX][NR]) __attribute__((always_inline)) {
       const size_t tb = (size_t)t * B + b;
+      if constexpr (MPC) {
+        if (a.mpc_states != nullptr) {   // c_hat = C tau + c: the row sums land in the affine column        mpc_step.py:305-317
+          static_for<0, NS>([&](auto i) {
+            float sum = 0.f;          // (tau is 0 in the lanes that hold no column of C)
+#pragma unroll
+            for (int h = 0; h < NR; ++h) sum = fmaf(Q4[i.value / 4][h][i.value % 4], aff[h] ? 0.f : mcur.tau[h], sum);
+            sum = group_sum<16>(sum);
+            Q4[i.value / 4][AB][i.value % 4] += affl ? sum : 0.f;
+          });
+        }
+      }
       if (t < T - 1) {
         if (!has_f) {
 #pragma unroll
@@ -322,21 +371,53 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
           });
         });
       }
-      if (gauss_jordan_rows_wide<NX, NU, NR>(Kt)) info_bits |= 1;
+      if constexpr (MPC) {
+        // every lane gets Quu, qu and the QP's bounds                                              mpc_step.py:119-138
+        float Quu[NU][NU], qu[NU], lo[NU], hi[NU], kt[NU];
+        static_for<0, NU>([&](auto l) {
+          constexpr int lb_ = (NX + l.value) / 16, ll = (NX + l.value) % 16;
+          static_for<0, NU>([&](auto m) { Quu[m.value][l.value] = G::template bcast<ll>(Qu[m.value][lb_]); });
+        });
+        static_for<0, NU>([&](auto m) {
+          qu[m.value] = G::template bcast<NS % 16>(Qu[m.value][AB]);
+          lo[m.value] = mcur.lb[m.value] - mcur.uc[m.value];
+          hi[m.value] = mcur.ub[m.value] - mcur.uc[m.value];
+          kt[m.value] = kprev[m.value];
+        });
+        PnqpResult<NU> qp;
+        pnqp_solve_rows<NU>(Quu, qu, lo, hi, kt, /*warm=*/t != T - 1, a.mpc_n_qp_iter, qp);      // :141-146
+        n_total += 1 + qp.it;
+        if (!qp.converged) info_bits |= 4;
+        // K_t = -LU_free^-1 Qux with the rows of clamped controls zeroed (:147-157); the affine column carries k_t
+        static_for<0, NR>([&](auto h) {
+          float col[NU];
 #pragma unroll
-      for (int m = 0; m < NU; ++m)
+          for (int m = 0; m < NU; ++m) col[m] = qp.free_[m] ? Qu[m][h.value] : 0.f;
+          lu_solve_rinv<NU>(qp.fac, qp.piv, qp.rinv, col);
 #pragma unroll
-        for (int h = 0; h < NR; ++h) Kt[m][h] = -Kt[m][h];
+          for (int m = 0; m < NU; ++m) Kt[m][h.value] = (h.value == AB && affl) ? kt[m] : -col[m];
+        });
+#pragma unroll
+        for (int m = 0; m < NU; ++m) kprev[m] = kt[m];
+      } else {
+        if (gauss_jordan_rows_wide<NX, NU, NR>(Kt)) info_bits |= 1;
+#pragma unroll
+        for (int m = 0; m < NU; ++m)
+#pragma unroll
+          for (int h = 0; h < NR; ++h) Kt[m][h] = -Kt[m][h];
+      }
       // gain rows [K_m | 0 | k_m] to the workspace (the rollout reads them like rows of F), and to the caller
       {
-        float *row = kw + (size_t)t * B * (NU * KROW);
-        if (lane < NX) {
+        if constexpr (!MPC) {
+          float *row = kw + (size_t)t * B * (NU * KROW);
+          if (lane < NX) {
 #pragma unroll
-          for (int m = 0; m < NU; ++m) row[m * KROW + lane] = Kt[m][0];
-        }
-        if (affl) {
+            for (int m = 0; m < NU; ++m) row[m * KROW + lane] = Kt[m][0];
+          }
+          if (affl) {
 #pragma unroll
-          for (int m = 0; m < NU; ++m) row[m * KROW + NS] = Kt[m][AB];
+            for (int m = 0; m < NU; ++m) row[m * KROW + NS] = Kt[m][AB];
+          }
         }
         if (a.Ks != nullptr) {
           if (lane < nx) {
@@ -394,12 +475,21 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
           wait_vmcnt<(DB - 1) * Lay::kDmaB>();
           read_slot(ring + j.value * Lay::SLOT_B, Q, Fc);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot's reads are in before it is refilled
+          if constexpr (MPC) mpc_load(t - 1, mnxt);
           issue_next(j.value);
           step(t, Q, Fc);
+          if constexpr (MPC) mcur = mnxt;
         }
       });
     }
     wait_vmcnt<0>();   // the ring is reused by the rollout, and this wave's gain rows have reached L2
+    if constexpr (MPC) {
+      if (lane == 0) {
+        a.mpc_n_qp_total[b] = n_total;
+        if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+      }
+      return;
+    }
     __threadfence();
   }
 

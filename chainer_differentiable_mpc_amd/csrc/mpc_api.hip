@@ -12,6 +12,7 @@
 #include "mpc_dma_kernels.hpp"
 #include "mpc_fwd_asm_kernel.hpp"
 #include "mpc_step_fused_kernel.hpp"
+#include "lqr_wide_kernel.hpp"
 #include "lqr_wave_api.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_tiled.hpp"
@@ -203,6 +204,32 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     s.mpc_n_qp_iter = a.n_qp_iter;
     s.mpc_n_qp_total = a.n_qp_total;
     return launch_mpc_wave_backward(nx, nu, s, stream);
+  }
+  // (12,4), (16,4): the sweep on the wide row kernel with the box QP inside (lqr_wide_kernel<..., MPC>: four trajectories per
+  // wavefront, matrix-core products; before, the runtime-dimension kernel - 2.0 ms at B = 4096, T = 50).  DMPC_NO_WIDE=1: that.
+  {
+    static const bool wide_off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
+    if (!wide_off && a.sync == nullptr && a.done == nullptr && !a.info_store && a.B >= 4 && a.T >= 2 &&
+        aligned16(a.C, a.c, a.F, a.f) && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31)) {
+      LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
+      s.mpc_controls = a.controls;
+      s.mpc_lower = a.lower;
+      s.mpc_upper = a.upper;
+      s.mpc_states = a.states;
+      s.mpc_n_qp_iter = a.n_qp_iter;
+      s.mpc_n_qp_total = a.n_qp_total;
+#define X(NX_, NU_)                                                                                            \
+  if (nx == NX_ && nu == NU_) {                                                                                \
+    constexpr size_t lds = LqrWideLayout<NX_, NU_, 2, 2>::lds_bytes();                                         \
+    if (lds > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, 2, 2, false, false, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+    DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, 2, 2, false, false, true>), dim3((s.B + 15) / 16), dim3(256), lds, stream, s); \
+    return (int)hipGetLastError();                                                                             \
+  }
+      X(12, 4) X(16, 4)
+#undef X
+    }
   }
   auto wave_container = [&](int cnx, int cnu) {   // wider than the 16-lane containers: padded inside a wave instance
     LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};

@@ -1,0 +1,26 @@
+"""MPCstep.forward (re-centring, sweep with the box QP of every step, line search) per shape at B = 4096 (or B=...), T = 50,
+bounds +-0.5: HIP-event time per call and the kernels it ran (the last two launches' names)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost, _lib
+from chainer_differentiable_mpc_amd.util import get_traj
+shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "8x2,8x4,12x4,16x4,16x8").split(",")]
+B, T = int(os.environ.get("B", 4096)), 50
+dev = torch.device("cuda")
+for nx, nu in shapes:
+    p, d = bench.make_inputs(B, T, nx, nu, 0, dev)
+    torch.manual_seed(0)
+    un = (0.5 * torch.randn((T, B, nu), device=dev)).clamp(-0.5, 0.5)
+    xn = get_traj(T, un, d["x_init"], LinDx(d["F"], d["f"]))
+    lo, hi = torch.full((T, B, nu), -0.5, device=dev), torch.full((T, B, nu), 0.5, device=dev)
+    step = MPCstep(un, T, hi, lo, B, nx, nu, xn, QuadCost(d["C"], d["c"]), LinDx(d["F"], d["f"]), 0.2, 5, need_expand=True)
+    import warnings
+    def fwd():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            step.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    t = bench.event_time(fwd, 5, warm=2, settled=False) * 1e6
+    print("(%d,%d) B=%d: MPCstep.forward %.1f us (incl. the wrapper's host work) [last: %s]" % (nx, nu, B, t, _lib.last_kernel_name()[:90]), flush=True)
+    del p, d, un, xn, lo, hi, step
+    torch.cuda.empty_cache()
