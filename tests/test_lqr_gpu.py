@@ -217,7 +217,8 @@ def test_wide_row_kernel_against_oracle(dims):
         d = to_dev(p)
         x, u = LqrRecursion(torch.zeros_like(d["x_init"]), d["C"], d["c"], d["F"], None, T, nx, nu,
                             u_zero_Index=torch.as_tensor(act).cuda()).solve_recursion()
-        assert _lib.last_kernel_name().startswith("void dmpc::lqr_wide_kernel<%d, %d" % inst) and "true>" in _lib.last_kernel_name()
+        assert _lib.last_kernel_name().startswith("void dmpc::lqr_wide_kernel<%d, %d" % inst)
+        assert ", true, false>(" in _lib.last_kernel_name()     # <..., PAD, MASKED = true, MPC = false>
         assert_close(npy(x), xr, TOL_PRIMAL, "x active")
         assert_close(npy(u), ur, TOL_PRIMAL, "u active")
         assert np.all(npy(u)[act] == 0)
