@@ -13,6 +13,7 @@
 #include "mpc_fwd_asm_kernel.hpp"
 #include "mpc_step_fused_kernel.hpp"
 #include "lqr_wide_kernel.hpp"
+#include "mpc_wide_forward_kernel.hpp"
 #include "lqr_wave_api.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_tiled.hpp"
@@ -366,6 +367,27 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   }
   DMPC_MPC_SHAPES(X)
 #undef X
+  // 17 to 31 elements of tau, at most 16 states: the line search of the wide row layout (mpc_wide_forward_kernel.hpp: four
+  // trajectories per wavefront; before, the runtime-dimension kernel - 0.68 ms at (12,4)).  DMPC_NO_WIDE=1: that one.
+  {
+    static const bool wide_off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
+    if (!wide_off && a.dyn_kind == 0 && a.ls_cap > 0 && a.B >= 4 && a.T >= 2 && a.info_in == nullptr &&
+        aligned16(a.C, a.c, a.F, a.f, a.Ks, a.ks, a.controls, a.lower, a.upper, a.states) &&
+        (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31)) {
+#define X(NX_, NU_)                                                                                            \
+  if (nx == NX_ && nu == NU_) {                                                                                \
+    using Lay = MpcWideFwdLayout<NX_, NU_, 2>;                                                                 \
+    static_assert(Lay::lds_bytes() <= 160 * 1024, "ring beyond a CU's LDS");                                   \
+    if (Lay::lds_bytes() > 64 * 1024)                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc_wide_forward_kernel<NX_, NU_, 2>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+    DMPC_LAUNCH_GGL((mpc_wide_forward_kernel<NX_, NU_, 2>), dim3((a.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, a); \
+    return (int)hipGetLastError();                                                                             \
+  }
+      X(12, 4) X(16, 4) X(12, 8) X(16, 8)
+#undef X
+    }
+  }
   if (a.dyn_kind == 0 && !mpc_container_disabled()) {
     a.nx_log = nx;
     a.nu_log = nu;
