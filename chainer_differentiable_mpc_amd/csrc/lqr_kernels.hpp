@@ -57,6 +57,7 @@ struct LqrArgs {
   const float *mpc_controls = nullptr, *mpc_lower = nullptr, *mpc_upper = nullptr, *mpc_states = nullptr;
   int mpc_n_qp_iter = 0;
   int32_t *mpc_n_qp_total = nullptr;
+  const int32_t *mpc_done = nullptr;   // lqr_wide_kernel<..., MPC>: device flag of the BoxDDP loop (non-zero -> no-op)
   float *tiled_scratch = nullptr;   // lqr_tiled_kernel (any nx, nu): [B][tiled_scratch_floats(nx, nu)] of the caller's workspace
 };
 

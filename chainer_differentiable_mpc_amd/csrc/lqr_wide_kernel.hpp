@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
   static_assert(!MPC || (!PAD && !MASKED && NR == 2), "the MPC sweep: exact two-register shapes");
 
+  if constexpr (MPC) {
+    if (a.mpc_done != nullptr && *a.mpc_done != 0) return;  // uniform: the iLQR loop has stopped
+  }
   const int T = a.T;
   const size_t B = (size_t)a.B;
   const bool has_f = a.f != nullptr;
@@ -486,7 +489,10 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
     if constexpr (MPC) {
       if (lane == 0) {
         a.mpc_n_qp_total[b] = n_total;
-        if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+        if (a.info != nullptr) {
+          if (a.info_store) a.info[b] = info_bits;
+          else if (info_bits != 0) atomicOr(&a.info[b], info_bits);
+        }
       }
       return;
     }

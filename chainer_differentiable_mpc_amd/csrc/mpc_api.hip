@@ -210,7 +210,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   // wavefront, matrix-core products; before, the runtime-dimension kernel - 2.0 ms at B = 4096, T = 50).  DMPC_NO_WIDE=1: that.
   {
     static const bool wide_off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
-    if (!wide_off && a.sync == nullptr && a.done == nullptr && !a.info_store && a.B >= 4 && a.T >= 2 &&
+    if (!wide_off && a.sync == nullptr && sel == nullptr && a.B >= 4 && a.T >= 2 &&
         aligned16(a.C, a.c, a.F, a.f) && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31)) {
       LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
       s.mpc_controls = a.controls;
@@ -219,6 +219,8 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
       s.mpc_states = a.states;
       s.mpc_n_qp_iter = a.n_qp_iter;
       s.mpc_n_qp_total = a.n_qp_total;
+      s.mpc_done = a.done;
+      s.info_store = a.info_store != 0;
 #define X(NX_, NU_)                                                                                            \
   if (nx == NX_ && nu == NU_) {                                                                                \
     constexpr size_t lds = LqrWideLayout<NX_, NU_, 2, 2>::lds_bytes();                                         \

@@ -141,6 +141,31 @@ def test_box_ddp_lindx_b128_against_oracle():
     assert_close(npy(costs), cr, TOL_PRIMAL, "costs")
 
 
+@pytest.mark.parametrize("dims", [(12, 4), (16, 4)], ids=lambda d: "%dx%d" % d)
+def test_box_ddp_quadrotor_sized_against_oracle(dims):
+    """`BoxDDP` with a LinDx at 12 / 16 states and four controls: the device-driven loop over the wide row kernels (the sweep
+    with the box QP inside lqr_wide_kernel<..., MPC>, the line search of mpc_wide_forward_kernel.hpp) - the iterates and the
+    status of the oracle's loop, and of the host loop over `MPCstep` objects"""
+    nx, nu = dims
+    B, T = 12, 8
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=35, with_f=True)
+    xr, ur, cr, status, n_iter, *_ = obox.box_ddp(p["x_init"], ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"]),
+                                                  T, -0.25, 0.25, nx, nu, batch_coupled=False, eps=1e-3, max_iter=10)
+    for device_loop in (True, False):
+        solver = BoxDDP(T, -0.25, 0.25, B, nx, nu, None, max_iter=10, quiet=True, eps=1e-3, device_loop=device_loop)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, costs = solver((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
+        assert solver.status.strip() == status.strip() and solver.n_iter == n_iter, (solver.status, solver.n_iter, status, n_iter)
+        assert float((u.abs() == 0.25).float().mean()) > 0.02
+        # The loop stops once a step is shorter than eps = 1e-3 (the pendulum experiments' mpc_eps), i.e. within a fraction of
+        # eps of its fixed point - and that is how far a float32 and a float64 run of it may end apart (measured 1.2e-4 here;
+        # one MPC step from a common iterate is held to 1e-4 by tests/test_mpc_step_gpu.py at these shapes)
+        assert_close(npy(u), ur, 3e-4, "u")
+        assert_close(npy(x), xr, 3e-4, "x")
+        assert_close(npy(costs), cr, 3e-4, "costs")
+
+
 def test_box_ddp_beyond_8_controls_runs_its_host_loop_against_oracle():
     """`BoxDDP` (mpc/box_ddp.py:93-291) on a problem with 12 controls: `dmpc_box_ddp`'s device-driven loop declines (its
     workspace has no room for the any-size kernels' matrices), `BoxDDP` runs the reference's loop over `MPCstep` objects on
