@@ -43,6 +43,7 @@ if [ "$PART" = "A" ]; then
   timeout -k 10 300 python3 scripts/f64_timing.py > $OUT/f64_timing.txt 2>&1
   timeout -k 10 300 python3 scripts/mpc_step_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mpc_step_one_launch.txt
   timeout -k 10 300 python3 scripts/kkt_shape_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/kkt_shape_timing.txt
+  timeout -k 10 300 python3 scripts/mpc_shape_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mpc_shape_timing.txt
   ls -la $OUT
 else
   rm -f $OUT/pmc_summary.txt
