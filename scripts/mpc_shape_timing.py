@@ -20,7 +20,16 @@ for nx, nu in shapes:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             step.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
-    t = bench.event_time(fwd, 5, warm=2, settled=False) * 1e6
-    print("(%d,%d) B=%d: MPCstep.forward %.1f us (incl. the wrapper's host work) [last: %s]" % (nx, nu, B, t, _lib.last_kernel_name()[:90]), flush=True)
+    for _ in range(3):
+        fwd()
+    torch.cuda.synchronize()
+    ts = []                 # single calls, the median reported (a mean over a handful is at the mercy of one hiccup)
+    for _ in range(9):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fwd(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    print("(%d,%d) B=%d: MPCstep.forward median %.1f us, min %.1f, max %.1f over 9 calls (incl. the wrapper's host work) [last: %s]"
+          % (nx, nu, B, ts[4], ts[0], ts[-1], _lib.last_kernel_name()[:70]), flush=True)
     del p, d, un, xn, lo, hi, step
     torch.cuda.empty_cache()
