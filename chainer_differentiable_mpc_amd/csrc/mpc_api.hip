@@ -193,21 +193,9 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   if (sel != nullptr && !(dma_ok && sel_sync != nullptr)) return DMPC_E_BADARG;   // callers ask mpc_back_dma_ok first
   DMPC_MPC_SHAPES(X)
 #undef X
-  // (16,8), (32,8): the matrix-core sweep with the box QP inside (lqr_wave_mfma_backward<..., MPC>); per-trajectory
-  // termination, not inside the device-driven BoxDDP loop (no `done` flag there)
-  if (a.sync == nullptr && a.done == nullptr && !a.info_store && ((nx == 16 && nu == 8) || (nx == 32 && nu == 8)) &&
-      a.T >= 1 && !mpc_wave_disabled()) {
-    LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
-    s.mpc_controls = a.controls;
-    s.mpc_lower = a.lower;
-    s.mpc_upper = a.upper;
-    s.mpc_states = a.states;
-    s.mpc_n_qp_iter = a.n_qp_iter;
-    s.mpc_n_qp_total = a.n_qp_total;
-    return launch_mpc_wave_backward(nx, nu, s, stream);
-  }
-  // (12,4), (16,4): the sweep on the wide row kernel with the box QP inside (lqr_wide_kernel<..., MPC>: four trajectories per
-  // wavefront, matrix-core products; before, the runtime-dimension kernel - 2.0 ms at B = 4096, T = 50).  DMPC_NO_WIDE=1: that.
+  // (12,4), (16,4), (12,8), (16,8): the sweep on the wide row kernel with the box QP inside (lqr_wide_kernel<..., MPC>: four
+  // trajectories per wavefront, matrix-core products; before, the runtime-dimension kernel - 2.0 ms at (12,4), B = 4096, T = 50 -
+  // and, at (16,8), a wavefront per trajectory).  DMPC_NO_WIDE=1: those.
   {
     static const bool wide_off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
     if (!wide_off && a.sync == nullptr && sel == nullptr && a.B >= 4 && a.T >= 2 &&
@@ -230,9 +218,22 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, 2, 2, false, false, true>), dim3((s.B + 15) / 16), dim3(256), lds, stream, s); \
     return (int)hipGetLastError();                                                                             \
   }
-      X(12, 4) X(16, 4)
+      X(12, 4) X(16, 4) X(12, 8) X(16, 8)
 #undef X
     }
+  }
+  // (16,8), (32,8): the matrix-core sweep with the box QP inside (lqr_wave_mfma_backward<..., MPC>); per-trajectory
+  // termination, not inside the device-driven BoxDDP loop (no `done` flag there)
+  if (a.sync == nullptr && a.done == nullptr && !a.info_store && ((nx == 16 && nu == 8) || (nx == 32 && nu == 8)) &&
+      a.T >= 1 && !mpc_wave_disabled()) {
+    LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
+    s.mpc_controls = a.controls;
+    s.mpc_lower = a.lower;
+    s.mpc_upper = a.upper;
+    s.mpc_states = a.states;
+    s.mpc_n_qp_iter = a.n_qp_iter;
+    s.mpc_n_qp_total = a.n_qp_total;
+    return launch_mpc_wave_backward(nx, nu, s, stream);
   }
   auto wave_container = [&](int cnx, int cnu) {   // wider than the 16-lane containers: padded inside a wave instance
     LqrArgs s{a.T, a.B, a.C, a.c, a.F, a.f, nullptr, nullptr, a.Ks, a.ks, nullptr, nullptr, nullptr, nullptr, a.info};
