@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
   static_assert(NX % 4 == 0 && NU % 4 == 0, "tiles of four rows");
   static_assert((DB - 1) * Lay::kDmaB <= 63 && (DF - 1) * Lay::kDmaF <= 63, "ring too deep for vmcnt");
   static_assert(DF % 2 == 0, "two alternating register sets in the rollout");
-  static_assert(!MPC || (!PAD && !MASKED && NR == 2), "the MPC sweep: exact two-register shapes");
+  static_assert(!MPC || (!MASKED && NR == 2), "the MPC sweep: two-register shapes");
 
   if constexpr (MPC) {
     if (a.mpc_done != nullptr && *a.mpc_done != 0) return;  // uniform: the iLQR loop has stopped
@@ -283,16 +283,17 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
       if constexpr (MPC) {
         const size_t tbm = (size_t)(t < 0 ? 0 : t) * B + b;
 #pragma unroll
-        for (int q = 0; q < NU; ++q) {
-          m.uc[q] = a.mpc_controls[tbm * NU + q];
-          m.lb[q] = a.mpc_lower[tbm * NU + q];
-          m.ub[q] = a.mpc_upper[tbm * NU + q];
+        for (int q = 0; q < NU; ++q) {      // (PAD: an unused control reads control 0 - its box becomes [-1, 1] below)
+          const int qc = (!PAD || q < nu) ? q : 0;
+          m.uc[q] = a.mpc_controls[tbm * nu + qc];
+          m.lb[q] = a.mpc_lower[tbm * nu + qc];
+          m.ub[q] = a.mpc_upper[tbm * nu + qc];
         }
 #pragma unroll
         for (int h = 0; h < NR; ++h) {
-          const int col = 16 * h + lane;
-          m.tau[h] = 0.f;
-          if (a.mpc_states != nullptr && col < NS) m.tau[h] = col < NX ? a.mpc_states[tbm * NX + col] : a.mpc_controls[tbm * NU + (col - NX)];
+          m.tau[h] = 0.f;          // lc[h]: where this lane's column lies in [x; u] (-1: the affine column, padding)
+          if (a.mpc_states != nullptr && lc[h] >= 0)
+            m.tau[h] = lc[h] < nx ? a.mpc_states[tbm * nx + lc[h]] : a.mpc_controls[tbm * nu + (lc[h] - nx)];
         }
       }
     };
@@ -383,8 +384,9 @@ __global__ __launch_bounds__(256) void lqr_wide_kernel(const LqrArgs a) {
         });
         static_for<0, NU>([&](auto m) {
           qu[m.value] = G::template bcast<NS % 16>(Qu[m.value][AB]);
-          lo[m.value] = mcur.lb[m.value] - mcur.uc[m.value];
-          hi[m.value] = mcur.ub[m.value] - mcur.uc[m.value];
+          const bool used = !PAD || m.value < nu;     // (an unused control: qu = 0 in the box [-1, 1] - its QP solution is 0)
+          lo[m.value] = used ? mcur.lb[m.value] - mcur.uc[m.value] : -1.f;
+          hi[m.value] = used ? mcur.ub[m.value] - mcur.uc[m.value] : 1.f;
           kt[m.value] = kprev[m.value];
         });
         PnqpResult<NU> qp;

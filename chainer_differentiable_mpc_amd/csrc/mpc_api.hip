@@ -220,6 +220,23 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   }
       X(12, 4) X(16, 4) X(12, 8) X(16, 8)
 #undef X
+      // ... and padded inside the smallest of those instances: every other shape with at most 16 states, 8 controls and
+      // nx + nu >= 16 (no 16-lane container), whole wavefronts
+      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && nx + nu >= 16 && a.B % 4 == 0 && !mpc_container_disabled()) {
+        s.nx_log = nx;
+        s.nu_log = nu;
+#define X(NX_, NU_)                                                                                            \
+  if (nx <= NX_ && nu <= NU_) {                                                                                \
+    constexpr size_t lds = LqrWideLayout<NX_, NU_, 2, 2>::lds_bytes();                                         \
+    if (lds > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, 2, 2, true, false, true>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+    DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, 2, 2, true, false, true>), dim3((s.B + 15) / 16), dim3(256), lds, stream, s); \
+    return (int)hipGetLastError();                                                                             \
+  }
+        X(12, 4) X(16, 4) X(12, 8) X(16, 8)
+#undef X
+      }
     }
   }
   // (16,8), (32,8): the matrix-core sweep with the box QP inside (lqr_wave_mfma_backward<..., MPC>); per-trajectory
@@ -389,6 +406,22 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   }
       X(12, 4) X(16, 4) X(12, 8) X(16, 8)
 #undef X
+      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && nx + nu >= 16 && a.B % 4 == 0 && !mpc_container_disabled()) {
+        MpcFwdArgs p = a;     // ... and padded inside the smallest of those instances (as the sweep)
+        p.nx_log = nx;
+        p.nu_log = nu;
+#define X(NX_, NU_)                                                                                            \
+  if (nx <= NX_ && nu <= NU_) {                                                                                \
+    using Lay = MpcWideFwdLayout<NX_, NU_, 2>;                                                                 \
+    if (Lay::lds_bytes() > 64 * 1024)                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc_wide_forward_kernel<NX_, NU_, 2, true>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+    DMPC_LAUNCH_GGL((mpc_wide_forward_kernel<NX_, NU_, 2, true>), dim3((p.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, p); \
+    return (int)hipGetLastError();                                                                             \
+  }
+        X(12, 4) X(16, 4) X(12, 8) X(16, 8)
+#undef X
+      }
     }
   }
   if (a.dyn_kind == 0 && !mpc_container_disabled()) {

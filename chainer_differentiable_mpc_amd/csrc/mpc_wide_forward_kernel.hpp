@@ -11,6 +11,7 @@
 #pragma once
 #include "dma_gather.hpp"
 #include "lqr_dma_kernel.hpp"   // lds_byte_address, wait_vmcnt
+#include "lqr_wide_kernel.hpp"  // padded_read
 #include "mpc_kernels.hpp"
 
 namespace dmpc {
@@ -24,10 +25,13 @@ struct MpcWideFwdLayout {
   static constexpr int CH_END = CH_x + NX;
   static constexpr int kDma = (CH_END + 63) / 64;   // gather DMAs per step; padding lanes repeat chunk 0 of C
   static constexpr int SLOT = kDma * 256;           // floats per wave and timestep
-  static constexpr size_t lds_bytes() { return (size_t)4 * DB * SLOT * 4; }
+  static constexpr size_t lds_bytes() { return (size_t)4 * DB * SLOT * 4 + 64; }   // + a zero per wave (PAD)
 };
 
-template <int NX, int NU, int DB>
+// PAD: container for a smaller problem (a.nx_log <= NX, a.nu_log <= NU; lqr_wide_kernel<..., PAD>): the arrays come into
+// container-sized regions of the slot as they are, the reads place element i of tau at lane i (state) or NX + m (control),
+// everything outside the problem is 0 and the unused controls stay 0 inside the box [-1, 1].  Needs B % 4 == 0.
+template <int NX, int NU, int DB, bool PAD = false>
 __global__ __launch_bounds__(256) void mpc_wide_forward_kernel(const MpcFwdArgs a) {
   using Lay = MpcWideFwdLayout<NX, NU, DB>;
   using G = Group<16>;
@@ -52,10 +56,18 @@ __global__ __launch_bounds__(256) void mpc_wide_forward_kernel(const MpcFwdArgs 
   float *ring = lds + wave * (DB * Lay::SLOT);
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
 
-  const bool is_x = lane < NX;
+  float *zo = lds + 4 * (DB * Lay::SLOT) + wave * 4;   // PAD: a zero for the padded reads (this wave's own)
+  if constexpr (PAD) {
+    if (lane64 == 0) zo[0] = 0.f;
+  }
+  // the problem's own dimensions, and where container element e of tau lies in them (-1: padding)
+  const int nx = PAD ? a.nx_log : NX, nu = PAD ? a.nu_log : NU, ns = nx + nu;
+  auto logical = [&](int e) -> int { return e < NX ? (e < nx ? e : -1) : (e - NX < nu ? nx + (e - NX) : -1); };
+  const bool is_x = lane < nx;
   const bool is_t1 = lane < N1;                 // this lane holds an element of tau / a row of C in its second register
-  const int lane_x = is_x ? lane : NX - 1;      // clamped: rows re-read by the idle lanes, never used
+  const int lane_x = is_x ? lane : nx - 1;      // clamped: rows re-read by the idle lanes, never used
   const int e1 = is_t1 ? 16 + lane : NS - 1;    // element / row of the second register (clamped)
+  const int le0 = PAD ? logical(lane) : lane, le1 = PAD ? (is_t1 ? logical(e1) : -1) : e1;   // ... in the problem's own numbering
 
   // per-lane source pointers of the gather groups at t = 0 (32-bit time strides: the launcher checks them); F and f have
   // T - 1 slices: on the last advance their lanes stay (the step t = T - 1 fetches slice T - 2 again, never consumed)
@@ -65,20 +77,22 @@ __global__ __launch_bounds__(256) void mpc_wide_forward_kernel(const MpcFwdArgs 
   for (int q = 0; q < Lay::kDma; ++q) {
     const int g = q * 64 + lane64;
     const char *base = (const char *)a.C;
-    size_t per = (size_t)NS * NS * 4;
+    size_t per = (size_t)ns * ns * 4;
     int g0 = g;   // absent arrays and padding lanes: chunk 0 of C again
     bool isF = false;
     if (g < Lay::CH_c) { g0 = Lay::CH_C; }
-    else if (g < Lay::CH_F) { base = (const char *)a.c; per = (size_t)NS * 4; g0 = Lay::CH_c; }
-    else if (g < Lay::CH_f) { base = (const char *)a.F; per = (size_t)NX * NS * 4; g0 = Lay::CH_F; isF = true; }
-    else if (g < Lay::CH_K) { if (has_f) { base = (const char *)a.f; per = (size_t)NX * 4; g0 = Lay::CH_f; isF = true; } }
-    else if (g < Lay::CH_k) { base = (const char *)a.Ks; per = (size_t)NU * NX * 4; g0 = Lay::CH_K; }
-    else if (g < Lay::CH_u) { base = (const char *)a.ks; per = (size_t)NU * 4; g0 = Lay::CH_k; }
-    else if (g < Lay::CH_lo) { base = (const char *)a.controls; per = (size_t)NU * 4; g0 = Lay::CH_u; }
-    else if (g < Lay::CH_hi) { base = (const char *)a.lower; per = (size_t)NU * 4; g0 = Lay::CH_lo; }
-    else if (g < Lay::CH_x) { base = (const char *)a.upper; per = (size_t)NU * 4; g0 = Lay::CH_hi; }
-    else if (g < Lay::CH_END) { base = (const char *)a.states; per = (size_t)NX * 4; g0 = Lay::CH_x; }
-    ptr0[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)(g - g0) * 16 - (unsigned long long)(q % 4) * 1024u;
+    else if (g < Lay::CH_F) { base = (const char *)a.c; per = (size_t)ns * 4; g0 = Lay::CH_c; }
+    else if (g < Lay::CH_f) { base = (const char *)a.F; per = (size_t)nx * ns * 4; g0 = Lay::CH_F; isF = true; }
+    else if (g < Lay::CH_K) { if (has_f) { base = (const char *)a.f; per = (size_t)nx * 4; g0 = Lay::CH_f; isF = true; } }
+    else if (g < Lay::CH_k) { base = (const char *)a.Ks; per = (size_t)nu * nx * 4; g0 = Lay::CH_K; }
+    else if (g < Lay::CH_u) { base = (const char *)a.ks; per = (size_t)nu * 4; g0 = Lay::CH_k; }
+    else if (g < Lay::CH_lo) { base = (const char *)a.controls; per = (size_t)nu * 4; g0 = Lay::CH_u; }
+    else if (g < Lay::CH_hi) { base = (const char *)a.lower; per = (size_t)nu * 4; g0 = Lay::CH_lo; }
+    else if (g < Lay::CH_x) { base = (const char *)a.upper; per = (size_t)nu * 4; g0 = Lay::CH_hi; }
+    else if (g < Lay::CH_END) { base = (const char *)a.states; per = (size_t)nx * 4; g0 = Lay::CH_x; }
+    // (PAD: every array sits at the start of its container-sized region; the chunks behind its end fetch its chunk 0 again)
+    const int gc = (!PAD || (size_t)(g - g0) * 16 < 4 * per) ? g - g0 : 0;
+    ptr0[q] = (unsigned long long)base + (size_t)b0 * per + (size_t)gc * 16 - (unsigned long long)(q % 4) * 1024u;
     str[q] = (unsigned)(B * per);
     dynF |= isF ? (1u << q) : 0u;
   }
@@ -101,32 +115,56 @@ __global__ __launch_bounds__(256) void mpc_wide_forward_kernel(const MpcFwdArgs 
     }
   };
   // per-lane LDS indices (floats, relative to a slot)
-  const int i_x = Lay::CH_x * 4 + r * NX + lane_x;
-  const int i_K = Lay::CH_K * 4 + r * NU * NX + lane_x;                         // + m * NX: K[m][lane_x]
-  const int i_C0 = Lay::CH_C * 4 + (r * NS + lane) * NS, i_C1 = Lay::CH_C * 4 + (r * NS + e1) * NS;
-  const int i_c0 = Lay::CH_c * 4 + r * NS + lane, i_c1 = Lay::CH_c * 4 + r * NS + e1;
-  const int i_F = Lay::CH_F * 4 + (r * NX + lane_x) * NS, i_f = Lay::CH_f * 4 + r * NX + lane_x;
+  const int i_x = Lay::CH_x * 4 + r * nx + lane_x;
+  const int i_K = Lay::CH_K * 4 + r * nu * nx + lane_x;                         // + m * nx: K[m][lane_x]
+  const int r0 = le0 >= 0 ? le0 : 0, r1 = le1 >= 0 ? le1 : 0;                   // this lane's rows of C (clamped)
+  const int i_C0 = Lay::CH_C * 4 + (r * ns + r0) * ns, i_C1 = Lay::CH_C * 4 + (r * ns + r1) * ns;
+  const int i_c0 = Lay::CH_c * 4 + r * ns + r0, i_c1 = Lay::CH_c * 4 + r * ns + r1;
+  const int i_F = Lay::CH_F * 4 + (r * nx + lane_x) * ns, i_f = Lay::CH_f * 4 + r * nx + lane_x;
 
   float xt, kvx[NU], ksv[NU], uc[NU], lb[NU], ub[NU], Crow0[NS], Crow1[NS], c0, c1, Frow[NS], fi;
   auto read_slot = [&](const float *slot) __attribute__((always_inline)) {
     xt = slot[i_x];
-#pragma unroll
-    for (int m = 0; m < NU; ++m) {
-      kvx[m] = slot[i_K + m * NX];
-      ksv[m] = slot[Lay::CH_k * 4 + r * NU + m];
-      uc[m] = slot[Lay::CH_u * 4 + r * NU + m];
-      lb[m] = slot[Lay::CH_lo * 4 + r * NU + m];
-      ub[m] = slot[Lay::CH_hi * 4 + r * NU + m];
-    }
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-      Crow0[j] = slot[i_C0 + j];
-      Crow1[j] = slot[i_C1 + j];
-      Frow[j] = slot[i_F + j];
-    }
+    static_for<0, NU>([&](auto m) {
+      if constexpr (PAD) {   // an unused control: K = 0, k = 0, u = 0 in the box [-1, 1]
+        const bool used = m.value < nu;   // uniform
+        const int mc = used ? m.value : 0;
+        kvx[m.value] = padded_read(slot + i_K + mc * nx, used, zo);
+        ksv[m.value] = padded_read(slot + Lay::CH_k * 4 + r * nu + mc, used, zo);
+        uc[m.value] = padded_read(slot + Lay::CH_u * 4 + r * nu + mc, used, zo);
+        const float l_ = slot[Lay::CH_lo * 4 + r * nu + mc], u_ = slot[Lay::CH_hi * 4 + r * nu + mc];
+        lb[m.value] = used ? l_ : -1.f;
+        ub[m.value] = used ? u_ : 1.f;
+      } else {
+        kvx[m.value] = slot[i_K + m.value * NX];
+        ksv[m.value] = slot[Lay::CH_k * 4 + r * NU + m.value];
+        uc[m.value] = slot[Lay::CH_u * 4 + r * NU + m.value];
+        lb[m.value] = slot[Lay::CH_lo * 4 + r * NU + m.value];
+        ub[m.value] = slot[Lay::CH_hi * 4 + r * NU + m.value];
+      }
+    });
+    static_for<0, NS>([&](auto j) {
+      if constexpr (PAD) {
+        const int lj = logical(j.value);   // uniform
+        const int jc = lj >= 0 ? lj : 0;
+        Crow0[j.value] = padded_read(slot + i_C0 + jc, lj >= 0 && le0 >= 0, zo);
+        Crow1[j.value] = padded_read(slot + i_C1 + jc, lj >= 0 && le1 >= 0, zo);
+        Frow[j.value] = padded_read(slot + i_F + jc, lj >= 0 && is_x, zo);
+      } else {
+        Crow0[j.value] = slot[i_C0 + j.value];
+        Crow1[j.value] = slot[i_C1 + j.value];
+        Frow[j.value] = slot[i_F + j.value];
+      }
+    });
     c0 = slot[i_c0];
     c1 = slot[i_c1];
     fi = has_f ? slot[i_f] : 0.f;
+    if constexpr (PAD) {
+      xt = is_x ? xt : 0.f;
+      c0 = le0 >= 0 ? c0 : 0.f;
+      c1 = le1 >= 0 ? c1 : 0.f;
+      fi = is_x ? fi : 0.f;
+    }
   };
   // (row . v): the elements of v broadcast from their lanes, two chains
   auto row_dot = [&](const float (&row)[NS], const float (&v)[2], float init) __attribute__((always_inline)) {
@@ -165,7 +203,7 @@ __global__ __launch_bounds__(256) void mpc_wide_forward_kernel(const MpcFwdArgs 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int e = h == 0 ? lane : e1;
-        valid[h] = h == 0 ? true : is_t1;       // (NS > 16: every lane holds an element in its first register)
+        valid[h] = PAD ? (h == 0 ? le0 >= 0 : le1 >= 0) : (h == 0 ? true : is_t1);   // this register holds an element of tau
         float tv = e < NX ? xh : 0.f, t0v = e < NX ? xt : 0.f;
         if (h == 1 && NX == 16) { tv = 0.f; t0v = 0.f; }   // (the second register holds controls only)
 #pragma unroll
@@ -189,13 +227,14 @@ __global__ __launch_bounds__(256) void mpc_wide_forward_kernel(const MpcFwdArgs 
       float obj = 0.f;
       if (a.objs != nullptr) obj = group_sum<16>(obj_l);
       if (searching) {  // outputs are overwritten by later passes; the last one is the accepted one
-        if (is_x) a.x[tb * NX + lane] = xh;
-        if (lane >= NX) a.u[tb * NU + (lane - NX)] = tau[0];                     // (NS > 16: lanes NX..15 hold controls)
-        if (is_t1 && e1 >= NX) a.u[tb * NU + (e1 - NX)] = tau[1];
+        const bool u0 = valid[0] && lane >= NX, u1 = valid[1] && e1 >= NX;      // this register holds a control: lanes NX.. / 16 + lane
+        if (is_x) a.x[tb * nx + lane] = xh;
+        if (u0) a.u[tb * nu + (lane - NX)] = tau[0];
+        if (u1) a.u[tb * nu + (e1 - NX)] = tau[1];
         if (a.objs != nullptr && lane == 0) a.objs[tb] = obj;
         if (a.u_first != nullptr && pass_idx == 0) {
-          if (lane >= NX) a.u_first[tb * NU + (lane - NX)] = tau[0];
-          if (is_t1 && e1 >= NX) a.u_first[tb * NU + (e1 - NX)] = tau[1];
+          if (u0) a.u_first[tb * nu + (lane - NX)] = tau[0];
+          if (u1) a.u_first[tb * nu + (e1 - NX)] = tau[1];
         }
       }
       if (t < T - 1) {  // new_x_{t+1} = F_t [new_x; new_u] + f_t under the TRUE dynamics   :229-236
