@@ -35,12 +35,14 @@ struct CostateWideLayout {
   static constexpr int kDma = (CH_END + 63) / 64;
   static constexpr int SLOT = kDma * 256;           // floats per wave and timestep (whole 1 KB pieces)
   static constexpr int SCR = 4 * NS * NS;           // output staging, floats per wave: dF rows, then dC rows (one buffer)
-  static constexpr size_t lds_bytes() { return (size_t)4 * (DB * SLOT + SCR) * 4 + 64; }   // + a zero per wave (PAD)
+  // per workgroup of `waves` wavefronts (+ a zero per wave for the PAD reads).  The padded (16,8) instance does not fit a CU's
+  // LDS with four wavefronts per workgroup (173 KB): it runs with three - the kernel is bound by memory, not by SIMDs
+  static constexpr size_t lds_bytes(int waves = 4) { return (size_t)waves * (DB * SLOT + SCR) * 4 + 64; }
   static_assert((NX * NS) % 4 == 0, "a trajectory's state rows of C are whole 16-byte chunks");
 };
 
-template <int NX, int NU, int DB, bool PAD = false>
-__global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) {
+template <int NX, int NU, int DB, bool PAD = false, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void costate_wide_kernel(const CostateArgs a) {
   using Lay = CostateWideLayout<NX, NU, DB, PAD>;
   using G = Group<16>;
   constexpr int NS = NX + NU, N1 = NS - 16;      // elements of tau in the second register
@@ -53,16 +55,16 @@ __global__ __launch_bounds__(256) void costate_wide_kernel(const CostateArgs a) 
   const int lane64 = threadIdx.x & 63;
   const int r = lane64 >> 4;  // trajectory within the wave
   const int lane = lane64 & 15;
-  int b0 = ((int)blockIdx.x * 4 + wave) * 4;
+  int b0 = ((int)blockIdx.x * WPB + wave) * 4;
   if (b0 > a.B - 4) b0 = a.B - 4;  // the last wave overlaps its neighbour instead of running ragged (same results twice)
   b0 = __builtin_amdgcn_readfirstlane(b0);
   const int b = b0 + r;
 
   extern __shared__ float lds[];
   float *ring = lds + wave * (DB * Lay::SLOT);
-  float *scr = lds + 4 * (DB * Lay::SLOT) + wave * Lay::SCR;
+  float *scr = lds + WPB * (DB * Lay::SLOT) + wave * Lay::SCR;
   const unsigned ring_addr = __builtin_amdgcn_readfirstlane(lds_byte_address(ring));
-  float *zo = lds + 4 * (DB * Lay::SLOT + Lay::SCR) + wave * 4;   // PAD: a zero for the padded reads (this wave's own)
+  float *zo = lds + WPB * (DB * Lay::SLOT + Lay::SCR) + wave * 4;   // PAD: a zero for the padded reads (this wave's own)
   if constexpr (PAD) {
     if (lane64 == 0) zo[0] = 0.f;
   }

@@ -101,9 +101,7 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
       DMPC_COSTATE_WIDE_SHAPES(X)
 #undef X
-      // ... and padded inside the (16,4) or (12,8) instance: the shapes without a 16-lane container (nx + nu >= 16) that fit one
-      // (the (16,8) instance's ring and staging buffer do not fit a CU's LDS: 13+ states with 5+ controls keep the wavefront
-      // container below)
+      // ... and padded inside the (16,4), (12,8) or (16,8) instance: the shapes without a 16-lane container (nx + nu >= 16)
       static const bool no_pad = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
       if (!no_pad && nx + nu >= 16 && nx >= 1 && nu >= 1) {
         CostateArgs p = a;
@@ -121,6 +119,16 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
         DMPC_COSTATE_WIDE_CONTAINERS(X)
 #undef X
+        if (nx <= 16 && nu <= 8) {   // 13+ states with 5+ controls: the (16,8) instance, three wavefronts per workgroup (LDS)
+          using Lay = CostateWideLayout<16, 8, 2, true>;
+          constexpr int kWaves = 3;
+          static_assert(Lay::lds_bytes(kWaves) <= 160 * 1024, "ring and staging beyond a CU's LDS");
+          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_wide_kernel<16, 8, 2, true, kWaves>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes(kWaves));
+          DMPC_LAUNCH_GGL((costate_wide_kernel<16, 8, 2, true, kWaves>), dim3((p.B + 4 * kWaves - 1) / (4 * kWaves)),
+                          dim3(64 * kWaves), Lay::lds_bytes(kWaves), stream, p);
+          return (int)hipGetLastError();
+        }
       }
     }
   }

@@ -17,8 +17,10 @@
 // rollout through its ring with F and f: at these sizes they do not fit next to the rings.
 //
 // Same arithmetic as lqr_kernel / lqr_dma_kernel with the row Gauss-Jordan of riccati_blocks.hpp (LAPACK's pivot choice).
-// Needs B >= 4, 16-byte aligned arrays, the workspace.  Plain solve only: LQR_active, the separate sweeps and the co-state
-// kernels of these shapes stay where they were (containers).
+// Needs B >= 4, 16-byte aligned arrays, the workspace.  Forms (template flags, see below): PAD - a container for every
+// smaller shape without a 16-lane kernel; MASKED - LQR_active; MPC - MPCstep.backward_rec with the box QP inside (no rollout).
+// The separate sweeps (LqrRecursion.backward() / forward()) of these shapes stay on the containers; the layout's co-state
+// sweep is costate_wide_kernel.hpp, its line search mpc_wide_forward_kernel.hpp.
 #pragma once
 #include "colwise.hpp"
 #include "dma_gather.hpp"

@@ -78,7 +78,8 @@ def test_container_shapes_against_oracle(dims, strict):
         assert_close(npy(got), want, TOLS[key], key)
 
 
-@pytest.mark.parametrize("dims", [(16, 4), (16, 8), (12, 8), (13, 3), (15, 1), (14, 2), (10, 6), (9, 8), (8, 8), (12, 5), (12, 4), (16, 2)],
+@pytest.mark.parametrize("dims", [(16, 4), (16, 8), (12, 8), (13, 3), (15, 1), (14, 2), (10, 6), (9, 8), (8, 8), (12, 5), (12, 4), (16, 2),
+                                  (15, 7), (13, 5), (16, 6)],
                          ids=lambda d: "%dx%d" % d)
 @pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
 def test_wide_costate_kernel_against_oracle(dims, strict):
@@ -98,7 +99,7 @@ def test_wide_costate_kernel_against_oracle(dims, strict):
         node = DiffLqr(T, B, nx, nu, strict_math=strict)
         node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
         out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
-        inst = dims if dims in ((16, 4), (16, 8), (12, 8)) else ((16, 4) if nu <= 4 else (12, 8))   # (padded inside these)
+        inst = dims if dims in ((16, 4), (16, 8), (12, 8)) else ((16, 4) if nu <= 4 else ((12, 8) if nx <= 12 else (16, 8)))   # (padded inside these)
         assert _lib.last_kernel_name().startswith("void dmpc::costate_wide_kernel<%d, %d" % inst)
         for got, want, key in zip(out, ref, KEYS):
             assert_close(npy(got), want, TOLS[key], key)
