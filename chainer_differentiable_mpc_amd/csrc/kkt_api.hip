@@ -66,11 +66,15 @@ bool costate_sums_available(int T, int B, int nx, int nu) {
 
 int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   if (a.dC_sum != nullptr && !costate_sums_available(a.T, a.B, nx, nu)) return DMPC_E_UNSUPPORTED;
+  // the LDS-DMA kernels move 16-byte chunks and store their rows as float4: every array they touch that way must be aligned
+  // (the entry points check C, c, F, dC, dF; the rest are the caller's tensors - a misaligned view takes the other kernels)
+  const bool al = aligned16(a.C) && aligned16(a.c) && aligned16(a.r) && aligned16(a.F) && aligned16(a.x) && aligned16(a.u) &&
+                  aligned16(a.dx) && aligned16(a.du) && aligned16(a.dC) && aligned16(a.dF);
 #define X(NX_, NU_, L_)                                                                                     \
   if (nx == NX_ && nu == NU_) {                                                                             \
     constexpr int GPB = 256 / L_;                                                                           \
     if constexpr (L_ == 16) { /* inputs staged through an LDS-DMA ring (costate_dma_kernel.hpp) */          \
-      if (a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled()) {                                                \
+      if (al && a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled()) {                                          \
         using Lay = CostateDmaLayout<NX_, NU_, kCostateDmaDepth>;                                           \
         const int waves = (a.B + 3) / 4;                                                                    \
         DMPC_LAUNCH_GGL((costate_dma_kernel<NX_, NU_, kCostateDmaDepth>), dim3((waves + 3) / 4), dim3(256), \
@@ -87,7 +91,7 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   // (costate_wide_kernel.hpp; before, a wavefront per trajectory inside the (16,8) container).  DMPC_NO_WIDE=1: that path.
   {
     static const bool off = [] { const char *e = getenv("DMPC_NO_WIDE"); return e && e[0] == '1'; }();
-    if (!off && a.dC_sum == nullptr && a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled() &&
+    if (!off && al && a.dC_sum == nullptr && a.B >= 4 && a.B % 4 == 0 && a.T >= 2 && !costate_dma_disabled() &&
         (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31)) {
 #define X(NX_, NU_)                                                                                            \
   if (nx == NX_ && nu == NU_) {                                                                                \

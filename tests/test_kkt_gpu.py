@@ -105,6 +105,31 @@ def test_wide_costate_kernel_against_oracle(dims, strict):
             assert_close(npy(got), want, TOLS[key], key)
 
 
+@pytest.mark.parametrize("dims", [(8, 2), (16, 4), (13, 3), (16, 8)], ids=lambda d: "%dx%d" % d)
+def test_misaligned_solution_views_give_the_aligned_result(dims):
+    """x, u and the upstream gradients four bytes off a 16-byte boundary (contiguous views the C-ABI accepts): the LDS-DMA
+    co-state kernels need 16-byte chunks, so these calls take the other kernels - same numbers within the parity bar."""
+    nx, nu = dims
+    B, T = 8, 7
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=300 + nx)
+    d = to_dev(p)
+    x, u = solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu)[:2]
+    g = torch.Generator(device="cpu").manual_seed(nx * 7 + nu)
+    gx, gu = torch.randn(T, B, nx, generator=g).cuda(), torch.randn(T, B, nu, generator=g).cuda()
+
+    def off(t):
+        buf = torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device)
+        v = buf[1:].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4 and v.is_contiguous()
+        return v
+    want = kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu)
+    got = kkt_grad_device(d["C"], d["c"], d["F"], off(x), off(u), off(gx), off(gu), T, nx, nu)
+    torch.cuda.synchronize()
+    for a, b, key in zip(got, want, KEYS):
+        assert_close(npy(a), npy(b), TOLS[key], key)
+
+
 def test_autograd_through_lqrnet_reproduces_the_notebook_anchor():
     """examples/LQRnet.ipynb:184 - loss 0.661925 at iteration 0, dynamics mse 4.774785 after the first
     RMSprop step - with forward AND backward on the HIP path, driven by torch.autograd."""
