@@ -125,6 +125,19 @@ __device__ __forceinline__ void wave_dma_region(const void *src, unsigned dst, u
   });
 }
 
+// a contiguous run of `floats` >= 1 floats at `src` (wave-uniform, any 4-byte alignment, a run-time length) -> LDS byte address
+// `dst`: 64 floats per instruction.  Lanes past the end read the last float again; their LDS words are padding (the regions
+// of a container's slot are whole multiples of 64 floats).
+__device__ __forceinline__ void wave_dma_run(const float *src, unsigned dst, int floats, int lane) {
+  const unsigned long long base = reinterpret_cast<unsigned long long>(src);
+  for (int o = 0; o < floats; o += 64) {   // uniform
+    set_m0(dst + o * 4);
+    const int e = o + lane;
+    const unsigned voff = (unsigned)(e < floats ? e : floats - 1) * 4u;
+    asm volatile("global_load_lds_dword %0, %1" DMPC_WAVE_DMA_POLICY ::"v"(voff), "s"(base) : "memory");
+  }
+}
+
 // Closed-loop rollout (LqrRecursion.forward, lqr/lqr_recursion.py:160-200) by the wavefront that has just finished the
 // backward sweep of the same trajectory: while it waits on memory here, the other wavefront of its SIMD is in the
 // compute-bound sweep of ANOTHER trajectory, so the bandwidth-bound and the compute-bound halves of the solve overlap
@@ -371,7 +384,11 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
   // ---- the input slot of this wavefront: [C_t | c_t | F_t | f_t] as they lie in HBM, filled by LDS-DMA a step ahead
   constexpr int kSlotC = 0, kSlotc = NS * NS, kSlotF = kSlotc + NS, kSlotf = kSlotF + NX * NS, kSlotFloats = kSlotf + NX;
   static_assert((NS * NS) % 4 == 0 && NS % 4 == 0 && (NX * NS) % 4 == 0 && NX % 4 == 0, "16-byte regions");
-  __shared__ __attribute__((aligned(16))) float slot_all[4][kSlotFloats];
+  // PAD: the same four regions at the PROBLEM's sizes and strides, each in its own multiple of 64 floats (wave_dma_run),
+  // and a word of zero for the lanes and rows outside the problem
+  constexpr int kPadC = 0, kPadc = (NS * NS + 63) / 64 * 64, kPadF = kPadc + 64, kPadf = kPadF + (NX * NS + 63) / 64 * 64,
+                kPadZero = kPadf + 64, kPadFloats = kPadZero + 4;
+  __shared__ __attribute__((aligned(16))) float slot_all[4][PAD ? kPadFloats : kSlotFloats];
   float *slot = slot_all[threadIdx.x >> 6];
   const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot);   // LDS byte address (low 32 bits of the pointer)
   const unsigned voff16 = lane * 16;
@@ -416,6 +433,58 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
       unsigned bits = 0;
 #pragma unroll
       for (int m = 0; m < NU; ++m) bits |= (a.mask[tb * NU + m] != 0 ? 1u : 0u) << m;
+      k.act = __builtin_amdgcn_readfirstlane(bits);
+    }
+  };
+  auto dma_issue_pad = [&](int t) {
+    const size_t tb = (size_t)t * B + b;
+    wave_dma_run(a.C + tb * ns * ns, slot_addr + kPadC * 4, ns * ns, lane);
+    wave_dma_run(a.c + tb * ns, slot_addr + kPadc * 4, ns, lane);
+    if (t < T - 1) {   // uniform
+      wave_dma_run(a.F + tb * nx * ns, slot_addr + kPadF * 4, nx * ns, lane);
+      if (has_f) wave_dma_run(a.f + tb * nx, slot_addr + kPadf * 4, nx, lane);
+    }
+  };
+  // slot -> bank at the container's positions: a lane's element of logical row li is at base + li * stride, where a column
+  // of the problem has (its column, ns), the affine lane (the c / f region, 1), every other lane (the zero word, 0) - the
+  // ADDRESS is selected, so every lane executes the same loads
+  auto read_bank_pad = [&](int t, Bank &k) {
+    const int c_base = lcol >= 0 ? kPadC + lcol : (col_aff ? kPadc : kPadZero);
+    const int f_base = lcol >= 0 ? kPadF + lcol : ((col_aff && has_f) ? kPadf : kPadZero);
+    int stride = lcol >= 0 ? ns : (col_aff ? 1 : 0), f_stride = lcol >= 0 ? ns : ((col_aff && has_f) ? 1 : 0);
+    // (opaque per step: the 72 addresses are loop invariants the compiler would otherwise keep in 72 registers)
+    asm volatile("" : "+v"(stride), "+v"(f_stride));
+    static_for<0, NS>([&](auto i) {
+      const int li = logical(i.value);   // uniform
+      float v = (i.value >= NX && lane == i.value) ? 1.f : 0.f;   // (row of an unused control: the unit diagonal)
+      if (li >= 0) v = slot[c_base + li * stride];
+      k.Q4[i.value / 4][i.value % 4] = v;
+    });
+    if (t < T - 1) {
+      static_for<0, NX>([&](auto r) {
+        float v = 0.f;
+        if (r.value < nx) v = slot[f_base + r.value * f_stride];   // uniform
+        k.Fc[r.value] = v;
+      });
+    }
+    if constexpr (MPC && PAD) {
+      if (a.mpc_states != nullptr) {   // the re-centring's row of C for this lane (container positions; 0 outside the problem)
+        const int crow_base = lcol >= 0 ? kPadC + lcol * ns : kPadZero;
+        int crow_step = lcol >= 0 ? 1 : 0;
+        asm volatile("" : "+v"(crow_step));
+        static_for<0, NS>([&](auto kk) {
+          const int lk = logical(kk.value);   // uniform
+          float v = 0.f;
+          if (lk >= 0) v = slot[crow_base + lk * crow_step];
+          crow_pad[kk.value] = v;
+        });
+      }
+    }
+    if constexpr (MASKED) {
+      const size_t tb = (size_t)t * B + b;
+      unsigned bits = 0;
+#pragma unroll
+      for (int m = 0; m < NU; ++m) bits |= (m < nu && a.mask[tb * nu + (m < nu ? m : 0)] != 0 ? 1u : 0u) << m;
       k.act = __builtin_amdgcn_readfirstlane(bits);
     }
   };
@@ -650,11 +719,28 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
 #if !DMPC_WAVE_PREFETCH
   if constexpr (PAD) {
     Bank kp;
+#if DMPC_WAVE_DMA
+#pragma unroll
+    for (int r = 0; r < NX; ++r) kp.Fc[r] = 0.f;
+    kp.act = 0;
+    if (lane == 0) slot[kPadZero] = 0.f;
+    dma_issue_pad(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the slot has landed (requested a whole step ago)
+      read_bank_pad(t, kp);
+      if (t > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and has been read: it can take the next step's inputs
+        dma_issue_pad(t - 1);
+      }
+      step(t, kp, kp);
+    }
+#else
     for (int t = T - 1; t >= 0; --t) {
       fetch_cost(t, kp);
       fetch_dyn(t, kp);
       step(t, kp, kp);
     }
+#endif
     if constexpr (MPC) {
       if (live && lane == 0) a.mpc_n_qp_total[b] = n_qp_total;
     }
