@@ -50,15 +50,21 @@ int launch_mpc_wave_container_backward(int cnx, int cnu, const LqrArgs &a, hipSt
   return DMPC_E_UNSUPPORTED;
 }
 
+// The sweep runs in the smallest instance that holds the problem (fewest columns first), whichever container the caller's
+// forward-only kernel is: the gains travel at the problem's own strides.  Measured and dropped (round 4, B = 4096, T = 50):
+// a test of rows and tiles at run time instead (uniform branches around the matrix-core blocks of one (32,8) instance:
+// (31,8) 1.43 -> 1.62 ms), and a rollout in the same launch with one 4-byte load per row element at the problem's
+// strides ((20,6) 0.96 -> 1.18 ms; the forward-only container kernel of lqr_kernels.hpp stays a launch of its own).
 int launch_lqr_wave_container_sweep(int cnx, int cnu, bool masked, const LqrArgs &a, hipStream_t stream) {
   const dim3 grid((a.B + 3) / 4), block(256);
+  if (a.nx_log > cnx || a.nu_log > cnu) return DMPC_E_BADARG;
 #define X(NX_, NU_)                                                                                                \
-  if (cnx == NX_ && cnu == NU_) {                                                                                  \
+  if (a.nx_log <= NX_ && a.nu_log <= NU_) {                                                                        \
     if (masked) DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, true, false, true>), grid, block, 0, stream, a);  \
     else DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, false, false, true>), grid, block, 0, stream, a);        \
     return (int)hipGetLastError();                                                                                 \
   }
-  X(16, 8) X(32, 8)
+  X(16, 8) X(24, 4) X(24, 8) X(32, 4) X(32, 8)
 #undef X
   return DMPC_E_UNSUPPORTED;
 }

@@ -138,6 +138,7 @@ def main():
              (4096, 50, 4, 4, False, None), (4096, 50, 8, 4, False, None), (4096, 50, 12, 3, False, None),
              (4096, 50, 3, 1, False, None), (2048, 50, 5, 5, False, None), (1024, 50, 16, 4, False, None),
              (1024, 50, 20, 6, False, None), (1024, 50, 31, 7, False, None), (1024, 50, 24, 8, True, None),
+             (1024, 50, 17, 4, False, None), (1024, 50, 28, 3, False, None),
              (4096, 100, 8, 2, False, None), (4096, 200, 8, 2, False, None), (4096, 60, 8, 2, False, None),
              # the wide row kernel: exact and padded instances (lqr_wide_kernel.hpp)
              (4096, 50, 16, 4, False, None), (4096, 50, 12, 8, False, None), (4096, 50, 13, 3, False, None),

@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from chainer_differentiable_mpc_amd import _lib
 from chainer_differentiable_mpc_amd.lqr_recursion import solve_device
-# SHAPES="4x4,8x4,12x3" sweeps shapes at B=4096, T=50 instead (algorithmic bytes 4(ns^2 + ns + nx ns + nx + ns) per timestep)
+# SHAPES="4x4,8x4,12x3" sweeps shapes at B=4096 (or BATCH=...), T=50 instead (algorithmic bytes 4(ns^2 + ns + nx ns + nx + ns) per timestep)
 shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "").split(",") if sh]
-cases = [(4096, 50, a, b) for a, b in shapes] or [(B, T, 8, 2) for B, T in (
+cases = [(int(os.environ.get("BATCH", 4096)), 50, a, b) for a, b in shapes] or [(B, T, 8, 2) for B, T in (
     (1024, 50), (2048, 50), (4096, 50), (8192, 50), (16384, 50), (65536, 50), (4096, 20), (4096, 51), (4096, 52), (4096, 74),
     (4096, 100), (4096, 200))]
 print("%7s %4s %7s %5s %10s %12s %8s" % ("B", "T", "shape", "path", "us/solve", "ts/s", "frac"))

@@ -123,6 +123,9 @@ def test_container_shapes_against_oracle(dims):
         assert_close(npy(x), xr, TOL_PRIMAL, "x")
         assert_close(npy(u), ur, TOL_PRIMAL, "u")
         Ks, ks = rec.backward()
+        if nx > 16:   # the sweep runs in the smallest wavefront-per-trajectory instance that holds the problem
+            inst = next(c for c in ((24, 4), (24, 8), (32, 4), (32, 8)) if nx <= c[0] and nu <= c[1])
+            assert _lib.last_kernel_name().startswith("void dmpc::lqr_wave_mfma_backward<%d, %d, false, false, true" % inst)
         assert_close(npy(torch.stack(Ks)), Ksr, TOL_PRIMAL, "Ks")
         assert_close(npy(torch.stack(ks)), ksr, TOL_PRIMAL, "ks")
         x2, u2 = rec.forward(Ks, ks)
@@ -140,7 +143,8 @@ def test_container_shapes_against_oracle(dims):
 
 
 WIDE_ROW_SHAPES = [(16, 4), (16, 8), (12, 4), (12, 8)]     # lqr_wide_kernel.hpp: two registers per matrix row
-WAVE_CONTAINER_SHAPES = [(5, 5), (3, 8), (12, 4), (16, 4), (10, 6), (16, 8), (15, 7), (20, 6), (24, 8), (31, 7), (17, 1), (32, 3)]
+WAVE_CONTAINER_SHAPES = [(5, 5), (3, 8), (12, 4), (16, 4), (10, 6), (16, 8), (15, 7), (20, 6), (24, 8), (31, 7), (17, 1), (32, 3),
+                         (24, 4), (21, 5), (25, 4), (32, 7)]
 
 
 @pytest.mark.parametrize("dims", WAVE_CONTAINER_SHAPES, ids=["%dx%d" % d for d in WAVE_CONTAINER_SHAPES])
