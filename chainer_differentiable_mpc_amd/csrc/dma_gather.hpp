@@ -21,4 +21,17 @@ __device__ __forceinline__ void set_m0(unsigned lds_dst) {  // + the wait state 
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst) : "memory");
 }
 
+// A contiguous run of `floats` >= 1 floats at `src` (wave-uniform, any 4-byte alignment, a run-time length) -> LDS byte address
+// `dst` (wave-uniform), 64 floats per instruction: lane l copies float o + l.  Lanes past the end read the last float again;
+// their LDS words are padding - the regions such runs land in are whole multiples of 64 floats.
+__device__ __forceinline__ void dma_run_floats(const float *src, unsigned dst, int floats, int lane) {
+  const unsigned long long base = reinterpret_cast<unsigned long long>(src);
+  for (int o = 0; o < floats; o += 64) {   // uniform
+    set_m0(dst + o * 4);
+    const int e = o + lane;
+    const unsigned voff = (unsigned)(e < floats ? e : floats - 1) * 4u;
+    asm volatile("global_load_lds_dword %0, %1" DMPC_DMA_POLICY ::"v"(voff), "s"(base) : "memory");
+  }
+}
+
 }  // namespace dmpc

@@ -125,19 +125,6 @@ __device__ __forceinline__ void wave_dma_region(const void *src, unsigned dst, u
   });
 }
 
-// a contiguous run of `floats` >= 1 floats at `src` (wave-uniform, any 4-byte alignment, a run-time length) -> LDS byte address
-// `dst`: 64 floats per instruction.  Lanes past the end read the last float again; their LDS words are padding (the regions
-// of a container's slot are whole multiples of 64 floats).
-__device__ __forceinline__ void wave_dma_run(const float *src, unsigned dst, int floats, int lane) {
-  const unsigned long long base = reinterpret_cast<unsigned long long>(src);
-  for (int o = 0; o < floats; o += 64) {   // uniform
-    set_m0(dst + o * 4);
-    const int e = o + lane;
-    const unsigned voff = (unsigned)(e < floats ? e : floats - 1) * 4u;
-    asm volatile("global_load_lds_dword %0, %1" DMPC_WAVE_DMA_POLICY ::"v"(voff), "s"(base) : "memory");
-  }
-}
-
 // Closed-loop rollout (LqrRecursion.forward, lqr/lqr_recursion.py:160-200) by the wavefront that has just finished the
 // backward sweep of the same trajectory: while it waits on memory here, the other wavefront of its SIMD is in the
 // compute-bound sweep of ANOTHER trajectory, so the bandwidth-bound and the compute-bound halves of the solve overlap
@@ -384,7 +371,7 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
   // ---- the input slot of this wavefront: [C_t | c_t | F_t | f_t] as they lie in HBM, filled by LDS-DMA a step ahead
   constexpr int kSlotC = 0, kSlotc = NS * NS, kSlotF = kSlotc + NS, kSlotf = kSlotF + NX * NS, kSlotFloats = kSlotf + NX;
   static_assert((NS * NS) % 4 == 0 && NS % 4 == 0 && (NX * NS) % 4 == 0 && NX % 4 == 0, "16-byte regions");
-  // PAD: the same four regions at the PROBLEM's sizes and strides, each in its own multiple of 64 floats (wave_dma_run),
+  // PAD: the same four regions at the PROBLEM's sizes and strides, each in its own multiple of 64 floats (dma_run_floats of dma_gather.hpp),
   // and a word of zero for the lanes and rows outside the problem
   constexpr int kPadC = 0, kPadc = (NS * NS + 63) / 64 * 64, kPadF = kPadc + 64, kPadf = kPadF + (NX * NS + 63) / 64 * 64,
                 kPadZero = kPadf + 64, kPadFloats = kPadZero + 4;
@@ -438,11 +425,11 @@ __global__ __launch_bounds__(256, (DMPC_WAVE_PREFETCH || MPC) ? 1 : DMPC_WAVE_OC
   };
   auto dma_issue_pad = [&](int t) {
     const size_t tb = (size_t)t * B + b;
-    wave_dma_run(a.C + tb * ns * ns, slot_addr + kPadC * 4, ns * ns, lane);
-    wave_dma_run(a.c + tb * ns, slot_addr + kPadc * 4, ns, lane);
+    dma_run_floats(a.C + tb * ns * ns, slot_addr + kPadC * 4, ns * ns, lane);
+    dma_run_floats(a.c + tb * ns, slot_addr + kPadc * 4, ns, lane);
     if (t < T - 1) {   // uniform
-      wave_dma_run(a.F + tb * nx * ns, slot_addr + kPadF * 4, nx * ns, lane);
-      if (has_f) wave_dma_run(a.f + tb * nx, slot_addr + kPadf * 4, nx, lane);
+      dma_run_floats(a.F + tb * nx * ns, slot_addr + kPadF * 4, nx * ns, lane);
+      if (has_f) dma_run_floats(a.f + tb * nx, slot_addr + kPadf * 4, nx, lane);
     }
   };
   // slot -> bank at the container's positions: a lane's element of logical row li is at base + li * stride, where a column

@@ -103,6 +103,11 @@ static bool mpc_container_disabled() {   // DMPC_NO_CONTAINER=1: the runtime-dim
   return off;
 }
 
+static bool mpc_staged_forward_disabled() {   // DMPC_NO_MPC_STAGED_FWD=1: mpc_generic_forward_kernel (A/B timing, parity between them)
+  static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_STAGED_FWD"); return e && e[0] == '1'; }();
+  return off;
+}
+
 static bool mpc_wave_disabled() {   // DMPC_NO_MPC_WAVE=1: wide MPC shapes on the runtime-dimension kernel (A/B timing)
   static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_WAVE"); return e && e[0] == '1'; }();
   return off;
@@ -221,8 +226,8 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
       X(12, 4) X(16, 4) X(12, 8) X(16, 8)
 #undef X
       // ... and padded inside the smallest of those instances: every other shape with at most 16 states, 8 controls and
-      // nx + nu >= 16 (no 16-lane container), whole wavefronts
-      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && nx + nu >= 16 && a.B % 4 == 0 && !mpc_container_disabled()) {
+      // no 16-lane container (nx + nu >= 16, or more than four controls: (5,5) 2.0 -> 1.3 ms per MPCstep.forward), whole wavefronts
+      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && (nx + nu >= 16 || nu > 4) && a.B % 4 == 0 && !mpc_container_disabled()) {
         s.nx_log = nx;
         s.nu_log = nu;
 #define X(NX_, NU_)                                                                                            \
@@ -282,9 +287,10 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   }
   // A padded wave instance costs what ITS shape costs (and fetches element by element, one wavefront per SIMD): measured at
   // B = 4096, T = 50 it beats the runtime-dimension kernel where the latter's QP in lane 0 is widest - (24,8) 9.2 against
-  // 12.5 ms - and loses below - (20,6) 7.8 against 5.4 ms, (10,5) 5.4 against 2.9 ms.  So: seven or eight controls only.
-  if (wave_ok && !small && nu >= 7 && nx <= 16 && nu <= 8) return wave_container(16, 8);
-  if (wave_ok && !small && nu >= 7 && nx <= 32 && nu <= 8) return wave_container(32, 8);
+  // 12.5 ms - and lost below - (20,6) 7.8 against 5.4 ms, (10,5) 5.4 against 2.9 ms.
+  // (Round 4, the padded instance fetching through its LDS-DMA slot: (20,6) 3.4 against 3.8 ms - six controls and more.)
+  if (wave_ok && !small && nu >= 6 && nx <= 16 && nu <= 8) return wave_container(16, 8);
+  if (wave_ok && !small && nu >= 6 && nx <= 32 && nu <= 8) return wave_container(32, 8);
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
   if (nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
     void *args2[] = {&a, &nx};
@@ -406,7 +412,7 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   }
       X(12, 4) X(16, 4) X(12, 8) X(16, 8)
 #undef X
-      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && nx + nu >= 16 && a.B % 4 == 0 && !mpc_container_disabled()) {
+      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && (nx + nu >= 16 || nu > 4) && a.B % 4 == 0 && !mpc_container_disabled()) {
         MpcFwdArgs p = a;     // ... and padded inside the smallest of those instances (as the sweep)
         p.nx_log = nx;
         p.nu_log = nu;
@@ -434,6 +440,17 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   }
     DMPC_MPC_CONTAINERS(X)
 #undef X
+  }
+  if (a.dyn_kind == 0 && nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu && !mpc_staged_forward_disabled()) {
+    // the inputs of a step through an LDS ring (mpc_staged_forward_kernel); DMPC_NO_MPC_STAGED_FWD=1: the kernel below
+    const size_t shmem = mpc_staged_fwd_lds_bytes(nx, nu);
+    if (shmem <= 150 * 1024) {
+      if (shmem > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc_staged_forward_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      DMPC_LAUNCH_GGL(mpc_staged_forward_kernel, dim3(a.B), dim3(64), shmem, stream, a, nx, nu);
+      return (int)hipGetLastError();
+    }
   }
   if (a.dyn_kind == 0 && nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
     DMPC_LAUNCH_GGL(mpc_generic_forward_kernel, dim3(a.B), dim3(64), mpc_generic_fwd_lds_bytes(nx, nu), stream, a,
