@@ -405,6 +405,10 @@ static int launch_lqr_wave_container(int mode, int nx, int nu, const LqrArgs &a0
     const int rc = launch_lqr_wave_container_sweep(NX, NU, masked, a, stream);
     if (rc != 0 || mode == kBackwardOnly) return rc;
   }
+  {
+    const int rc = launch_lqr_staged_forward(nx, nu, a, stream);   // (the rows through an LDS ring: lqr_staged_forward.hpp)
+    if (rc != DMPC_E_UNSUPPORTED) return rc;
+  }
   const dim3 grid((a.B + 3) / 4), block(256);
   if (masked) DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, 64, true, kForwardOnly, false, true>), grid, block, 0, stream, a);
   else DMPC_LAUNCH_GGL((lqr_kernel<NX, NU, 64, false, kForwardOnly, false, true>), grid, block, 0, stream, a);

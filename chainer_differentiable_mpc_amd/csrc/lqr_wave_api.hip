@@ -5,6 +5,7 @@
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
 #include "lqr_wave_api.hpp"
+#include "lqr_staged_forward.hpp"
 #include "lqr_wave_mfma.hpp"
 
 namespace dmpc {
@@ -67,6 +68,20 @@ int launch_lqr_wave_container_sweep(int cnx, int cnu, bool masked, const LqrArgs
   X(16, 8) X(24, 4) X(24, 8) X(32, 4) X(32, 8)
 #undef X
   return DMPC_E_UNSUPPORTED;
+}
+
+// the rollout of a problem padded inside those instances (gains from a.Ks / a.ks, else the workspace), inputs staged through LDS
+// (lqr_staged_forward.hpp).  DMPC_E_UNSUPPORTED - nothing launched - for the clamped rollout, T == 1 or DMPC_NO_STAGED_FWD=1.
+int launch_lqr_staged_forward(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_STAGED_FWD"); return e && e[0] == '1'; }();
+  const size_t shmem = lqr_staged_fwd_lds_bytes(nx, nu);
+  if (off || a.mask != nullptr || a.T < 2 || nx + nu > 63 || shmem > 150 * 1024 || (a.Ks == nullptr && a.wsK == nullptr))
+    return DMPC_E_UNSUPPORTED;
+  if (shmem > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_staged_forward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  DMPC_LAUNCH_GGL(lqr_staged_forward_kernel, dim3(a.B), dim3(64), shmem, stream, a, nx, nu);
+  return (int)hipGetLastError();
 }
 
 }  // namespace dmpc

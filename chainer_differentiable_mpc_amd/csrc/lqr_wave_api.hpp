@@ -16,4 +16,7 @@ int launch_mpc_wave_container_backward(int cnx, int cnu, const LqrArgs &a, hipSt
 // the sweep of a smaller problem (a.nx_log, a.nu_log) padded inside the (cnx, cnu) instance - (16,8) or (32,8)
 int launch_lqr_wave_container_sweep(int cnx, int cnu, bool masked, const LqrArgs &a, hipStream_t stream);
 
+// the rollout of a padded problem with its inputs staged through LDS; DMPC_E_UNSUPPORTED (nothing launched) where it does not apply
+int launch_lqr_staged_forward(int nx, int nu, const LqrArgs &a, hipStream_t stream);
+
 }  // namespace dmpc
