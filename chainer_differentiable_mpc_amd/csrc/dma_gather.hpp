@@ -34,4 +34,21 @@ __device__ __forceinline__ void dma_run_floats(const float *src, unsigned dst, i
   }
 }
 
+// s_waitcnt vmcnt takes an immediate: the largest of a few values that does not exceed n (waiting for more is always safe)
+__device__ __forceinline__ void wait_vmcnt_at_most(int n) {   // n uniform
+  if (n >= 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+  else if (n >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+  else if (n >= 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+  else if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace dmpc

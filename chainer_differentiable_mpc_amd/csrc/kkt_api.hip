@@ -11,6 +11,7 @@
 #include "costate_dma_kernel.hpp"
 #include "costate_wide_kernel.hpp"
 #include "costate_kernels.hpp"
+#include "costate_staged_kernel.hpp"
 
 namespace dmpc {
 
@@ -149,6 +150,18 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
       DMPC_COSTATE_CONTAINERS(X)
 #undef X
+      {   // wider (17+ states, ragged batches of the wide shapes): a wavefront per trajectory, the step's blocks through an
+          // LDS ring at the problem's own dimensions (costate_staged_kernel.hpp); DMPC_NO_STAGED_COSTATE=1: the containers below
+        static const bool staged_off = [] { const char *e = getenv("DMPC_NO_STAGED_COSTATE"); return e && e[0] == '1'; }();
+        const size_t shmem = costate_staged_lds_bytes(nx, nu, a.r_cols);
+        if (!staged_off && a.T >= 2 && nx + nu <= 63 && shmem <= 150 * 1024) {
+          if (shmem > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_staged_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+          DMPC_LAUNCH_GGL(costate_staged_kernel, dim3(a.B), dim3(64), shmem, stream, a, nx, nu);
+          return (int)hipGetLastError();
+        }
+      }
 #define X(NX_, NU_)                                                                                          \
   if (nx <= NX_ && nu <= NU_) {   /* wider: a wavefront per trajectory */                                     \
     DMPC_LAUNCH_GGL((costate_kernel<NX_, NU_, 64, true>), dim3((p.B + 3) / 4), dim3(256), 0, stream, p);     \

@@ -37,21 +37,6 @@ __host__ __device__ inline LqrStagedFwdSlot lqr_staged_fwd_slot(int nx, int nu, 
 constexpr int kStagedFwdDepth = 3;
 inline size_t lqr_staged_fwd_lds_bytes(int nx, int nu) { return (size_t)kStagedFwdDepth * lqr_staged_fwd_slot(nx, nu, true).floats * 4; }
 
-// s_waitcnt vmcnt takes an immediate: the largest of a few values that does not exceed n (waiting for more is always safe)
-__device__ __forceinline__ void wait_vmcnt_at_most(int n) {   // n uniform
-  if (n >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-  else if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-  else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if (n >= 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (n >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 __global__ __launch_bounds__(64) void lqr_staged_forward_kernel(const LqrArgs a, const int nx, const int nu) {
   const int ns = nx + nu;
   const int lane = threadIdx.x;
