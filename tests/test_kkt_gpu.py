@@ -57,8 +57,8 @@ def test_strict_math_variant_against_oracle(shape):
     assert np.abs(dC - np.swapaxes(dC, 2, 3)).max() <= 1e-6 * max(1.0, np.abs(dC).max())
 
 
-@pytest.mark.parametrize("dims", [(3, 3), (6, 3), (5, 1), (13, 2), (9, 4), (14, 1), (2, 4), (10, 3), (5, 5), (16, 4), (20, 6), (31, 7)],
-                         ids=lambda d: "%dx%d" % d)
+@pytest.mark.parametrize("dims", [(3, 3), (6, 3), (5, 1), (13, 2), (9, 4), (14, 1), (2, 4), (10, 3), (5, 5), (16, 4), (20, 6), (31, 7),
+                                  (17, 1), (24, 8), (32, 7), (25, 4)], ids=lambda d: "%dx%d" % d)
 @pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
 def test_container_shapes_against_oracle(dims, strict):
     """shapes without a specialisation: the second solve and the co-state sweep run padded inside a container kernel"""
@@ -73,9 +73,37 @@ def test_container_shapes_against_oracle(dims, strict):
     d = to_dev(p)
     node = DiffLqr(T, B, nx, nu, strict_math=strict)
     node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    if nx > 16:   # (rollout and co-state sweep of these: the kernels that stage a step's blocks through LDS)
+        from chainer_differentiable_mpc_amd import _lib
+        assert _lib.last_kernel_name().startswith("dmpc::lqr_staged_forward_kernel")
     out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    if nx > 16:
+        assert _lib.last_kernel_name().startswith("dmpc::costate_staged_kernel")
     for got, want, key in zip(out, ref, KEYS):
         assert_close(npy(got), want, TOLS[key], key)
+
+
+@pytest.mark.parametrize("case", [(5, 2, 20, 6, True), (3, 3, 17, 2, False), (2, 41, 20, 6, True), (9, 4, 31, 8, False)],
+                         ids=lambda c: "B%d_T%d_%dx%d" % c[:4])
+def test_staged_kernels_at_short_and_ring_wrapping_horizons(case):
+    """lqr_staged_forward_kernel / costate_staged_kernel (17+ states): two steps (the whole horizon inside the prologue's
+    fetches), three (the ring exactly), a horizon that wraps it many times; with and without f"""
+    B, T, nx, nu, with_f = case
+    p = synthetic.make_lqr_problem(B, T, nx, nu, seed=500 + T, with_f=with_f)
+    rng = np.random.RandomState(T * 31 + nx)
+    gx = rng.randn(T, B, nx).astype(np.float32).astype(np.float64)
+    gu = rng.randn(T, B, nu).astype(np.float32).astype(np.float64)
+    xr, ur = olqr.lqr_solve(p["x_init"], p["C"], p["c"], p["F"], p["f"], T, nx, nu)
+    ref = okkt.difflqr_backward(p["x_init"], p["C"], p["c"], p["F"], xr, ur, gx, gu, T, nx, nu)
+    d = to_dev(p)
+    node = DiffLqr(T, B, nx, nu)
+    x, u = node.forward((d["x_init"], d["C"], d["c"], d["F"], d["f"]))
+    assert_close(npy(x), xr, TOL_PRIMAL, "x")
+    assert_close(npy(u), ur, TOL_PRIMAL, "u")
+    out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))
+    for got, want, key in zip(out, ref, KEYS):
+        if want is not None and got is not None:
+            assert_close(npy(got), want, TOLS[key], key)
 
 
 @pytest.mark.parametrize("dims", [(16, 4), (16, 8), (12, 8), (13, 3), (15, 1), (14, 2), (10, 6), (9, 8), (8, 8), (12, 5), (12, 4), (16, 2),
