@@ -23,7 +23,6 @@ struct CostateArgs {
   // timesteps, one atomic add per element and wavefront; the caller zeroes them.  dC / dc may then be nullptr.
   float *dC_sum = nullptr, *dc_sum = nullptr;
   int nx_log = 0, nu_log = 0;   // container launches (costate_kernel<..., PAD>): the problem's own dimensions
-  int pad_buffer_loads = 0;     // ... their padded loads as buffer loads (a timestep's slice of C below 2 GB)
 };
 
 // Shape dispatch (defined in kkt_api.hip).

@@ -81,24 +81,6 @@ __global__ __launch_bounds__(256) void costate_kernel(const CostateArgs a) {
     s.tau = *tp;
     s.dtau = *dp;
     if constexpr (PAD) {   // clamped addresses; step() discards what lies outside the problem
-      if (a.pad_buffer_loads) {   // descriptor of the timestep's slice + this lane's 32-bit offset + the element's scalar offset
-        const __amdgpu_buffer_rsrc_t rC = pad_rsrc(a.C + (size_t)t * B * ns * ns);
-        const int vC = (b * ns + lane_x) * ns * 4;
-        static_for<0, NS>([&](auto j) {
-          const int lj = logical(j.value) >= 0 ? logical(j.value) : 0;   // uniform
-          s.Crow[j.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, vC, lj * 4, 0));
-        });
-        s.ci = a.c[tb * ns + lane_x];
-        s.ri = a.r[tb * (a.r_cols ? a.r_cols : ns) + lane_x];
-        const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
-        const __amdgpu_buffer_rsrc_t rF = pad_rsrc((T > 1 ? a.F : a.C) + (size_t)tF * B * nx * ns);
-        const int vF = (b * nx * ns + lane_x) * 4;
-        static_for<0, NX>([&](auto k) {
-          const int kc = k.value < nx ? k.value : 0;   // uniform
-          s.Fcol[k.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rF, vF, kc * ns * 4, 0));
-        });
-        return;
-      }
       const float *Cp = a.C + (tb * ns + lane_x) * ns;
       static_for<0, NS>([&](auto j) {
         const int lj = logical(j.value);

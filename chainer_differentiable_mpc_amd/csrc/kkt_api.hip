@@ -143,8 +143,6 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
       CostateArgs p = a;
       p.nx_log = nx;
       p.nu_log = nu;
-      static const bool no_buf = [] { const char *e = getenv("DMPC_NO_PAD_BUFFER_LOADS"); return e && e[0] == '1'; }();
-      p.pad_buffer_loads = !no_buf && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31) ? 1 : 0;
 #define X(NX_, NU_)                                                                                          \
   if (nx <= NX_ && nu <= NU_) {                                                                              \
     DMPC_LAUNCH_GGL((costate_kernel<NX_, NU_, 16, true>), dim3((p.B + 15) / 16), dim3(256), 0, stream, p);  \

@@ -433,10 +433,6 @@ static int launch_lqr_container(int mode, int nx, int nu, const LqrArgs &a0, hip
   LqrArgs a = a0;
   a.nx_log = nx;
   a.nu_log = nu;
-  // the padded loads as buffer loads (descriptor + 32-bit offsets: a timestep's slice of C must stay below 2 GB); (6,3) 130 ->
-  // 119 us, (13,2) 190 -> 158 us on one box.  DMPC_NO_PAD_BUFFER_LOADS=1: pointer arithmetic per element
-  static const bool no_buf = [] { const char *e = getenv("DMPC_NO_PAD_BUFFER_LOADS"); return e && e[0] == '1'; }();
-  a.pad_buffer_loads = !no_buf && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31) ? 1 : 0;
   const dim3 grid((a.B + GPB - 1) / GPB), block(256);
   const bool masked = a.mask != nullptr;
   const size_t lds_gain = (size_t)GPB * a.T * NU * (NX + 1) * sizeof(float);

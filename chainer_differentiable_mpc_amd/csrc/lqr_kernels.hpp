@@ -51,7 +51,6 @@ struct LqrArgs {
   int df_shift = 0;
   // container launches (lqr_kernel<..., PAD>): the problem's own dimensions, nx_log <= NX and nu_log <= NU of the kernel
   int nx_log = 0, nu_log = 0;
-  int pad_buffer_loads = 0;   // ... their padded loads as buffer loads (the arrays' per-timestep slices below 2 GB)
   // MPCstep.backward_rec on the wavefront-per-trajectory kernel (lqr_wave_mfma_backward<..., MPC>): k_t is a box QP
   // on (Quu, qu) with the bounds lower - u, upper - u (mpc/mpc_step.py:119-146); with mpc_states the re-centring
   // c_hat = C [x_t; u_t] + c happens inside the sweep (:305-317); mpc_n_qp_total [B] receives sum_t (1 + i_t)
@@ -101,11 +100,6 @@ constexpr int ring_depth(int regs_per_slot, int budget, int max_depth) {
 // control m at NX + m), everything else of [C|c] and [F|f] is 0 and the unused controls get a unit diagonal in Quu - their
 // gain rows come out exactly 0, the pivot search never picks their rows for a real column (LAPACK's choice is unchanged),
 // and every added term of a dot product is an exact 0.  Arrays in HBM keep the problem's own strides.
-// a timestep's slice of an input array as a raw buffer descriptor (48-bit base, stride 0, 2 GB of records, DATA_FORMAT 32)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pad_rsrc(const float *base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
-}
-
 template <int NX, int NU, int L, bool MASKED, int MODE, bool K_LDS, bool PAD = false>
 __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
   constexpr int NS = NX + NU;
@@ -166,24 +160,6 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
       const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
       const size_t tbF = (size_t)tF * B + b;
       if constexpr (PAD) {   // clamped addresses, the same loads on every path as below; step() discards the padding
-        if (a.pad_buffer_loads) {
-          // buffer loads: the timestep's slice as an SGPR descriptor, this lane's trajectory and column as a 32-bit offset,
-          // the row (run-time stride) as the scalar offset - no 64-bit address arithmetic on the VALU per element
-          const __amdgpu_buffer_rsrc_t rC = pad_rsrc(a.C + (size_t)t * B * ns * ns), rc = pad_rsrc(a.c + (size_t)t * B * ns);
-          const __amdgpu_buffer_rsrc_t rF = pad_rsrc(Fsafe + (size_t)tF * B * nx * ns), rf = pad_rsrc(fsafe + (size_t)tF * B * nx);
-          const int vC = (b * ns * ns + lcol_c) * 4, vc = b * ns * 4, vF = (b * nx * ns + lcol_c) * 4, vf = b * nx * 4;
-          static_for<0, NS>([&](auto i) {
-            const int li = logical(i.value) >= 0 ? logical(i.value) : 0;   // uniform
-            Qn[i.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rC, vC, li * ns * 4, 0));
-            cn[i.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rc, vc, li * 4, 0));
-          });
-          static_for<0, NX>([&](auto k) {
-            const int kc = k.value < nx ? k.value : 0;   // uniform
-            Fn[k.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rF, vF, kc * ns * 4, 0));
-            fn[k.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, vf, kc * 4, 0));
-          });
-          return;
-        }
         const float *Cp = a.C + tb * ns * ns + lcol_c;
         const float *cp = a.c + tb * ns;
         static_for<0, NS>([&](auto i) {
@@ -373,20 +349,11 @@ __global__ __launch_bounds__(256) void lqr_kernel(const LqrArgs a) {
       const int tF = t < T - 1 ? t : (T > 1 ? T - 2 : 0);
       const size_t tbF = (size_t)tF * B + b;
       if constexpr (PAD) {
-        if (a.pad_buffer_loads && T > 1) {   // (as in the backward sweep: descriptor + lane offset + scalar element offset)
-          const __amdgpu_buffer_rsrc_t rF = pad_rsrc(Fsafe + (size_t)tF * B * nx * ns);
-          const int vF = (b * nx + lane_x) * ns * 4;
-          static_for<0, NS>([&](auto j) {
-            const int lj = logical(j.value) >= 0 ? logical(j.value) : 0;   // uniform
-            Fn[j.value] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rF, vF, lj * 4, 0));
-          });
-        } else {
-          const float *Fp = Fsafe + (tbF * nx + lane_x) * ns;
+        const float *Fp = Fsafe + (tbF * nx + lane_x) * ns;
 #pragma unroll
-          for (int j = 0; j < NS; ++j) {
-            const int lj = logical(j);   // uniform
-            if (T > 1) Fn[j] = Fp[lj >= 0 ? lj : 0];
-          }
+        for (int j = 0; j < NS; ++j) {
+          const int lj = logical(j);   // uniform
+          if (T > 1) Fn[j] = Fp[lj >= 0 ? lj : 0];
         }
       } else {
         if (T > 1) load_contig<NS>(Fsafe + (tbF * NX + lane_x) * NS, Fn);
