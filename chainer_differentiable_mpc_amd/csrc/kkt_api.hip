@@ -106,9 +106,13 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
   }
       DMPC_COSTATE_WIDE_SHAPES(X)
 #undef X
-      // ... and padded inside the (16,4), (12,8) or (16,8) instance: the shapes without a 16-lane container (nx + nu >= 16)
+      // ... and padded inside the (16,4), (12,8) or (16,8) instance: the shapes without a 16-lane container (nx + nu >= 16), and
+      // the larger ones of those with one - the 16-lane container stores its rows of dC / dF element by element, this kernel
+      // stages them: gradient at B = 4096, T = 50 (9,4) 400 -> 295 us, (11,4) 530 -> 309, (13,2) 568 -> 321; below 13
+      // elements of tau the container wins ((6,3) 208 against 247 us).  DMPC_COSTATE_WIDE_MIN_NS moves the threshold.
       static const bool no_pad = [] { const char *e = getenv("DMPC_NO_CONTAINER"); return e && e[0] == '1'; }();
-      if (!no_pad && nx + nu >= 16 && nx >= 1 && nu >= 1) {
+      static const int min_ns = [] { const char *e = getenv("DMPC_COSTATE_WIDE_MIN_NS"); return e ? atoi(e) : 13; }();
+      if (!no_pad && nx + nu >= min_ns && nx >= 1 && nu >= 1) {
         CostateArgs p = a;
         p.nx_log = nx;
         p.nu_log = nu;

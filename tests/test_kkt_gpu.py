@@ -107,12 +107,12 @@ def test_staged_kernels_at_short_and_ring_wrapping_horizons(case):
 
 
 @pytest.mark.parametrize("dims", [(16, 4), (16, 8), (12, 8), (13, 3), (15, 1), (14, 2), (10, 6), (9, 8), (8, 8), (12, 5), (12, 4), (16, 2),
-                                  (15, 7), (13, 5), (16, 6)],
+                                  (15, 7), (13, 5), (16, 6), (13, 2), (9, 4), (14, 1), (11, 4), (12, 1), (6, 7)],
                          ids=lambda d: "%dx%d" % d)
 @pytest.mark.parametrize("strict", [False, True], ids=["faithful", "strict"])
 def test_wide_costate_kernel_against_oracle(dims, strict):
-    """17 to 31 elements of tau, at most 16 states: the gradient's second solve on lqr_wide_kernel and its co-state sweep on
-    costate_wide_kernel (four trajectories per wavefront, tau in two registers) - whole batches (a ragged one takes the
+    """13 to 31 elements of tau, at most 16 states: the gradient's second solve on lqr_wide_kernel (16 and more; below, the
+    16-lane containers) and its co-state sweep on costate_wide_kernel (four trajectories per wavefront, tau in two registers) - whole batches (a ragged one takes the
     wavefront-per-trajectory container: compared with it too), short and ring-wrapping horizons."""
     from chainer_differentiable_mpc_amd import _lib
     nx, nu = dims
