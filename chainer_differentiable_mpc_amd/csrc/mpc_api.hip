@@ -108,6 +108,12 @@ static bool mpc_staged_forward_disabled() {   // DMPC_NO_MPC_STAGED_FWD=1: mpc_g
   return off;
 }
 
+// Which shapes run padded inside the wide row kernels' instances (sweep and line search alike): those without a 16-lane MPC
+// container (16 and more elements of tau, or more than four controls) and, of those with one, three and four controls from
+// 12 elements on - MPCstep.forward at B = 4096, T = 50: (9,4) 707 -> 605 us, (11,4) 769 -> 645, (10,3) 629 -> 578; with one
+// or two controls the container's short QP wins ((13,2) 568 against 695 us, (14,1) 460 against 562).
+static bool mpc_wide_padded(int nx, int nu) { return nx + nu >= 16 || nu > 4 || (nu >= 3 && nx + nu >= 12); }
+
 static bool mpc_wave_disabled() {   // DMPC_NO_MPC_WAVE=1: wide MPC shapes on the runtime-dimension kernel (A/B timing)
   static const bool off = [] { const char *e = getenv("DMPC_NO_MPC_WAVE"); return e && e[0] == '1'; }();
   return off;
@@ -227,7 +233,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
 #undef X
       // ... and padded inside the smallest of those instances: every other shape with at most 16 states, 8 controls and
       // no 16-lane container (nx + nu >= 16, or more than four controls: (5,5) 2.0 -> 1.3 ms per MPCstep.forward), whole wavefronts
-      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && (nx + nu >= 16 || nu > 4) && a.B % 4 == 0 && !mpc_container_disabled()) {
+      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && mpc_wide_padded(nx, nu) && a.B % 4 == 0 && !mpc_container_disabled()) {
         s.nx_log = nx;
         s.nu_log = nu;
 #define X(NX_, NU_)                                                                                            \
@@ -412,7 +418,7 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   }
       X(12, 4) X(16, 4) X(12, 8) X(16, 8)
 #undef X
-      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && (nx + nu >= 16 || nu > 4) && a.B % 4 == 0 && !mpc_container_disabled()) {
+      if (nx >= 1 && nu >= 1 && nx <= 16 && nu <= 8 && mpc_wide_padded(nx, nu) && a.B % 4 == 0 && !mpc_container_disabled()) {
         MpcFwdArgs p = a;     // ... and padded inside the smallest of those instances (as the sweep)
         p.nx_log = nx;
         p.nu_log = nu;

@@ -216,7 +216,9 @@ def test_headline_shape_properties():
                                    (8, 6, 13, 3, 0.25), (4, 5, 10, 6, 0.375), (12, 6, 15, 7, 0.25), (8, 5, 14, 2, 0.5), (4, 6, 16, 3, 0.25),
                                    (8, 5, 9, 8, 0.25),
                                    # ... and below 16 columns with more than 4 controls (no 16-lane MPC container holds them)
-                                   (8, 6, 5, 5, 0.25), (4, 5, 9, 6, 0.375), (12, 5, 3, 8, 0.25), (4, 6, 1, 5, 0.5)])   # bounds exact in float32
+                                   (8, 6, 5, 5, 0.25), (4, 5, 9, 6, 0.375), (12, 5, 3, 8, 0.25), (4, 6, 1, 5, 0.5),
+                                   # ... and three / four controls from 12 elements of tau on (whole wavefronts; a container otherwise)
+                                   (8, 5, 9, 4, 0.25), (4, 6, 11, 4, 0.375), (8, 5, 10, 3, 0.5), (4, 7, 9, 3, 0.25)])   # bounds exact in float32
 def test_shapes_without_a_specialisation_against_the_oracle(shape, coupled):
     """shapes outside the register-resident list - padded inside a container kernel (nu <= 4, nx + nu <= 15; (3,3) is the
     shape of the reference's experiment_mpc/MpcNet.py:43-44), on the matrix-core sweep with the box QP inside ((16,8), (32,8),
