@@ -6,7 +6,7 @@ import torch, bench
 from chainer_differentiable_mpc_amd import _lib
 from chainer_differentiable_mpc_amd import differentiable_lqr as dl
 from chainer_differentiable_mpc_amd.lqr_recursion import solve_device
-shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "8x2,8x4,12x3,16x4,16x8,13x3,20x6,24x8,32x8").split(",")]
+shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "8x2,8x4,12x3,6x3,9x4,11x4,13x2,16x4,16x8,13x3,20x6,24x8,32x8").split(",")]
 B, T = int(os.environ.get("B", 4096)), 50
 for nx, nu in shapes:
     Bq = B if nx < 32 else 2048

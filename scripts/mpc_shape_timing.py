@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from chainer_differentiable_mpc_amd import LinDx, MPCstep, QuadCost, _lib
 from chainer_differentiable_mpc_amd.util import get_traj
-shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "8x2,8x4,12x4,16x4,16x8,13x3,10x6,5x5,9x6,20x6").split(",")]
+shapes = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("SHAPES", "8x2,8x4,9x4,11x4,13x2,12x4,16x4,16x8,13x3,10x6,5x5,9x6,20x6").split(",")]
 B, T = int(os.environ.get("B", 4096)), 50
 dev = torch.device("cuda")
 for nx, nu in shapes:
