@@ -234,6 +234,37 @@ def hbm_copy_calibration(device, gib=1.0, reps=5):
     return 2 * n * 4 / statistics.median(ts) / 1e9
 
 
+def secondary_shapes(device):
+    """The fused solve and the KKT gradient of shapes beyond the headline's kernel at B=4096, T=50 - one line per kernel
+    family: 16-lane HIP kernel, wide row kernel (exact / padded), wavefront-per-trajectory container with the staged rollout.
+    Fractions are of the HBM roof on the path's algorithmic bytes (solve: 4(ns^2 + ns + nx ns + nx + ns) per timestep-solve)."""
+    from chainer_differentiable_mpc_amd import _lib
+    from chainer_differentiable_mpc_amd.differentiable_lqr import kkt_grad_device
+    out = {"what": "fused solve / DiffLqr gradient (second solve + co-state sweep) per shape, B=4096 T=50, HIP events over "
+                   "20 back-to-back calls at the device's steady clocks (settle)"}
+    B, T = 4096, 50
+    for nx, nu in ((8, 4), (12, 4), (16, 4), (13, 3), (16, 8), (20, 6)):
+        try:
+            p, d = make_inputs(B, T, nx, nu, 0, device)
+            x = torch.empty((T, B, nx), dtype=torch.float32, device=device)
+            u = torch.empty((T, B, nu), dtype=torch.float32, device=device)
+            gx, gu = torch.ones_like(x), torch.ones_like(u)
+            t_solve = event_time(lambda: solve_device(d["C"], d["c"], d["F"], d["f"], d["x_init"], None, T, nx, nu, out=(x, u)),
+                                 20, warm=3)
+            k_solve = _lib.last_kernel_name()
+            t_grad = event_time(lambda: kkt_grad_device(d["C"], d["c"], d["F"], x, u, gx, gu, T, nx, nu), 20, warm=3)
+            k_grad = _lib.last_kernel_name()
+            bts = synthetic.lqr_algorithmic_bytes_per_timestep(nx, nu)
+            out["%dx%d" % (nx, nu)] = {"us_solve": t_solve * 1e6, "frac_hbm_solve": bts * B * T / t_solve / 1e9 / HBM_PEAK_GBS,
+                                      "us_gradient": t_grad * 1e6, "finite": bool(torch.isfinite(x).all()),
+                                      "kernel": k_solve, "kernel_gradient_last": k_grad}
+            del p, d, x, u, gx, gu
+            torch.cuda.empty_cache()
+        except Exception as e:  # pragma: no cover
+            out["%dx%d" % (nx, nu)] = {"error": repr(e)}
+    return out
+
+
 def secondary_metrics(device, d_headline):
     """SURVEY.md 8d's secondary numbers, measured live (about 10 s in total)"""
     import warnings
@@ -703,6 +734,10 @@ def main():
                 sec = secondary_metrics(device, d)
             except Exception as e:  # pragma: no cover
                 sec["error"] = "secondary_metrics: %r" % (e,)
+            try:
+                sec["shape_families"] = secondary_shapes(device)
+            except Exception as e:  # pragma: no cover
+                sec["shape_families"] = {"error": repr(e)}
             try:
                 sec["headline_f64"] = secondary_f64(device, d)
             except Exception as e:  # pragma: no cover
