@@ -402,6 +402,10 @@ static int launch_lqr_wave_container(int mode, int nx, int nu, const LqrArgs &a0
   if (mode != kForwardOnly) {
     if (a.Ks == nullptr) { a.Ks = a.wsK; a.ks = a.wsk; }
     if (a.Ks == nullptr) return DMPC_E_WORKSPACE;
+    if (!wave_mfma_disabled()) {   // a size that IS one of the instances: the exact kernel (rollout in the same launch)
+      const int rx = launch_lqr_wave_mfma_backward(nx, nu, masked, mode == kSolve, a, stream);
+      if (rx != DMPC_E_UNSUPPORTED) return rx;
+    }
     const int rc = launch_lqr_wave_container_sweep(NX, NU, masked, a, stream);
     if (rc != 0 || mode == kBackwardOnly) return rc;
   }
