@@ -39,7 +39,7 @@ if [ "$PART" = "A" ]; then
   stats bench_headline python3 $REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary
   stats bench_secondary python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline
   stats rows python3 $REPO/scripts/rows_workload.py
-  { timeout -k 10 300 python3 scripts/size_sweep.py; SHAPES="4x2,3x1,6x2,4x4,8x4,12x3,6x3,13x2,9x4,11x4,5x5,12x4,12x8,16x4,16x8,13x3,10x6,15x7,20x6,17x4,24x8" timeout -k 10 300 python3 scripts/size_sweep.py; } > $OUT/size_sweep_steady.txt 2>&1
+  { timeout -k 10 300 python3 scripts/size_sweep.py; SHAPES="4x2,3x1,6x2,4x4,8x4,12x3,6x3,13x2,9x4,11x4,5x5,12x4,12x8,16x4,16x8,13x3,10x6,15x7,20x6,17x4,24x8,24x4,32x4" timeout -k 10 300 python3 scripts/size_sweep.py; } > $OUT/size_sweep_steady.txt 2>&1
   timeout -k 10 300 python3 scripts/f64_timing.py > $OUT/f64_timing.txt 2>&1
   timeout -k 10 300 python3 scripts/mpc_step_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mpc_step_one_launch.txt
   timeout -k 10 300 python3 scripts/kkt_shape_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/kkt_shape_timing.txt
