@@ -7,11 +7,46 @@
 #include "lqr_wave_api.hpp"
 #include "lqr_staged_forward.hpp"
 #include "lqr_wave_mfma.hpp"
+#include "lqr_tile16.hpp"
 
 namespace dmpc {
 
+// DMPC_NO_TILE16=1: the plain sweep on the 4x4x1 outer-product kernel of lqr_wave_mfma.hpp (A/B timing)
+static bool tile16_disabled() {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_TILE16"); return e && e[0] == '1'; }();
+  return off;
+}
+
+// the plain (unclamped) sweep on 16x16x4 tiles (lqr_tile16.hpp); DMPC_E_UNSUPPORTED - nothing launched - for other shapes
+static int launch_lqr_tile16(int nx, int nu, bool rollout, const LqrArgs &a, hipStream_t stream) {
+  const dim3 grid((a.B + 3) / 4), block(256);
+#define X(NX_, NU_)                                                                                                   \
+  if (nx == NX_ && nu == NU_) {                                                                                       \
+    constexpr size_t lds = Tile16Layout<NX_, NU_>::lds_bytes();                                                       \
+    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");                                                    \
+    static const bool once = [] {                                                                                     \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, true>),                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, false>),                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+      return true;                                                                                                    \
+    }();                                                                                                              \
+    (void)once;                                                                                                       \
+    if (rollout) DMPC_LAUNCH_GGL((lqr_tile16_kernel<NX_, NU_, true>), grid, block, lds, stream, a);                   \
+    else DMPC_LAUNCH_GGL((lqr_tile16_kernel<NX_, NU_, false>), grid, block, lds, stream, a);                          \
+    return (int)hipGetLastError();                                                                                    \
+  }
+  X(32, 8)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
 int launch_lqr_wave_mfma_backward(int nx, int nu, bool masked, bool rollout, const LqrArgs &a, hipStream_t stream) {
   const dim3 grid((a.B + 3) / 4), block(256);   // four wavefronts (= trajectories) per workgroup, one per SIMD
+  if (!masked && !tile16_disabled()) {
+    const int rt = launch_lqr_tile16(nx, nu, rollout, a, stream);
+    if (rt != DMPC_E_UNSUPPORTED) return rt;
+  }
 #define X(NX_, NU_)                                                                                       \
   if (nx == NX_ && nu == NU_) {                                                                           \
     if (masked && rollout) DMPC_LAUNCH_GGL((lqr_wave_mfma_backward<NX_, NU_, true, true>), grid, block, 0, stream, a);   \
