@@ -18,15 +18,17 @@
 // The affine terms ride along as column ns of [C | c], [F | f], [Q | q], [K | k] and as the column ns of [V | v] (kept in
 // its own registers `Vaff`: lanes j == ns % 16 of the tile column ns / 16).
 //
-// INPUTS.  The step's [C_t | c_t | F_t | f_t] come HBM -> LDS by per-lane gather LDS-DMA a step ahead, each instruction
-// filling ONE tile in the order the reads want it ([r][g][j]: a 16-byte chunk = four consecutive columns of one row, 64 chunks
-// = one tile), so a tile register is one conflict-free ds_read of 64 consecutive floats and the bytes fetched are exactly the
-// arrays' own (chunks outside a matrix are masked off and stay at the zero the LDS area starts with).
+// INPUTS.  The step's [C_t | c_t | F_t | f_t] come HBM -> LDS by per-lane gather LDS-DMA a step ahead, in the order the reads
+// want them ([r][g][j]: a 16-byte chunk = four consecutive columns of one row, 64 chunks = one full tile), so a tile register is
+// one conflict-free ds_read of consecutive floats and the bytes fetched are exactly the arrays' own (PackedImage below: a
+// partial tile keeps only the rows and columns the matrix has).  11.8 KB of image + 1.5 KB of scratch per wavefront: three
+// wavefronts per SIMD (fp32 MFMA and the vector ALU exclude each other on a SIMD - measured: two wavefronts overlap only 15 %
+// - so the LDS, DMA-issue and scalar latencies of one wavefront need the others' arithmetic to hide behind).
 //
-// GAINS (lqr_recursion.py:112-120).  The control rows [Qux | Quu | qu] go through 1.7 KB of LDS into the column-per-lane
+// GAINS (lqr_recursion.py:112-120).  The control rows [Qux | Quu | qu] go through 1.5 KB of LDS into the column-per-lane
 // layout (a row = one register across the lanes), where the Gauss-Jordan elimination of lqr_wave_mfma.hpp runs unchanged
 // (LAPACK's pivot order); K~ returns through the same LDS rows in a COMPACT contraction layout (register r2 of lane 16 g + j
-// = K~[4 r2 + g][j]), Qxu likewise (transposed through 1 KB), so Qxu K~ costs nu / 4 instructions per tile instead of four.
+// = K~[4 r2 + g][j]), Qxu likewise (transposed through the same area), so Qxu K~ costs nu / 4 instructions per tile instead of four.
 //
 // As in lqr_wave_mfma.hpp the term K~^T (Q~u. + Quu K~) of lqr_recursion.py:151-152 multiplies the residual of the gain solve
 // and is left out (measured against the float64 kernels on all 8,192 trajectories of a shard: tests/test_f64_gpu.py).
@@ -36,44 +38,85 @@
 namespace dmpc {
 
 __device__ __forceinline__ f4v mfma16(float a, float b, f4v c) {
+#ifdef DMPC_T16_KNOB_NOMFMA   // timing knob (wrong results): the sweep without its matrix instructions
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
-// lanes of the tile-filling LDS-DMA instruction that lie inside a ROWS x COLS matrix: lane L = 16 r + 4 g + cq carries
-// columns 4 cq .. 4 cq + 3 of row 4 g + r of tile (ib, jb)
-constexpr unsigned long long tile16_dma_mask(int ib, int jb, int rows, int cols) {
-  unsigned long long m = 0;
-  for (int L = 0; L < 64; ++L) {
-    const int r = L / 16, g = (L / 4) % 4, cq = L % 4;
-    if (16 * ib + 4 * g + r < rows && 16 * jb + 4 * cq < cols) m |= 1ull << L;
-  }
-  return m;
+// NT: the non-temporal cache policy (C_t is read exactly once; F_t and the gains are read again by the rollout)
+template <bool NT>
+__device__ __forceinline__ void tile16_dma_full(unsigned voff, unsigned long long base) {
+  if constexpr (NT) asm volatile("global_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(base) : "memory");
+  else asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base) : "memory");
+}
+template <bool NT>
+__device__ __forceinline__ void tile16_dma_masked(unsigned voff, unsigned long long base, unsigned long long mask) {
+  if constexpr (NT) asm volatile("s_mov_b64 exec, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt\n\ts_mov_b64 exec, -1" ::"v"(voff), "s"(base), "s"(mask) : "memory");
+  else asm volatile("s_mov_b64 exec, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(voff), "s"(base), "s"(mask) : "memory");
 }
 
-__device__ __forceinline__ void tile16_dma_full(unsigned vpat, unsigned long long base) {
-  asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(vpat), "s"(base) : "memory");
-}
-__device__ __forceinline__ void tile16_dma_masked(unsigned vpat, unsigned long long base, unsigned long long mask) {
-  asm volatile("s_mov_b64 exec, %2\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(vpat), "s"(base), "s"(mask) : "memory");
-}
-
-// a ROWS x COLS row-major matrix (COLS % 4 == 0) at `src` (wave-uniform) -> RT x CT tiles of 1 KB at LDS byte address dst;
-// vpat = this lane's byte offset inside a tile's source rows: ((4 g + r) * COLS + 4 cq) * 4
+// The PACKED LDS image of a ROWS x COLS row-major matrix (ROWS % 4 == 0, COLS % 4 == 0) cut into RT x CT tiles.  A tile keeps
+// only what the matrix has: gv row groups (of 4 rows) and cv column chunks (of 4 columns); register r of the tile is the segment
+// [g < gv][4 cv columns] - gv * 4 cv consecutive floats -, the four segments of a tile follow one another, the full tiles come
+// first (they share one DMA lane pattern), then the others in row-major order.  The image is exactly ROWS * COLS floats: the
+// LDS-DMA moves the arrays' own bytes and nothing else.  A 16-byte chunk of the image is four consecutive columns of one row.
 template <int ROWS, int COLS, int RT, int CT>
-__device__ __forceinline__ void tile16_dma(const float *src, unsigned dst, unsigned vpat) {
-  static_assert(COLS % 4 == 0, "16-byte chunks");
-  static_for<0, RT>([&](auto ib) {
-    static_for<0, CT>([&](auto jb) {
-      constexpr unsigned long long mask = tile16_dma_mask(ib.value, jb.value, ROWS, COLS);
-      if constexpr (mask != 0) {
-        set_m0(dst + (ib.value * CT + jb.value) * 1024);
-        const unsigned long long base = reinterpret_cast<unsigned long long>(src) + (16 * ib.value * COLS + 16 * jb.value) * 4;
-        if constexpr (mask == ~0ull) tile16_dma_full(vpat, base);
-        else tile16_dma_masked(vpat, base, mask);
+struct PackedImage {
+  static_assert(ROWS % 4 == 0 && COLS % 4 == 0, "whole row groups and 16-byte chunks");
+  static constexpr int clamp04(int v) { return v < 0 ? 0 : (v > 4 ? 4 : v); }
+  static constexpr int gv(int ib) { return clamp04((ROWS - 16 * ib) / 4); }
+  static constexpr int cv(int jb) { return clamp04((COLS - 16 * jb) / 4); }
+  static constexpr bool full(int ib, int jb) { return gv(ib) == 4 && cv(jb) == 4; }
+  static constexpr int chunks(int ib, int jb) { return 4 * gv(ib) * cv(jb); }
+  static constexpr int seg_floats(int ib, int jb) { return gv(ib) * 4 * cv(jb); }
+  static constexpr int base_chunk(int ib, int jb) {
+    int n = 0;
+    const bool f = full(ib, jb);
+    for (int i = 0; i < RT; ++i)
+      for (int jj = 0; jj < CT; ++jj) {
+        const bool fi = full(i, jj), earlier = i * CT + jj < ib * CT + jb;
+        if (f ? (fi && earlier) : (fi || earlier)) n += chunks(i, jj);
+      }
+    return n;
+  }
+  static constexpr int n_full() {
+    int n = 0;
+    for (int i = 0; i < RT; ++i)
+      for (int jj = 0; jj < CT; ++jj) n += full(i, jj) ? 1 : 0;
+    return n;
+  }
+  static constexpr int total_chunks() { return ROWS * COLS / 4; }
+  static constexpr int tail_instrs() { return (total_chunks() - 64 * n_full() + 63) / 64; }
+  // (ib, jb) of the k-th full tile
+  static constexpr int full_tile(int k) {
+    int n = 0;
+    for (int i = 0; i < RT; ++i)
+      for (int jj = 0; jj < CT; ++jj)
+        if (full(i, jj)) {
+          if (n == k) return i * CT + jj;
+          ++n;
+        }
+    return -1;
+  }
+  // float offset inside the matrix of image chunk n (a chunk of a partial tile); 0 past the end (those lanes are masked off)
+  static __device__ __forceinline__ int tail_src_offset(int n) {
+    int off = 0;
+    static_for<0, RT * CT>([&](auto tl) {
+      constexpr int ib = tl.value / CT, jb = tl.value % CT;
+      if constexpr (!full(ib, jb) && chunks(ib, jb) > 0) {
+        constexpr int base = base_chunk(ib, jb), cnt = chunks(ib, jb), gvv = gv(ib), cvv = cv(jb);
+        if (n >= base && n < base + cnt) {
+          const int q = n - base, r = q / (gvv * cvv), gg = (q / cvv) % gvv, cq = q % cvv;
+          off = (16 * ib + 4 * gg + r) * COLS + 16 * jb + 4 * cq;
+        }
       }
     });
-  });
-}
+    return off;
+  }
+};
 
 template <int NX, int NU>
 struct Tile16Layout {
@@ -81,21 +124,38 @@ struct Tile16Layout {
   static constexpr int RX = (NX + 15) / 16;       // row tiles of F~, V, G (rows = states)
   static constexpr int RS = (NS + 15) / 16;       // row tiles of Q~ (rows = states and controls)
   static constexpr int CA = (NS + 16) / 16;       // column tiles of Q~, F~, G (columns 0 .. ns, the affine one included)
-  static constexpr int SU = 16 * CA + 4;          // row stride of the control-row scratch (floats)
-  static constexpr int XS = NU + 1;               // row stride of the Qxu scratch
-  static constexpr int kC = 0, kF = kC + RS * CA * 256, kc = kF + RX * CA * 256, kf = kc + 16 * RS, kU = kf + 16 * RX,
-                       kX = kU + NU * SU, kFloats = (kX + NX * XS + 3) / 4 * 4;
+  static constexpr int SU = 16 * CA;              // row stride of the control-row scratch (floats)
+  using ImgC = PackedImage<NS, NS, RS, CA>;
+  using ImgF = PackedImage<NX, NS, RX, CA>;
+  // [C image | c (read up to row 16 RS) | F image | f (up to row 16 RX) | nu rows of [Qux | Quu | qu], later of K~ | Qxu]
+  static constexpr int kC = 0, kc = kC + NS * NS, kF = kc + 16 * RS, kf = kF + NX * NS, kU = kf + 16 * RX,
+                       kX = kU + NU * SU, kFloats = (kX + NX * NU + 3) / 4 * 4;
   static constexpr size_t lds_bytes() { return (size_t)4 * kFloats * sizeof(float); }   // four wavefronts per workgroup
 };
 
+#ifndef DMPC_T16_OCC
+#define DMPC_T16_OCC 2    // wavefronts per SIMD the registers and the LDS image are sized for
+#endif
+#ifndef DMPC_T16_NT
+#define DMPC_T16_NT 0     // bit 0: C_t by non-temporal LDS-DMA, bit 1: F_t too
+#endif
+#ifndef DMPC_T16_STAGGER_TICKS
+#define DMPC_T16_STAGGER_TICKS 0   // 100 MHz ticks
+#endif
+#ifndef DMPC_T16_RING
+#define DMPC_T16_RING (DMPC_T16_OCC >= 3 ? 3 : 4)   // steps the rollout requests its rows ahead (42 registers each)
+#endif
+
 template <int NX, int NU, bool ROLLOUT>
-__global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
+__global__ __launch_bounds__(256, DMPC_T16_OCC) void lqr_tile16_kernel(const LqrArgs a) {
   using Lay = Tile16Layout<NX, NU>;
+  using ImgC = typename Lay::ImgC;
+  using ImgF = typename Lay::ImgF;
   constexpr int NS = NX + NU, AFF = NS;
   static_assert(NX % 4 == 0 && NU % 4 == 0, "rows in whole lane groups of four");
   static_assert(NX % 16 + NU <= 16, "the control rows / columns lie inside one tile");
   static_assert(NS + 1 <= 64, "the gain solve holds a row of [Qux | Quu | qu] across one wavefront");
-  constexpr int RX = Lay::RX, RS = Lay::RS, CA = Lay::CA, SU = Lay::SU, XS = Lay::XS;
+  constexpr int RX = Lay::RX, RS = Lay::RS, CA = Lay::CA, SU = Lay::SU;
   constexpr int TA = AFF / 16, JA = AFF % 16;                  // the affine column: tile column TA, lane column JA
   constexpr int TU = NX / 16, JU = NX % 16, GU = JU / 4, RU = NU / 4;   // controls: tile TU, lane groups GU.., lane columns JU..
   constexpr bool kRaggedX = NX % 16 != 0;                      // the last state tile also holds control rows / columns
@@ -119,22 +179,66 @@ __global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
   extern __shared__ __attribute__((aligned(16))) float tile16_lds[];
   float *slot = tile16_lds + wv * Lay::kFloats;
   const unsigned slot_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot);
-  // the area starts at zero: chunks outside the matrices are never written and must read as zero
+  // (the padding behind c / f and the scratch rows are read before anything writes them: finite values, never used)
   for (int i = lane; i < Lay::kFloats; i += 64) slot[i] = 0.f;
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+  // ---- LDS-DMA lane patterns: a full tile's chunk L = 16 r + 4 g + cq is columns 4 cq.. of row 4 g + r; the chunks of the
+  // partial tiles follow the image order (PackedImage::tail_src_offset), one register per instruction
   const unsigned vpat = (unsigned)(((4 * ((lane >> 2) & 3) + (lane >> 4)) * NS + 4 * (lane & 3)) * 4);
   const unsigned voff16 = lane * 16;
+  unsigned tailC[ImgC::tail_instrs() > 0 ? ImgC::tail_instrs() : 1], tailF[ImgF::tail_instrs() > 0 ? ImgF::tail_instrs() : 1];
+  static_for<0, ImgC::tail_instrs()>([&](auto k) { tailC[k.value] = 4u * (unsigned)ImgC::tail_src_offset(64 * (ImgC::n_full() + k.value) + lane); });
+  static_for<0, ImgF::tail_instrs()>([&](auto k) { tailF[k.value] = 4u * (unsigned)ImgF::tail_src_offset(64 * (ImgF::n_full() + k.value) + lane); });
+  auto dma_image = [&](auto img, auto nt, const float *src, unsigned dst, const unsigned *tail) {
+    using Img = decltype(img);
+    constexpr bool NT = decltype(nt)::value;
+    const unsigned long long base = reinterpret_cast<unsigned long long>(src);
+    static_for<0, Img::n_full()>([&](auto k) {
+      constexpr int tl = Img::full_tile(k.value), ib = tl / CA, jb = tl % CA;
+      set_m0(dst + k.value * 1024);
+      tile16_dma_full<NT>(vpat, base + (16 * ib * NS + 16 * jb) * 4);
+    });
+    static_for<0, Img::tail_instrs()>([&](auto k) {
+      constexpr int left = Img::total_chunks() - 64 * (Img::n_full() + k.value);
+      set_m0(dst + (Img::n_full() + k.value) * 1024);
+      if constexpr (left >= 64) tile16_dma_full<NT>(tail[k.value], base);
+      else tile16_dma_masked<NT>(tail[k.value], base, (1ull << left) - 1);
+    });
+  };
   auto dma_issue = [&](int t) {
     const size_t tb = (size_t)t * B + b;
-    tile16_dma<NS, NS, RS, CA>(a.C + tb * NS * NS, slot_addr + Lay::kC * 4, vpat);
+    dma_image(ImgC{}, std::integral_constant<bool, (DMPC_T16_NT & 1) != 0>{}, a.C + tb * NS * NS, slot_addr + Lay::kC * 4, tailC);
     wave_dma_region<NS * 4>(a.c + tb * NS, slot_addr + Lay::kc * 4, voff16);
     if (t < T - 1) {   // uniform; there is no F_{T-1}
-      tile16_dma<NX, NS, RX, CA>(a.F + tb * NX * NS, slot_addr + Lay::kF * 4, vpat);
+      dma_image(ImgF{}, std::integral_constant<bool, (DMPC_T16_NT & 2) != 0>{}, a.F + tb * NX * NS, slot_addr + Lay::kF * 4, tailF);
       if (has_f) wave_dma_region<NX * 4>(a.f + tb * NX, slot_addr + Lay::kf * 4, voff16);
     }
   };
+  // register r of tile (ib, jb) of an image at float offset `at`: lanes outside the tile's rows / columns read a duplicate
+  // (finite, never used: rows and columns beyond the matrix only ever feed rows and columns beyond the matrix)
+  auto tile_read = [&](auto img, auto ib, auto jb, int at, f4v &dst) {
+    using Img = decltype(img);
+    constexpr int gvv = Img::gv(ib.value), cvv = Img::cv(jb.value);
+    if constexpr (gvv * cvv == 0) {
+      dst = f4v{0.f, 0.f, 0.f, 0.f};
+    } else {
+      constexpr int base = 4 * Img::base_chunk(ib.value, jb.value), seg = Img::seg_floats(ib.value, jb.value);
+      const int lp = (g < gvv ? g : gvv - 1) * 4 * cvv + (j < 4 * cvv ? j : 4 * cvv - 1);
+      static_for<0, 4>([&](auto r) { dst[r.value] = slot[at + base + r.value * seg + lp]; });
+    }
+  };
 
+  if constexpr (ROLLOUT && DMPC_T16_STAGGER_TICKS > 0) {
+    // as in lqr_wave_mfma_backward: the wavefronts in an odd slot of their SIMD start late in the first round, so that the
+    // rollout (memory) of one wavefront of a SIMD runs beside the sweep (arithmetic) of the other instead of beside its rollout
+    const unsigned slot_id = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);   // HW_ID bits 3:0 = wave slot in the SIMD
+    constexpr unsigned kResident = DMPC_T16_OCC * 256;
+    if (gridDim.x > kResident && blockIdx.x < kResident && (slot_id & 1u)) {
+      const unsigned long long t0 = wall_clock64();
+      while (wall_clock64() - t0 < (unsigned long long)DMPC_T16_STAGGER_TICKS) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   f4v V[RX][RX], Vaff[RX];   // [V | v]: V[rho][bb] = rows 16 rho.., columns 16 bb..; Vaff[rho] = v in lanes j == JA
 #pragma unroll
   for (int r = 0; r < RX; ++r) {
@@ -167,24 +271,22 @@ __global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
     // ---- slot -> registers
     f4v Q[RS][CA], Ft[RX][CA];
     static_for<0, RS>([&](auto ib) {
-      static_for<0, CA>([&](auto jb) {
-        static_for<0, 4>([&](auto r) { Q[ib.value][jb.value][r.value] = slot[Lay::kC + (ib.value * CA + jb.value) * 256 + 64 * r.value + lane]; });
-      });
+      static_for<0, CA>([&](auto jb) { tile_read(ImgC{}, ib, jb, Lay::kC, Q[ib.value][jb.value]); });
       const f4v cv = *reinterpret_cast<const f4v *>(slot + Lay::kc + 16 * ib.value + 4 * g);
       static_for<0, 4>([&](auto r) { Q[ib.value][TA][r.value] = j == JA ? cv[r.value] : Q[ib.value][TA][r.value]; });
     });
     if (t < T - 1) {
       static_for<0, RX>([&](auto ib) {
-        static_for<0, CA>([&](auto jb) {
-          static_for<0, 4>([&](auto r) { Ft[ib.value][jb.value][r.value] = slot[Lay::kF + (ib.value * CA + jb.value) * 256 + 64 * r.value + lane]; });
-        });
+        static_for<0, CA>([&](auto jb) { tile_read(ImgF{}, ib, jb, Lay::kF, Ft[ib.value][jb.value]); });
         const f4v fv = *reinterpret_cast<const f4v *>(slot + Lay::kf + 16 * ib.value + 4 * g);
         static_for<0, 4>([&](auto r) { Ft[ib.value][TA][r.value] = j == JA ? fv[r.value] : Ft[ib.value][TA][r.value]; });
       });
     }
     if (t > 0) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and has been read: it can take the next step's inputs
+#ifndef DMPC_T16_KNOB_NODMA   // timing knob (wrong results): the sweep on whatever the slot holds
       dma_issue(t - 1);
+#endif
     }
     T16_STAMP(1);
     T16_PRIO(0);
@@ -223,39 +325,75 @@ __global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
         static_for<0, 4>([&](auto r) { slot[Lay::kU + (4 * (g - GU) + r.value) * SU + 16 * jb.value + j] = Q[TU][jb.value][r.value]; });
       });
     }
-    if (t > 0 && j >= JU && j < JU + NU) {   // Qxu, row-major [i][m], for the value update
+    // (lanes beyond the row's 16 CA columns read a duplicate: finite, never used)
+    float Kr[NU];
+    auto read_rows = [&] {
+#pragma unroll
+      for (int m = 0; m < NU; ++m) Kr[m] = slot[Lay::kU + m * SU + (lane < 16 * CA ? lane : 0)];
+    };
+    read_rows();
+    // ---- Qxu through LDS: written row-major [i][m], read in the compact contraction layout (register r2 of lane 16 g + i =
+    // Qxu[i][4 r2 + g])
+    f4v Xc[RX];   // only the first RU registers of each are used
+    if (t > 0) {
+      if (j >= JU && j < JU + NU) {
+        static_for<0, RX>([&](auto ib) {
+          static_for<0, 4>([&](auto r) {
+            const int i = 16 * ib.value + 4 * g + r.value;
+            if (!kRaggedX || i < NX) slot[Lay::kX + i * NU + (j - JU)] = Q[ib.value][TU][r.value];
+          });
+        });
+      }
       static_for<0, RX>([&](auto ib) {
-        static_for<0, 4>([&](auto r) {
-          const int i = 16 * ib.value + 4 * g + r.value;
-          if (!kRaggedX || i < NX) slot[Lay::kX + i * XS + (j - JU)] = Q[ib.value][TU][r.value];
+        static_for<0, RU>([&](auto r2) {
+          const int i = 16 * ib.value + j;
+          Xc[ib.value][r2.value] = (!kRaggedX || i < NX) ? slot[Lay::kX + (kRaggedX && i >= NX ? 0 : i) * NU + 4 * r2.value + g] : 0.f;
         });
       });
     }
-    float Kr[NU];
-#pragma unroll
-    for (int m = 0; m < NU; ++m) Kr[m] = slot[Lay::kU + m * SU + (lane < 16 * CA ? lane : 0)];
-    if (lane >= 16 * CA) {
-#pragma unroll
-      for (int m = 0; m < NU; ++m) Kr[m] = 0.f;
-    }
     T16_STAMP(4);
-    // ---- gains (:112-120): Gauss-Jordan on the rows where they lie; the multiplier of row i at pivot k is lane nx+k of it
+    // ---- gains (:112-120): Gauss-Jordan on the rows where they lie; the multiplier of row i at pivot k is lane nx+k of it.
+    // Fast path without row interchanges and without branches: LAPACK interchanges at pivot k exactly when some |a_ik| (i > k)
+    // exceeds |a_kk| - lane nx+k holds that whole column, one compare there per pivot collects the verdict, and the rare
+    // trajectory that does need an interchange repeats the solve on the rows (still in LDS) in LAPACK's order.
+    unsigned long long need_swap = 0;
+    unsigned zero_pivot = 0;
+#ifdef DMPC_T16_KNOB_NOGJ   // timing knob (wrong results): no gain solve
+    static_for<0, 0>([&](auto kc) {
+#else
     static_for<0, NU>([&](auto kc) {
+#endif
       constexpr int kk = kc.value;
-      float p = G64::template bcast<NX + kk>(Kr[kk]);
-      float li[NU];
-      float mx = 0.f;
+      if constexpr (kk + 1 < NU) {
+        float d = 0.f;
 #pragma unroll
-      for (int i = kk + 1; i < NU; ++i) {
-        li[i] = G64::template bcast<NX + kk>(Kr[i]);
-        mx = fmaxf(mx, fabsf(li[i]));
+        for (int i = kk + 1; i < NU; ++i) d = fmaxf(d, fabsf(Kr[i]));
+        need_swap |= __builtin_amdgcn_ballot_w64(d > fabsf(Kr[kk])) & (1ull << (NX + kk));
       }
-      if (__builtin_expect(mx > fabsf(p), 0)) {   // uniform, rare: LAPACK's row interchange (first largest entry)
+      const float p = G64::template bcast<NX + kk>(Kr[kk]);
+      float l[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+        if (i != kk) l[i] = G64::template bcast<NX + kk>(Kr[i]);
+      zero_pivot |= (__builtin_bit_cast(unsigned, p) << 1) == 0u ? 1u : 0u;
+      Kr[kk] *= fast_rcp(p);
+#pragma unroll
+      for (int i = 0; i < NU; ++i)
+        if (i != kk) Kr[i] = fmaf(-l[i], Kr[kk], Kr[i]);
+    });
+    if (__builtin_expect(need_swap != 0, 0)) {   // uniform, rare
+      read_rows();
+      zero_pivot = 0;
+      static_for<0, NU>([&](auto kc) {
+        constexpr int kk = kc.value;
+        float p = G64::template bcast<NX + kk>(Kr[kk]);
+        float li[NU];
         float best = fabsf(p);
         int pr = kk;
 #pragma unroll
         for (int i = kk + 1; i < NU; ++i) {
-          const bool gt = fabsf(li[i]) > best;
+          li[i] = G64::template bcast<NX + kk>(Kr[i]);
+          const bool gt = fabsf(li[i]) > best;   // first largest entry
           best = gt ? fabsf(li[i]) : best;
           pr = gt ? i : pr;
         }
@@ -270,17 +408,18 @@ __global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
             p = G64::template bcast<NX + kk>(Kr[kk]);
           }
         }
-      }
-      if (p == 0.f) info_bits |= 1;
-      const float rp = fast_rcp(p);
-      Kr[kk] *= rp;
+        if (p == 0.f) zero_pivot = 1;
+        const float rp = fast_rcp(p);
+        Kr[kk] *= rp;
 #pragma unroll
-      for (int i = 0; i < NU; ++i) {
-        if (i == kk) continue;
-        const float l = i > kk ? li[i] : G64::template bcast<NX + kk>(Kr[i]);
-        Kr[i] = fmaf(-l, Kr[kk], Kr[i]);
-      }
-    });
+        for (int i = 0; i < NU; ++i) {
+          if (i == kk) continue;
+          const float l = i > kk ? li[i] : G64::template bcast<NX + kk>(Kr[i]);
+          Kr[i] = fmaf(-l, Kr[kk], Kr[i]);
+        }
+      });
+    }
+    if (zero_pivot) info_bits |= 1;
     float Kt[NU];
 #pragma unroll
     for (int m = 0; m < NU; ++m) Kt[m] = -Kr[m];
@@ -297,15 +436,9 @@ __global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
 #pragma unroll
         for (int m = 0; m < NU; ++m) slot[Lay::kU + m * SU + lane] = k_lane ? Kt[m] : 0.f;
       }
-      f4v Kc[CA], Xc[RX];   // only the first RU registers of each are used
+      f4v Kc[CA];
       static_for<0, CA>([&](auto jb) {
         static_for<0, RU>([&](auto r2) { Kc[jb.value][r2.value] = slot[Lay::kU + (4 * r2.value + g) * SU + 16 * jb.value + j]; });
-      });
-      static_for<0, RX>([&](auto ib) {
-        static_for<0, RU>([&](auto r2) {
-          const int i = 16 * ib.value + j;
-          Xc[ib.value][r2.value] = (!kRaggedX || i < NX) ? slot[Lay::kX + (kRaggedX && i >= NX ? 0 : i) * XS + 4 * r2.value + g] : 0.f;
-        });
       });
       // ---- value update (:151-152): V~ = Q~x. + Qxu K~ on the state tiles and the affine tile column
       static_for<0, RX>([&](auto ib) {
@@ -350,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void lqr_tile16_kernel(const LqrArgs a) {
 #endif
   if constexpr (ROLLOUT) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the gain stores of this wavefront have reached L2
-    wave_rollout<NX, NU, false>(a, b, lane, live, Ks, ks, info_bits);
+    wave_rollout<NX, NU, false, DMPC_T16_RING>(a, b, lane, live, Ks, ks, info_bits);
   }
   if (a.info != nullptr && live && info_bits != 0) atomicOr(&a.info[b], info_bits);
 }

@@ -23,7 +23,7 @@ static int launch_lqr_tile16(int nx, int nu, bool rollout, const LqrArgs &a, hip
 #define X(NX_, NU_)                                                                                                   \
   if (nx == NX_ && nu == NU_) {                                                                                       \
     constexpr size_t lds = Tile16Layout<NX_, NU_>::lds_bytes();                                                       \
-    static_assert(2 * lds <= 160 * 1024, "two workgroups per CU");                                                    \
+    static_assert(DMPC_T16_OCC * lds <= 160 * 1024, "DMPC_T16_OCC workgroups per CU");                                                    \
     static const bool once = [] {                                                                                     \
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, true>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
@@ -36,7 +36,8 @@ static int launch_lqr_tile16(int nx, int nu, bool rollout, const LqrArgs &a, hip
     else DMPC_LAUNCH_GGL((lqr_tile16_kernel<NX_, NU_, false>), grid, block, lds, stream, a);                          \
     return (int)hipGetLastError();                                                                                    \
   }
-  X(32, 8)
+  // ((16,8) stays on the 4x4x1 kernel: 388 against 384 us at B = 4096, T = 50 - profiles/r05/tile16_shapes.txt)
+  X(32, 8) X(24, 8) X(32, 4) X(24, 4)
 #undef X
   return DMPC_E_UNSUPPORTED;
 }

@@ -132,7 +132,7 @@ __device__ __forceinline__ void wave_dma_region(const void *src, unsigned dst, u
 // nx+m row m of [K_t | 0 | k_t]; ONE pass  acc = aff + sum_i w[i] x_t[i]  (x_t[i] by readlane) gives the state part of
 // x_{t+1} in the F lanes and u_t in the K lanes, then  acc += w[nx+m] u_t[m]  completes x_{t+1}.  The gains were
 // written by this wavefront (other lanes) moments ago: they are read back with glc (from L2, never a stale L1 line).
-template <int NX, int NU, bool MASKED>
+template <int NX, int NU, bool MASKED, int kRing = 4>
 __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, const int lane, const bool live,
                                              const float *Ks, const float *ks, int &info_bits) {
   constexpr int NS = NX + NU, TS = NS / 4, TX = NX / 4;
@@ -206,7 +206,6 @@ __device__ __forceinline__ void wave_rollout(const LqrArgs &a, const int b, cons
     if (f_lane) xv = s;
   };
   // a step is ~100 instructions, a trip to HBM several times that: rows are requested kRing steps ahead
-  constexpr int kRing = 4;
   Row ring[kRing];
   static_for<0, kRing - 1>([&](auto j) { fetch(j.value, ring[j.value]); });
   for (int t0 = 0; t0 < T; t0 += kRing) {

@@ -8,7 +8,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    if 'wave_mfma' in r.get('Kernel_Name', ''):
+    if 'tile16' in r.get('Kernel_Name', '') or 'wave_mfma' in r.get('Kernel_Name', ''):
         agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(agg.items()):
     print("  %-28s n=%3d  mean=%.4g" % (k, len(v), sum(v) / len(v)))
@@ -16,3 +16,4 @@ PY
 }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM
+pass sq3 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE

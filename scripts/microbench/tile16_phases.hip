@@ -32,6 +32,9 @@ int main(int argc, char **argv) {
   dmpc::LqrArgs a{T, B, dC, dc, dF, df, nullptr, nullptr, dK, dk, nullptr, nullptr, reinterpret_cast<float *>(dt), nullptr, nullptr};
   const size_t lds = argc > 2 ? (size_t)atoi(argv[2]) : dmpc::Tile16Layout<32, 8>::lds_bytes();   // a larger request = fewer workgroups per CU
   hipFuncSetAttribute(reinterpret_cast<const void *>(&dmpc::lqr_tile16_kernel<32, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  int occ = -1;
+  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, dmpc::lqr_tile16_kernel<32, 8, false>, 256, lds);
+  printf("dynamic LDS %zu B per workgroup, occupancy query: %d workgroups per CU\n", lds, occ);
   for (int rep = 0; rep < 4; ++rep) {
     hipMemset(dt, 0, 16 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);

@@ -76,7 +76,7 @@ def test_container_shapes_against_oracle(dims, strict):
     if nx > 16:   # (rollout and co-state sweep of these: the kernels that stage a step's blocks through LDS)
         from chainer_differentiable_mpc_amd import _lib
         if dims in ((24, 8), (24, 4), (32, 4)):   # a size that IS one of the sweep's instances: the exact kernel, rollout included
-            assert _lib.last_kernel_name().startswith("void dmpc::lqr_wave_mfma_backward<%d, %d, false, true, false, false>" % dims)
+            assert _lib.last_kernel_name().startswith("void dmpc::lqr_tile16_kernel<%d, %d, true>" % dims)
         else:
             assert _lib.last_kernel_name().startswith("dmpc::lqr_staged_forward_kernel")
     out = node.backward((0, 1, 2, 3, 4), (torch.as_tensor(gx).cuda(), torch.as_tensor(gu).cuda()))

@@ -125,8 +125,10 @@ def test_container_shapes_against_oracle(dims):
         Ks, ks = rec.backward()
         if nx > 16:   # the sweep runs in the smallest wavefront-per-trajectory instance that holds the problem
             inst = next(c for c in ((24, 4), (24, 8), (32, 4), (32, 8)) if nx <= c[0] and nu <= c[1])
-            pad = "false" if dims == inst else "true"     # (a size that IS an instance runs the exact kernel)
-            assert _lib.last_kernel_name().startswith("void dmpc::lqr_wave_mfma_backward<%d, %d, false, false, %s" % (inst + (pad,)))
+            if dims == inst:     # a size that IS an instance runs the exact kernel: the 16x16x4 tile sweep (lqr_tile16.hpp)
+                assert _lib.last_kernel_name().startswith("void dmpc::lqr_tile16_kernel<%d, %d, false>" % inst)
+            else:
+                assert _lib.last_kernel_name().startswith("void dmpc::lqr_wave_mfma_backward<%d, %d, false, false, true" % inst)
         assert_close(npy(torch.stack(Ks)), Ksr, TOL_PRIMAL, "Ks")
         assert_close(npy(torch.stack(ks)), ksr, TOL_PRIMAL, "ks")
         x2, u2 = rec.forward(Ks, ks)
