@@ -40,7 +40,7 @@ __device__ __forceinline__ float test_stream(int iters, float seed, float *lds) 
   return a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)s;
 }
 
-template <int MODE>
+template <int MODE, int GAP>
 __global__ __launch_bounds__(512) void k(float *out, unsigned long long *ticks, int mfma_iters, int test_iters, int prio) {
   __shared__ float lds[2048];
   for (int i = threadIdx.x; i < 2048; i += 512) lds[i] = 1.f;
@@ -55,7 +55,14 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *ticks, 
     const float av = threadIdx.x * 0.001f, bv = 1.f - av;
     for (int it = 0; it < mfma_iters; ++it) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i & 7], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) {
+        acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i & 7], 0, 0, 0);
+        if constexpr (GAP == 1) { asm volatile("s_nop 7\n\ts_nop 7"); }
+        else if constexpr (GAP == 2) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7"); }
+        else if constexpr (GAP == 3) { asm volatile("s_sleep 0"); }
+        else if constexpr (GAP == 4) { asm volatile("s_nop 0"); }
+        else if constexpr (GAP == 5) { asm volatile("s_nop 3\n\ts_nop 3\n\ts_nop 3\n\ts_nop 3\n\ts_nop 3\n\ts_nop 3"); }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(512) void k(float *out, unsigned long long *ticks, 
   if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 8 + wave] = t1 - t0;
 }
 
-template <int MODE>
+template <int MODE, int GAP = 0>
 void run(const char *name, int per_iter, int prio = 0) {
   float *out; unsigned long long *ticks;
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&ticks, 256 * 8 * 8);
@@ -77,7 +84,7 @@ void run(const char *name, int per_iter, int prio = 0) {
   double res[3][2];
   for (int cfg = 0; cfg < 3; ++cfg) {   // 0: both, 1: matrix stream alone, 2: test stream alone
     const int mi = cfg == 2 ? 0 : MI, ti = cfg == 1 ? 0 : TI;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(512), 0, 0, out, ticks, mi, ti, prio);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE, GAP>), dim3(256), dim3(512), 0, 0, out, ticks, mi, ti, prio);
     hipDeviceSynchronize();
     hipMemcpy(h, ticks, sizeof(h), hipMemcpyDeviceToHost);
     res[cfg][0] = (double)h[0] / (MI * 16);          // cycles per MFMA (wave 0)
@@ -99,5 +106,11 @@ int main() {
   run<1>("s_add_u32", 64, 1);
   run<2>("ds_read_b32 (+ v_add)", 64, 1);
   run<3>("v_readlane + v_fma + v_add", 96, 1);
+#define GAPRUN(G, label)                                                       \
+  printf("matrix stream with a gap after every MFMA (%s):\n", label);          \
+  run<0, G>("v_fma_f32 x8 independent", 64);                                    \
+  run<2, G>("ds_read_b32 (+ v_add)", 64);                                       \
+  run<3, G>("v_readlane + v_fma + v_add", 96);
+  GAPRUN(4, "s_nop 0") GAPRUN(1, "2 x s_nop 7") GAPRUN(2, "3 x s_nop 7") GAPRUN(5, "6 x s_nop 3") GAPRUN(3, "s_sleep 0")
   return 0;
 }
