@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdmpc_hip.so"
 LIB_PATH = os.environ.get("DMPC_LIB", os.path.join(_HERE, LIB_NAME))
 
-ABI_VERSION = 400           # include/dmpc.h: DMPC_VERSION the signatures below were written for
+ABI_VERSION = 410           # include/dmpc.h: DMPC_VERSION the signatures below were written for
 E_BADARG, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 INFO_SINGULAR, INFO_NONFINITE, INFO_QP_ITERCAP, INFO_LS_ITERCAP = 1, 2, 4, 8
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "dmpc_mpc_step_backward": (_c_i, [_c_i] * 4 + [_c_f] * 9 + [_c_f] * 7 + [_c_f, _c_f, ctypes.c_float]
                                + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_lin_rollout": (_c_i, [_c_i] * 4 + [_c_f] * 6),
+    "dmpc_mpc_step_status": (_c_i, [_c_i] + [_c_f] * 5),
     "dmpc_box_ddp_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_box_ddp": (_c_i, [_c_i] * 4 + [_c_f] * 5 + [_c_i, _c_f] + [_c_f] * 3 +
                      [ctypes.c_float, _c_i, ctypes.c_float, _c_i, ctypes.c_float, _c_i, _c_i, _c_i, _c_i] +

@@ -559,6 +559,39 @@ static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   return w;
 }
 
+// dmpc_mpc_step_status: one workgroup reduces the step's per-trajectory words (include/dmpc.h)
+__global__ __launch_bounds__(1024) void mpc_step_status_kernel(int B, const int32_t *__restrict__ info, const int32_t *__restrict__ nqp,
+                                                               const float *__restrict__ alphas, int32_t *__restrict__ status) {
+  __shared__ int s_or[16], s_max[16], s_bad[16];
+  __shared__ double s_sum[16];
+  int o = 0, m = 0, bad = 0;
+  double sum = 0.0;
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    if (info != nullptr) {
+      const int v = info[b];
+      o |= v;
+      bad += (v & DMPC_INFO_NONFINITE) != 0 ? 1 : 0;
+    }
+    if (nqp != nullptr) m = max(m, nqp[b]);
+    if (alphas != nullptr) sum += (double)alphas[b];
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    o |= __shfl_xor(o, d);
+    m = max(m, __shfl_xor(m, d));
+    bad += __shfl_xor(bad, d);
+    sum += __shfl_xor(sum, d);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_or[w] = o; s_max[w] = m; s_bad[w] = bad; s_sum[w] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) { o |= s_or[i]; m = max(m, s_max[i]); bad += s_bad[i]; sum += s_sum[i]; }
+    const unsigned long long bits = __double_as_longlong(sum);
+    status[0] = o; status[1] = m; status[2] = bad; status[3] = 0;
+    status[4] = (int32_t)(bits & 0xffffffffull); status[5] = (int32_t)(bits >> 32); status[6] = 0; status[7] = 0;
+  }
+}
+
 static int grid_for(size_t n) {
   const size_t blocks = (n + 255) / 256;
   return (int)(blocks > 8192 ? 8192 : (blocks == 0 ? 1 : blocks));
@@ -726,6 +759,15 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0 || !x_init || !u || !x_out || (T > 1 && !F)) return DMPC_E_BADARG;
   DMPC_LAUNCH_GGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream_), T, B, nx,
                      nu, x_init, u, F, f, x_out, nullptr, ChainClear{});
+  return (int)hipGetLastError();
+}
+
+int dmpc_mpc_step_status(int B, const int32_t *info, const int32_t *n_qp_iter, const float *alphas, int32_t *status,
+                         dmpc_stream_t stream_) {
+  if (B <= 0 || !status) return DMPC_E_BADARG;
+  // (not noted as "the kernel this thread launched last": dmpc_last_kernel_name() keeps naming the step's own kernel)
+  hipLaunchKernelGGL(mpc_step_status_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream_), B, info, n_qp_iter, alphas,
+                     status);
   return (int)hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ Differences from the reference, by design:
 """
 from collections import namedtuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -30,6 +31,49 @@ from .util import LinDx, QuadCost, bdot, bmv, bquad, clamp, get_cost
 
 LqrBackOut = namedtuple("lqrBackOut", "n_total_qp_iter")
 LqrForOut = namedtuple("lqrForOut", "objs full_du_norm alpha_du_norm mean_alphas costs")
+
+
+class _LazyForOut:
+    """`LqrForOut` of the one-launch `MPCstep.forward` (mpc_step.py:175-286) with the two norms formed when first asked for:
+    full_du_norm / alpha_du_norm are a handful of small launches each that most callers (BoxDDP's device loop has its own)
+    never read.  Same fields, order and tuple behaviour as the namedtuple."""
+    _fields = LqrForOut._fields
+    __slots__ = ("objs", "mean_alphas", "costs", "_make_full", "_make_alpha", "_full", "_alpha")
+
+    def __init__(self, objs, make_full, make_alpha, mean_alphas, costs):
+        self.objs, self.mean_alphas, self.costs = objs, mean_alphas, costs
+        self._make_full, self._make_alpha = make_full, make_alpha
+        self._full = self._alpha = None
+
+    @property
+    def full_du_norm(self):
+        if self._full is None:
+            self._full = self._make_full()
+        return self._full
+
+    @property
+    def alpha_du_norm(self):
+        if self._alpha is None:
+            self._alpha = self._make_alpha()
+        return self._alpha
+
+    def _astuple(self):
+        return LqrForOut(self.objs, self.full_du_norm, self.alpha_du_norm, self.mean_alphas, self.costs)
+
+    def __iter__(self):
+        return iter(self._astuple())
+
+    def __len__(self):
+        return 5
+
+    def __getitem__(self, i):
+        return self._astuple()[i]
+
+    def _asdict(self):
+        return self._astuple()._asdict()
+
+    def __repr__(self):
+        return repr(self._astuple())
 
 
 def _is_simple_pendulum(dyn):
@@ -163,6 +207,8 @@ class MPCstep:
         self.alphas = None
         self.info = None
         self._retained = None
+        self._true_model = None   # (the true cost / dynamics tensors as the kernels take them, cached by identity)
+        self._ws_need = None
         self._dev = _device_of(self.controls, self.current_states)
         self._out_dtype = self.controls.dtype if self.controls.dtype.is_floating_point else torch.float32
         self._out_device = self.controls.device
@@ -361,36 +407,55 @@ class MPCstep:
         T, B, nx, nu, ns = self.T, self.n_batch, self.n_state, self.n_ctrl, self.n_sc
         if self._fused_ok():
             lib = _lib.load()
-            Ct, ct = _lib.f32c(_as_tensor(self.true_cost.C), d), _lib.f32c(_as_tensor(self.true_cost.c), d)
-            Ft, ft = _lib.f32c(_as_tensor(self.true_dynamics.F), d), _lib.f32c(_as_tensor(self.true_dynamics.f), d)
-            f32 = dict(dtype=torch.float32, device=d)
-            x, u, u1 = torch.empty((T, B, nx), **f32), torch.empty((T, B, nu), **f32), torch.empty((T, B, nu), **f32)
-            Ks, ks = torch.empty((T, B, nu, nx), **f32), torch.empty((T, B, nu), **f32)
-            costs, old, alphas = torch.empty((B,), **f32), torch.empty((B,), **f32), torch.empty((B,), **f32)
-            objs = torch.empty((T, B), **f32)
-            nqp = torch.empty((B,), dtype=torch.int32, device=d)
-            nls = torch.empty((B,), dtype=torch.int32, device=d)
-            info = torch.zeros(B, dtype=torch.int32, device=d)
-            need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
+            # the true model's arrays: converted once per (object, tensors) - the step is called in a loop with the same ones
+            tm = self._true_model
+            key = (self.true_cost.C, self.true_cost.c, self.true_dynamics.F, self.true_dynamics.f)
+            if tm is None or any(a_ is not b_ for a_, b_ in zip(tm[0], key)):
+                tm = (key, tuple(_lib.f32c(_as_tensor(v), d) for v in key))
+                self._true_model = tm
+            Ct, ct, Ft, ft = tm[1]
+            # ONE allocation for the step's float outputs, one (zeroed) for its integer words; ONE read-back for everything the
+            # reference turns into host scalars or asserts (NaN flags, n_total_qp_iter, mean_alphas): dmpc_mpc_step_status.
+            # The views of the two blocks are cut while the kernel runs: the launch needs their addresses only.
+            sizes = (T * B * nx, T * B * nu, T * B * nu, T * B * nu * nx, T * B * nu, B, B, B, T * B)
+            blk = torch.empty((sum(sizes),), dtype=torch.float32, device=d)
+            iblk = torch.zeros((3 * B + 8,), dtype=torch.int32, device=d)
+            fp, ip = blk.data_ptr(), iblk.data_ptr()
+            offs = [fp]
+            for n_ in sizes[:-1]:
+                offs.append(offs[-1] + 4 * n_)
+            p_x, p_u, p_u1, p_Ks, p_ks, p_costs, p_old, p_alphas, p_objs = offs
+            p_info, p_nqp, p_nls, p_status = ip, ip + 4 * B, ip + 8 * B, ip + 12 * B
+            need = self._ws_need
+            if need is None:
+                need = self._ws_need = lib.dmpc_mpc_step_workspace_bytes(T, B, nx, nu)
             ws = _workspace(need, d)
+            stream = _lib.stream_ptr(d)
             with _lib.guard(d):
                 rc = lib.dmpc_mpc_step_forward(
-                    T, B, nx, nu, _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), _lib.ptr(self._u),
-                    _lib.ptr(self._xs), _lib.ptr(self._lo), _lib.ptr(self._hi), _lib.ptr(Ct), _lib.ptr(ct),
-                    _lib.ptr(Ft), _lib.ptr(ft), 1 if self.need_expand else 0, self.ls_decay, self.max_ls_iter,
-                    self.n_qp_iter_max, 1 if self.batch_coupled else 0, _lib.ptr(x), _lib.ptr(u), _lib.ptr(Ks),
-                    _lib.ptr(ks), _lib.ptr(costs),
-                    _lib.ptr(old), _lib.ptr(alphas), _lib.ptr(objs), _lib.ptr(u1), _lib.ptr(nqp), _lib.ptr(nls),
-                    _lib.ptr(ws), need, _lib.ptr(info), _lib.stream_ptr(d))
-            _lib.check(rc, "dmpc_mpc_step_forward")
-            raise_info(info, "MPCstep.forward")                                 # the reference asserts on NaN
+                    T, B, nx, nu, C.data_ptr(), c.data_ptr(), F.data_ptr(), _lib.ptr(f), self._u.data_ptr(),
+                    self._xs.data_ptr(), self._lo.data_ptr(), self._hi.data_ptr(), Ct.data_ptr(), ct.data_ptr(),
+                    Ft.data_ptr(), _lib.ptr(ft), 1 if self.need_expand else 0, self.ls_decay, self.max_ls_iter,
+                    self.n_qp_iter_max, 1 if self.batch_coupled else 0, p_x, p_u, p_Ks, p_ks, p_costs, p_old, p_alphas, p_objs,
+                    p_u1, p_nqp, p_nls, ws.data_ptr(), need, p_info, stream)
+                _lib.check(rc, "dmpc_mpc_step_forward")
+                _lib.check(lib.dmpc_mpc_step_status(B, p_info, p_nqp, p_alphas, p_status, stream), "dmpc_mpc_step_status")
+            x, u, u1, Ks, ks, costs, old, alphas, objs = (v.view(sh) for v, sh in zip(
+                blk.split(sizes), ((T, B, nx), (T, B, nu), (T, B, nu), (T, B, nu, nx), (T, B, nu), (B,), (B,), (B,), (T, B))))
+            info, nqp, nls, status = iblk[:B], iblk[B:2 * B], iblk[2 * B:3 * B], iblk[3 * B:]
+            st = status.cpu().numpy()                                           # the step's one synchronisation
+            if int(st[0]) & _lib.INFO_NONFINITE:                                # the reference asserts on NaN (:133-135, 211-223);
+                raise AssertionError("MPCstep.forward: NaN/Inf in the solution of %d trajectories" % int(st[2]))   # the kernels flag every non-finite x, u
             self.info, self.n_qp_iter, self.n_ls_iter, self.alphas = info, nqp, nls, alphas
             self.Ks, self.ks = Ks, ks
             scr = not self.strict_math
-            self.back_out = LqrBackOut(n_total_qp_iter=int(nqp.max().item()))
-            self.for_out = LqrForOut(self._out(objs), self._out(du_norm(self._u, u1, scr)),
-                                     self._out(du_norm(self._u, u, scr)), float(alphas.mean().item()),
-                                     self._out(costs))
+            self.back_out = LqrBackOut(n_total_qp_iter=int(st[1]))
+            u_nom = self._u
+            self.for_out = _LazyForOut(self._out(objs), lambda: self._out(du_norm(u_nom, u1, scr)),
+                                       lambda: self._out(du_norm(u_nom, u, scr)),
+                                       float(st[4:6].view(np.float64)[0]) / B, self._out(costs))
+            self._retained.update(x=x, u=u)
+            return self._out(x), self._out(u)
         else:
             if self.need_expand:                                                 # mpc_step.py:305-317
                 tau = torch.cat((self._xs, self._u), dim=2)

@@ -31,7 +31,7 @@ extern "C" {
  * 400 (round 4): covers the round-3 changes that were made under 202 (dmpc_lqr_solve_saving + Vv_out, dmpc_lqr_kkt_grad_saved
  * + Vv, dmpc_pendulum_rollout_linearize + clamp_grad_closed, dmpc_mpc_step_backward + 5 arguments, dmpc_box_ddp dyn_params[6],
  * larger dmpc_lqr_workspace_bytes) and this round's additions. */
-#define DMPC_VERSION 400
+#define DMPC_VERSION 410
 
 #define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
 #define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */
@@ -220,6 +220,15 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
                           float *Ks_out, float *ks_out, float *costs, float *old_costs, float *alphas, float *objs,
                           float *u_first, int32_t *n_qp_iter, int32_t *n_ls_iter, void *ws, size_t ws_bytes,
                           int32_t *info, dmpc_stream_t stream);
+
+/* One read-back per step for the host layer (round 5): the per-trajectory flags and counters of a step, reduced on the device
+ * to eight words, so that MPCstep.forward (mpc_step.py:288-328: its NaN asserts, LqrBackOut.n_total_qp_iter,
+ * LqrForOut.mean_alphas) synchronises once instead of once per scalar.  info / n_qp_iter / alphas [B] (each may be NULL):
+ *   status[0] = OR of info, status[1] = max of n_qp_iter, status[2] = trajectories with DMPC_INFO_NONFINITE,
+ *   status[3] = 0, status[4..5] = the bits of the DOUBLE sum of alphas (low word first), status[6..7] = 0.
+ * One workgroup; `status` [8] int32 is written, not accumulated into. */
+int dmpc_mpc_step_status(int B, const int32_t *info, const int32_t *n_qp_iter, const float *alphas, int32_t *status,
+                         dmpc_stream_t stream);
 
 /* The two halves of forward(), separately callable like the reference's methods:
  * backward_rec (mpc_step.py:70-173): c_hat must already be re-centred when need_expand applies;

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdmpc_hip.so lacks %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.dmpc_version() == _lib.ABI_VERSION == 400
+    assert lib.dmpc_version() == _lib.ABI_VERSION == 410
 
 
 def test_library_belongs_to_the_sources_in_the_tree():
@@ -45,15 +45,15 @@ def test_binding_refuses_a_library_of_another_abi_or_of_other_sources(monkeypatc
     """`_lib.load` compares `dmpc_version()` with the number its ctypes signatures were written for (always),
     and the in-tree library's `dmpc_source_hash()` with the hash of the sources in the tree (unless the library was named
     explicitly: load(path) / DMPC_LIB, the variant builds)"""
-    monkeypatch.setattr(_lib, "ABI_VERSION", 399)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 409)
     with pytest.raises(_lib.DmpcError, match="C-ABI version"):
         _lib.load(_lib.LIB_PATH)
-    monkeypatch.setattr(_lib, "ABI_VERSION", 400)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 410)
     lib = _lib.load(_lib.LIB_PATH)                       # explicit path: version checked, hash not
 
     class Fake:
         def dmpc_version(self):
-            return 400
+            return 410
 
         def dmpc_source_hash(self):
             return b"0" * 32
@@ -63,7 +63,7 @@ def test_binding_refuses_a_library_of_another_abi_or_of_other_sources(monkeypatc
         _lib._check_identity(Fake(), "x.so", explicit=False)
     monkeypatch.setenv("DMPC_SKIP_HASH_CHECK", "1")
     _lib._check_identity(Fake(), "x.so", explicit=False)
-    assert lib.dmpc_version() == 400
+    assert lib.dmpc_version() == 410
 
 
 def test_dispatch_table_and_workspace_queries():
