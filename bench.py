@@ -56,9 +56,33 @@ INFINITY_CACHE_BYTES = 256 * 2 ** 20
 WORKLOADS = {
     # name: (B per GPU, T, nx, nu)
     "headline": (4096, 50, 8, 2),        # BASELINE.json configs[2] - the configuration the metric is quoted on
-    "cfg5-shard": (8192, 50, 32, 8),     # BASELINE.json configs[4]: 65536 trajectories sharded over 8 GPUs
+    "cfg5-shard": (8192, 50, 32, 8),     # BASELINE.json configs[4]: 65536 trajectories sharded over 8 GPUs (see STRONG below)
     "pendulum": (1024, 20, 3, 1),        # shapes of configs[1]/[3] (pure LQR part)
 }
+# workloads whose TOTAL batch is fixed and split over the ranks (strong scaling): config 5 is 65,536 trajectories whatever N is -
+# `--workload cfg5-shard --gpus N` solves 65536 / N per GPU (8 GPUs: the 8,192-trajectory shard the name says; 1 GPU: all of it)
+STRONG = {"cfg5-shard": 65536}
+
+
+def init_distributed(world, rank, local_rank, environ=None):
+    """one process per GPU: (dist module or None, device, backend, device of the timing reductions).  Backend "nccl" is RCCL
+    on ROCm, bound to this rank's device at init (device_id).  Rehearsal knobs (tests/test_dist_gpu.py runs this file with two
+    ranks on a ONE-GPU box): DMPC_BENCH_BACKEND=gloo takes the collectives through the host (RCCL refuses two ranks on one
+    device), DMPC_BENCH_DEVICE pins every rank's device."""
+    environ = os.environ if environ is None else environ
+    backend = environ.get("DMPC_BENCH_BACKEND", "nccl")
+    device = torch.device("cuda", int(environ.get("DMPC_BENCH_DEVICE", local_rank)))
+    torch.cuda.set_device(device)
+    red_dev = device if backend == "nccl" else torch.device("cpu")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, device, backend, red_dev
 
 
 def make_inputs(B, T, nx, nu, seed, device):
@@ -482,6 +506,11 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     B, T, nx, nu = WORKLOADS[args.workload]
+    strong_total = STRONG.get(args.workload)
+    if strong_total is not None:
+        if strong_total % world:
+            raise SystemExit("--workload %s splits %d trajectories over the ranks: --gpus %d does not divide it" % (args.workload, strong_total, world))
+        B = strong_total // world
     # the CPU legs run first, on rank 0 at N = 1 only: the worker pool is forked before this process touches the GPU
     cb = cb_mp = xr = ur = p_host = None
     want_cpu = not args.no_cpu_baseline and world == 1 and B * T * (nx + nu) ** 2 <= 64 * 1024 * 1024
@@ -496,20 +525,7 @@ def main():
         cb, xr, ur = cpu_baseline(p_host, T, nx, nu, args.cpu_seconds)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # rehearsal knobs (tests/test_dist_gpu.py runs this file with two ranks on a ONE-GPU box): DMPC_BENCH_BACKEND=gloo takes
-    # the collectives through the host (RCCL refuses two ranks on one device), DMPC_BENCH_DEVICE pins every rank's device
-    backend = os.environ.get("DMPC_BENCH_BACKEND", "nccl")
-    device = torch.device("cuda", int(os.environ.get("DMPC_BENCH_DEVICE", local_rank)))
-    torch.cuda.set_device(device)
-    red_dev = device if backend == "nccl" else torch.device("cpu")     # where the timing reductions live
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    dist, device, backend, red_dev = init_distributed(world, rank, local_rank)
 
     p, d = make_inputs(B, T, nx, nu, seed=rank, device=device)
     # "Inputs resident in HBM when the timed region starts" - in HBM, not in the 256 MiB Infinity Cache: where one input
@@ -590,8 +606,10 @@ def main():
         # the three times the overlapped figure is made of, every rank making the same number of calls (collectives inside):
         # the solve alone, the gather alone (side stream, waited for), and the two one after the other on one stream
         e0 = sets[0]
+        pipe.reset()      # (the timed region left its own numbering in the two buffer sets)
 
         def timed(fn, reps=10):
+            pipe.reset()
             for _ in range(2):
                 fn()
             torch.cuda.synchronize()
@@ -658,12 +676,13 @@ def main():
             "unit": "timestep-solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if strong_total is None else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: synthetic random LQR, B=%d per GPU, T=%d, n_x=%d, n_u=%d, fused "
+            "config": {"workload": "%s: synthetic random LQR, B=%d per GPU%s, T=%d, n_x=%d, n_u=%d, fused "
                                    "solve_recursion (Riccati backward + rollout), inputs resident in HBM (streamed: "
                                    "input sets in rotation)"
-                                   % (args.workload, B, T, nx, nu),
+                                   % (args.workload, B, "" if strong_total is None else " (%d in all, split over the ranks: BASELINE.json configs[4])" % strong_total,
+                                      T, nx, nu),
                        "global_batch": world * B, "parallelism": "batch-shard x%d%s" % (
                            world, " + overlapped all-gather(x,u)" if gx is not None else ", no collective")
                        + ("" if backend == "nccl" else " [REHEARSAL: backend %s, every rank on %s - not a scaling number]" % (backend, device))},

@@ -139,6 +139,16 @@ class GatherPipeline:
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
         self.gathered = [None, None]    # event: gather k has finished (side stream)
+        self.step_of = [None, None]     # which solve each buffer set holds (or is receiving)
+        self.newest = None              # the latest solve handed to gather()
+        if self.world > 1:              # equal shards are assumed by every collective below: checked once, not per gather
+            mine = torch.tensor([self.shapes[0][1]], dtype=torch.int64, device=self.device)
+            every = torch.empty((self.world,), dtype=torch.int64, device=self.device)
+            _all_gather_into(every, mine, group)
+            sizes = [int(v) for v in every.cpu().tolist()]
+            if len(set(sizes)) != 1:
+                raise ValueError("GatherPipeline needs equal shards on every rank, got batch sizes %r "
+                                 "(all_gather_batch handles ragged shards)" % (sizes,))
 
     def _pieces(self, shape, dtype):
         flat = torch.empty((self.world * _prod(shape),), dtype=dtype, device=self.device)
@@ -149,8 +159,25 @@ class GatherPipeline:
             off += n
         return pieces
 
+    def reset(self):
+        """forget which solves the buffer sets hold (both streams are waited for first): the next solve may be numbered anew"""
+        if self.cuda:
+            torch.cuda.current_stream(self.device).synchronize()
+            self.side.synchronize()
+        self.gathered, self.step_of, self.newest = [None, None], [None, None], None
+
+    def _check_current(self, k, what):
+        """buffer set k % 2 must hold solve k: an older k names a set that a later gather is overwriting on the side stream"""
+        if self.step_of[k % 2] != k:
+            raise ValueError("GatherPipeline.%s(%d): that buffer set holds solve %r (two sets in rotation: only the newest "
+                             "solve and the one before it are kept, newest = %r)" % (what, k, self.step_of[k % 2], self.newest))
+
     def local_buffers(self, k):
         """the buffer set solve k writes; the caller's stream first waits for the gather that last read it (k - 2)"""
+        if self.newest is not None and k < self.newest - 1:
+            raise ValueError("GatherPipeline.local_buffers(%d): solve %d has already been gathered" % (k, self.newest))
+        if self.step_of[k % 2] is not None and self.step_of[k % 2] > k:
+            raise ValueError("GatherPipeline.local_buffers(%d): that buffer set already holds solve %d" % (k, self.step_of[k % 2]))
         ev = self.gathered[k % 2]
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)
@@ -158,6 +185,10 @@ class GatherPipeline:
 
     def gather(self, k):
         """enqueue the all-gather of buffer set k % 2 behind the work now on the caller's stream, on the side stream"""
+        if self.step_of[k % 2] is not None and self.step_of[k % 2] > k:
+            raise ValueError("GatherPipeline.gather(%d): that buffer set already holds solve %d" % (k, self.step_of[k % 2]))
+        self.step_of[k % 2] = k
+        self.newest = k if self.newest is None else max(self.newest, k)
         loc, out = self.local[k % 2], self.out[k % 2]
         if not self.cuda:
             for pieces, t in zip(out, loc):
@@ -177,6 +208,7 @@ class GatherPipeline:
 
     def result(self, k):
         """the gathered tensors of solve k (one list of pieces per tensor); the caller's stream waits for their arrival"""
+        self._check_current(k, "result")
         ev = self.gathered[k % 2]
         if ev is not None:
             torch.cuda.current_stream(self.device).wait_event(ev)

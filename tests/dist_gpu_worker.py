@@ -4,8 +4,10 @@
     shard_problem -> solve_device / kkt_grad_device (the HIP library) -> all_gather_batch / all_reduce_param_grad
     (+ the overlapped GatherPipeline over three consecutive solves)
 
-Both ranks use GPU 0 (a one-GPU box); the backend is gloo (RCCL refuses two ranks on one device), which dist.py serves by
-staging the collectives through the host.  Rank 0 also solves the UNSHARDED problem with the same library and writes
+Default: both ranks use GPU 0 (a one-GPU box) and the backend is gloo (RCCL refuses two ranks on one device), which dist.py
+serves by staging the collectives through the host.  DIST_BACKEND=nccl: RCCL, rank r on device LOCAL_RANK - two devices for two
+ranks, or a process group of ONE rank on device 0 (the collectives then run through RCCL's own code path on the side stream,
+which is what a one-GPU box can prove of it).  Rank 0 also solves the UNSHARDED problem with the same library and writes
 both to `out` for the parent to compare bit for bit.  Environment: RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT."""
 import os
 import sys
@@ -21,14 +23,19 @@ sys.path.insert(0, ROOT)
 def main():
     out_path, B, T, nx, nu = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DIST_BACKEND", "gloo")
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from chainer_differentiable_mpc_amd import _lib, synthetic
     from chainer_differentiable_mpc_amd.differentiable_lqr import kkt_grad_device
     from chainer_differentiable_mpc_amd.dist import (GatherPipeline, all_gather_batch, all_reduce_param_grad, shard_bounds,
                                                      shard_problem)
     from chainer_differentiable_mpc_amd.lqr_recursion import solve_device
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=11)
     full = [torch.as_tensor(p[k], dtype=torch.float32, device=dev) for k in ("x_init", "C", "c", "F", "f")]
     x0, C, c, F, f = shard_problem(*full)
@@ -55,6 +62,10 @@ def main():
         if k >= 1:      # consume the previous gather while this one is in flight
             piped.append(GatherPipeline.as_time_major(pipe.result(k - 1)[0]).clone())
     piped.append(GatherPipeline.as_time_major(pipe.result(2)[0]).clone())
+    if backend == "nccl":     # RCCL's all-reduce and barrier too, whatever the group's size
+        ones = torch.ones(4, device=dev)
+        dist.all_reduce(ones)
+        assert float(ones.sum()) == 4.0 * world
     torch.cuda.synchronize()
     if rank == 0:
         xf, uf, _, _ = solve_device(full[1], full[2], full[3], full[4], full[0], None, T, nx, nu)
@@ -67,7 +78,7 @@ def main():
                  dF_sum=dF_sum.cpu().numpy(), dF_sum_full=g_full[3].double().sum(dim=(0, 1)).cpu().numpy(),
                  dx0_local=dx0.cpu().numpy(), dx0_full=g_full[0].cpu().numpy(), b0=b0, b1=b1,
                  piped=np.stack([t.cpu().numpy() for t in piped]), piped_ref=np.stack([t.cpu().numpy() for t in piped_ref]),
-                 kernel=np.array(kernel), lib=np.array(_lib.LIB_PATH))
+                 kernel=np.array(kernel), lib=np.array(_lib.LIB_PATH), backend=np.array(dist.get_backend()))
     dist.barrier()
     dist.destroy_process_group()
 

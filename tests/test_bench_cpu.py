@@ -55,3 +55,45 @@ def test_bench_command_line_is_the_drivers():
     assert r.returncode == 0, r.stderr
     for flag in ("--gpus", "--steps", "--warmup", "--workload", "--gather", "--allow-secondary-failure"):
         assert flag in r.stdout
+
+
+def test_the_rccl_argument_path_up_to_init_process_group(monkeypatch):
+    """bench.py's N > 1 start-up with the default backend, as far as a box without a GPU can take it: backend "nccl" (= RCCL
+    on ROCm), this rank's device bound at init (device_id), the timing reductions on that device, MASTER_ADDR defaulted to
+    127.0.0.1 - with torch.distributed.init_process_group and torch.cuda.set_device replaced by recorders."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = {}
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.setdefault("set_device", d))
+    monkeypatch.setattr(dist, "init_process_group", lambda *a, **k: calls.setdefault("init", (a, k)))
+    env = {}
+    d, device, backend, red_dev = bench.init_distributed(world=8, rank=5, local_rank=5, environ=env)
+    assert d is dist and backend == "nccl" and device == torch.device("cuda", 5) and red_dev == device
+    assert calls["set_device"] == device
+    a, k = calls["init"]
+    assert a == ("nccl",) and k == dict(rank=5, world_size=8, device_id=device)
+    assert env["MASTER_ADDR"] == "127.0.0.1"
+    # the rehearsal knobs: gloo through the host, every rank on one device
+    calls.clear()
+    env = {"DMPC_BENCH_BACKEND": "gloo", "DMPC_BENCH_DEVICE": "0"}
+    d, device, backend, red_dev = bench.init_distributed(world=2, rank=1, local_rank=1, environ=env)
+    assert backend == "gloo" and device == torch.device("cuda", 0) and red_dev == torch.device("cpu")
+    assert calls["init"] == (("gloo",), dict(rank=1, world_size=2))
+    # one rank: no process group at all
+    calls.clear()
+    d, device, backend, red_dev = bench.init_distributed(world=1, rank=0, local_rank=0, environ={})
+    assert d is None and "init" not in calls
+
+
+def test_config5_is_a_strong_scaling_workload():
+    """`--workload cfg5-shard --gpus N`: 65,536 trajectories in all whatever N is (BASELINE.json configs[4]); N = 8 gives the
+    8,192-trajectory shard of the name"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.STRONG == {"cfg5-shard": 65536}
+    assert bench.STRONG["cfg5-shard"] // 8 == bench.WORKLOADS["cfg5-shard"][0] == 8192
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"scaling": "weak" if strong_total is None else "strong"' in src
+    assert '"global_batch": world * B' in src

@@ -101,3 +101,46 @@ def test_gather_pipeline_world2_chunked(tmp_path):
     port = free_port()
     mp.spawn(pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(os.path.join(str(tmp_path), "ok"))
+
+
+def pipeline_guard_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from chainer_differentiable_mpc_amd.dist import GatherPipeline
+    T, b, nx = 4, 3, 2
+    pipe = GatherPipeline([(T, b, nx)], "cpu", chunks=2)
+    for k in range(3):
+        pipe.local_buffers(k)[0].fill_(float(10 * k + rank))
+        pipe.gather(k)
+    assert float(GatherPipeline.as_time_major(pipe.result(2)[0])[0, 0, 0]) == 20.0
+    assert float(GatherPipeline.as_time_major(pipe.result(1)[0])[0, b, 0]) == 11.0      # the one before the newest is still there
+    for bad in (lambda: pipe.result(0), lambda: pipe.local_buffers(0), lambda: pipe.gather(0)):   # set 0 holds solve 2 by now
+        try:
+            bad()
+        except ValueError as e:
+            assert "solve" in str(e)
+        else:
+            raise AssertionError("a stale step index went through")
+    pipe.reset()
+    pipe.local_buffers(0)
+    pipe.gather(0)
+    pipe.result(0)
+    ragged = None
+    try:       # shards of different sizes: refused at construction (every rank raises: the size exchange is a collective)
+        GatherPipeline([(T, b + rank, nx)], "cpu")
+    except ValueError as e:
+        ragged = str(e)
+    assert ragged is not None and "equal shards" in ragged
+    if rank == 0:
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_pipeline_refuses_stale_steps_and_ragged_shards(tmp_path):
+    """the two buffer sets carry the number of the solve they hold - `result(k - 2)` after `gather(k)` used to read
+    a buffer the side stream was overwriting; shards of different sizes used to reach the equal-size collective"""
+    port = free_port()
+    mp.spawn(pipeline_guard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok"))
