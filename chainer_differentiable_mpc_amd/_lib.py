@@ -111,17 +111,32 @@ def _check_identity(lib, p, explicit):
             p, ver, ABI_VERSION, os.path.join(_HERE, "csrc", "build.py")))
     if explicit or os.environ.get("DMPC_SKIP_HASH_CHECK") == "1":
         return
+    # (1) the library against the stamp csrc/build.py wrote next to it: no source is read, nothing is executed
+    got = lib.dmpc_source_hash().decode()
+    stamp_path = p + ".srchash"
+    stamp = open(stamp_path).read().split("\n") if os.path.exists(stamp_path) else None
+    if stamp is not None and stamp[0].strip() != got:
+        raise DmpcError("%s (source hash %s) does not belong to the stamp next to it (%s: %s) - the library was replaced without "
+                        "its stamp; rebuild it (python %s)" % (p, got, stamp_path, stamp[0].strip(), os.path.join(_HERE, "csrc", "build.py")))
+    # (2) the stamp against the sources in the tree - only where there is a source tree (an installed package without the
+    # kernels' sources has nothing to compare against).  What differs is named: the SOURCES (edited after the build: refused)
+    # or only the build's flags / GEN_* knobs in this process's environment (the same sources: accepted)
     build_py = os.path.join(_HERE, "csrc", "build.py")
-    if not os.path.exists(build_py):
-        return                      # installed without sources: nothing to compare against
+    import glob
+    if not os.path.exists(build_py) or not glob.glob(os.path.join(_HERE, "csrc", "*.hip")):
+        return
     import importlib.util
     spec = importlib.util.spec_from_file_location("_dmpc_build", build_py)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    want, got = mod.source_hash(), lib.dmpc_source_hash().decode()
-    if want != got:
-        raise DmpcError("%s was built from other sources (library %s, tree %s) - rebuild it (python %s), or set "
-                        "DMPC_SKIP_HASH_CHECK=1 to use it anyway" % (p, got, want, build_py))
+    if mod.source_hash() == got:
+        return
+    if stamp is not None and len(stamp) > 1 and stamp[1].strip() == mod.content_hash():
+        return       # same sources, built with other flags / knobs than this process's environment names
+    raise DmpcError("%s was built from other SOURCES than the tree's (library %s; tree %s with this environment's flags, "
+                    "sources alone %s against the stamp's %s) - rebuild it (python %s), or set DMPC_SKIP_HASH_CHECK=1 to use "
+                    "it anyway" % (p, got, mod.source_hash(), mod.content_hash(),
+                                   stamp[1].strip() if stamp is not None and len(stamp) > 1 else "?", build_py))
 
 
 def last_kernel_name():

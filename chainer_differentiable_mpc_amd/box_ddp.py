@@ -405,6 +405,12 @@ class BoxDDP(torch.nn.Module):
         needs_graph = any(isinstance(t, torch.Tensor) and t.requires_grad for t in (Cm, cm, Fm, fm, x_init))
         if needs_graph:
             x, u = node.apply((x[0].detach(), Cm, cm, Fm, fm))
+        if self.detach_unconverged and deferred and x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a hipGraph is being captured on this (generic) path: the read-back below would end the capture with an error deep
+            # inside the runtime - say what is and is not capturable instead
+            raise RuntimeError("BoxDDP: this solve cannot be captured in a hipGraph with detach_unconverged=True (the gradient "
+                               "path of a cost that is not a TiledQuadCost, or the host loop, decides the detach mask on the "
+                               "host); capture with detach_unconverged=False, or use a TiledQuadCost on the device loop")
         if self.detach_unconverged and unconverged():                                      # :263-289
             self._warn()
             if last_norm is None:

@@ -5,12 +5,27 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <unordered_map>
+
 namespace dmpc {
 
 // Vector loads (float2/float4) assume 16-byte aligned array bases; NULL is "absent", hence fine.
 static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 static constexpr size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, set once per kernel (and again only for a larger request), not per
+// launch: the call costs a few microseconds of host time, as much as the launch it precedes
+inline void set_max_lds(const void *kernel, int bytes) {
+  static std::mutex m;
+  static std::unordered_map<const void *, int> done;
+  std::lock_guard<std::mutex> g(m);
+  auto it = done.find(kernel);
+  if (it != done.end() && it->second >= bytes) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done[kernel] = bytes;
+}
 
 // The kernel this thread launched last, for dmpc_last_kernel_name() (diagnostics and benchmark labelling: the name a
 // profiler lists is asked of the runtime, not kept by hand).  Thread-local: entry points stay thread-compatible.

@@ -77,11 +77,16 @@ def source_hash():
     return _sha(hand_written_sources(), " ".join(HASHED_FLAGS) + gen_env())[:32]
 
 
+def content_hash():
+    """the hand-written sources alone: no flags, no GEN_* knobs - what tells "the sources were edited" from "built with knobs"."""
+    return _sha(hand_written_sources(), "")[:32]
+
+
 def is_current():
     """the library in the tree was built from the sources in the tree"""
     if not (os.path.exists(OUT) and os.path.exists(STAMP)):
         return False
-    return open(STAMP).read().strip() == source_hash()
+    return open(STAMP).read().split()[0] == source_hash()
 
 
 def generate(force=False):
@@ -145,7 +150,8 @@ def build(force=False, jobs=None, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-        open(STAMP, "w").write(src_hash)
+        # line 1: what dmpc_source_hash() returns (sources + flags + GEN_* knobs); line 2: the sources alone; line 3: the knobs
+        open(STAMP, "w").write("%s\n%s\n%s\n" % (src_hash, content_hash(), " ".join(HASHED_FLAGS) + " " + gen_env()))
     if verbose:
         print("built", OUT, "(%d translation units, %d recompiled, source hash %s)" % (len(srcs), rebuilt, src_hash))
     return OUT

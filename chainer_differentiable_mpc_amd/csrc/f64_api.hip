@@ -272,7 +272,7 @@ static constexpr size_t kMaxLds = 160 * 1024;
 template <class K>
 static void allow_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024)   // above the default limit the runtime wants to be told (once per kernel; cheap to repeat)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    set_max_lds(reinterpret_cast<const void *>(kernel), (int)bytes);
 }
 
 // returns 0 / a HIP error, or DMPC_E_UNSUPPORTED when the shape has no instantiation (nothing launched)

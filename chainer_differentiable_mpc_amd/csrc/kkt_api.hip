@@ -99,8 +99,8 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
     using Lay = CostateWideLayout<NX_, NU_, 2>;                                                                \
     static_assert(Lay::lds_bytes() <= 160 * 1024, "ring and staging beyond a CU's LDS");                      \
     if (Lay::lds_bytes() > 64 * 1024)                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_wide_kernel<NX_, NU_, 2>),             \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+      set_max_lds(reinterpret_cast<const void *>(&costate_wide_kernel<NX_, NU_, 2>), \
+                                (int)Lay::lds_bytes());           \
     DMPC_LAUNCH_GGL((costate_wide_kernel<NX_, NU_, 2>), dim3((a.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, a); \
     return (int)hipGetLastError();                                                                             \
   }
@@ -121,8 +121,8 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
     using Lay = CostateWideLayout<NX_, NU_, 2, true>;                                                          \
     static_assert(Lay::lds_bytes() <= 160 * 1024, "ring and staging beyond a CU's LDS");                      \
     if (Lay::lds_bytes() > 64 * 1024)                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_wide_kernel<NX_, NU_, 2, true>),       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+      set_max_lds(reinterpret_cast<const void *>(&costate_wide_kernel<NX_, NU_, 2, true>), \
+                                (int)Lay::lds_bytes());           \
     DMPC_LAUNCH_GGL((costate_wide_kernel<NX_, NU_, 2, true>), dim3((p.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, p); \
     return (int)hipGetLastError();                                                                             \
   }
@@ -132,8 +132,7 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
           using Lay = CostateWideLayout<16, 8, 2, true>;
           constexpr int kWaves = 3;
           static_assert(Lay::lds_bytes(kWaves) <= 160 * 1024, "ring and staging beyond a CU's LDS");
-          (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_wide_kernel<16, 8, 2, true, kWaves>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes(kWaves));
+          set_max_lds(reinterpret_cast<const void *>(&costate_wide_kernel<16, 8, 2, true, kWaves>), (int)Lay::lds_bytes(kWaves));
           DMPC_LAUNCH_GGL((costate_wide_kernel<16, 8, 2, true, kWaves>), dim3((p.B + 4 * kWaves - 1) / (4 * kWaves)),
                           dim3(64 * kWaves), Lay::lds_bytes(kWaves), stream, p);
           return (int)hipGetLastError();
@@ -160,8 +159,7 @@ int launch_costate(int nx, int nu, const CostateArgs &a, hipStream_t stream) {
         const size_t shmem = costate_staged_lds_bytes(nx, nu, a.r_cols);
         if (!staged_off && a.T >= 2 && nx + nu <= 63 && shmem <= 150 * 1024) {
           if (shmem > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&costate_staged_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            set_max_lds(reinterpret_cast<const void *>(&costate_staged_kernel), (int)shmem);
           DMPC_LAUNCH_GGL(costate_staged_kernel, dim3(a.B), dim3(64), shmem, stream, a, nx, nu);
           return (int)hipGetLastError();
         }

@@ -328,12 +328,16 @@ static bool wide_container_shape(int nx, int nu) {
 }
 // can the wide kernel take this solve?  (whole wavefronts of four trajectories, a horizon with an F, 32-bit time strides;
 // the gain rows travel through the caller's workspace, rows of the INSTANCE's width - dmpc_lqr_workspace_bytes allows for it)
+// the geometric half of wide_ok - shape, batch, horizon and the 32-bit stride bound - shared with dmpc_lqr_solve_path, so that the
+// path a caller is told (and sizes its workspace for) is the path dispatch_lqr takes
+static bool wide_geometry_ok(int T, int B, int nx, int nu) {
+  const bool exact = wide_shape(nx, nu), padded = wide_container_shape(nx, nu) && B % 4 == 0 && !container_disabled();
+  return (exact || padded) && !wide_disabled() && B >= 4 && T >= 2 && (size_t)B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
+}
 static bool wide_ok(int mode, int nx, int nu, const LqrArgs &a) {
-  const bool exact = wide_shape(nx, nu), padded = wide_container_shape(nx, nu) && a.B % 4 == 0 && !container_disabled();
   // (the generated streams' own argument forms - c in two arrays, saved gains, x_init = 0 - are not its business)
   const bool plain = a.c_u == nullptr && a.Ks_in == nullptr && a.Vv_in == nullptr && a.Quu_out == nullptr && a.x_init != nullptr;
-  return mode == kSolve && plain && (exact || padded) && !wide_disabled() && a.wsK != nullptr &&
-         a.B >= 4 && a.T >= 2 && (size_t)a.B * (nx + nu) * (nx + nu) * 4 < ((size_t)1 << 31);
+  return mode == kSolve && plain && wide_geometry_ok(a.T, a.B, nx, nu) && a.wsK != nullptr;
 }
 static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream) {
   const dim3 grid((a.B + 15) / 16), block(256);
@@ -342,13 +346,17 @@ static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream)
     constexpr int DB = 2, DF = 2;                                                                          \
     constexpr size_t lds = LqrWideLayout<NX_, NU_, DB, DF>::lds_bytes();                                   \
     static_assert(lds <= 160 * 1024, "rings beyond a CU's LDS");                                           \
-    if (lds > 64 * 1024)                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF>),        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+    static const bool attr_once = [] {   /* the LDS request above 64 KB: set once per instantiation, not per launch */ \
+      if (lds > 64 * 1024) {                                                                               \
+        set_max_lds(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF>), \
+                                  (int)lds);                   \
+        set_max_lds(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, false, true>), \
+                                  (int)lds);                   \
+      }                                                                                                    \
+      return true;                                                                                         \
+    }();                                                                                                   \
+    (void)attr_once;                                                                                       \
     if (a.mask != nullptr) {                                                                               \
-      if (lds > 64 * 1024)                                                                                 \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, false, true>), \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
       DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, false, true>), grid, block, lds, stream, a);      \
     } else {                                                                                               \
       DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF>), grid, block, lds, stream, a);                   \
@@ -365,12 +373,12 @@ static int launch_lqr_wide(int nx, int nu, const LqrArgs &a, hipStream_t stream)
     constexpr int DB = 2, DF = 2;                                                                          \
     constexpr size_t lds = LqrWideLayout<NX_, NU_, DB, DF>::lds_bytes();                                   \
     if (lds > 64 * 1024)                                                                                   \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true>),  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      set_max_lds(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true>), \
+                                (int)lds);                     \
     if (p.mask != nullptr) {                                                                               \
       if (lds > 64 * 1024)                                                                                 \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true, true>), \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        set_max_lds(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, DB, DF, true, true>), \
+                                  (int)lds);                   \
       DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, true, true>), grid, block, lds, stream, p);       \
     } else {                                                                                               \
       DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, DB, DF, true>), grid, block, lds, stream, p);             \
@@ -543,12 +551,12 @@ int dmpc_lqr_kernel_family(int nx, int nu) { return lqr_family(nx, nu); }
 
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu) {
   if (T <= 0 || B <= 0) return DMPC_E_BADARG;
-  if (wide_shape(nx, nu) && !wide_disabled() && B >= 4 && T >= 2) return 9;   // lqr_wide_kernel (given the workspace)
+  if (wide_shape(nx, nu) && wide_geometry_ok(T, B, nx, nu)) return 9;   // lqr_wide_kernel (given the workspace)
 #define X(NX_, NU_, L_) \
   if (nx == NX_ && nu == NU_) return solve_path<NX_, NU_, L_>(T, B);
   DMPC_LQR_SHAPES(X)
 #undef X
-  if (wide_container_shape(nx, nu) && !wide_disabled() && !container_disabled() && B >= 4 && B % 4 == 0 && T >= 2) return 9;
+  if (wide_container_shape(nx, nu) && wide_geometry_ok(T, B, nx, nu)) return 9;
   if (lqr_family(nx, nu) == 4 && !container_disabled()) return 7;   // a container kernel (lqr_kernel<..., PAD>)
   if (lqr_family(nx, nu) == 5) return 8;                              // lqr_tiled_kernel: any size
   return (lqr_family(nx, nu) == 3 || lqr_family(nx, nu) == 4) ? 0 : DMPC_E_UNSUPPORTED;

@@ -196,12 +196,12 @@ __global__ __launch_bounds__(256, DMPC_T16_OCC) void lqr_tile16_kernel(const Lqr
     const unsigned long long base = reinterpret_cast<unsigned long long>(src);
     static_for<0, Img::n_full()>([&](auto k) {
       constexpr int tl = Img::full_tile(k.value), ib = tl / CA, jb = tl % CA;
-      set_m0(dst + k.value * 1024);
+      set_m0(__builtin_amdgcn_readfirstlane(dst + k.value * 1024));   // (uniform by construction; said so for -O1 builds)
       tile16_dma_full<NT>(vpat, base + (16 * ib * NS + 16 * jb) * 4);
     });
     static_for<0, Img::tail_instrs()>([&](auto k) {
       constexpr int left = Img::total_chunks() - 64 * (Img::n_full() + k.value);
-      set_m0(dst + (Img::n_full() + k.value) * 1024);
+      set_m0(__builtin_amdgcn_readfirstlane(dst + (Img::n_full() + k.value) * 1024));
       if constexpr (left >= 64) tile16_dma_full<NT>(tail[k.value], base);
       else tile16_dma_masked<NT>(tail[k.value], base, (1ull << left) - 1);
     });

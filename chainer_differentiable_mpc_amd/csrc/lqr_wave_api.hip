@@ -25,10 +25,10 @@ static int launch_lqr_tile16(int nx, int nu, bool rollout, const LqrArgs &a, hip
     constexpr size_t lds = Tile16Layout<NX_, NU_>::lds_bytes();                                                       \
     static_assert(DMPC_T16_OCC * lds <= 160 * 1024, "DMPC_T16_OCC workgroups per CU");                                                    \
     static const bool once = [] {                                                                                     \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, true>),                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, false>),                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                \
+      set_max_lds(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, true>), \
+                                (int)lds);                                \
+      set_max_lds(reinterpret_cast<const void *>(&lqr_tile16_kernel<NX_, NU_, false>), \
+                                (int)lds);                                \
       return true;                                                                                                    \
     }();                                                                                                              \
     (void)once;                                                                                                       \
@@ -117,8 +117,7 @@ int launch_lqr_staged_forward(int nx, int nu, const LqrArgs &a, hipStream_t stre
   if (off || a.mask != nullptr || a.T < 2 || nx + nu > 63 || shmem > 150 * 1024 || (a.Ks == nullptr && a.wsK == nullptr))
     return DMPC_E_UNSUPPORTED;
   if (shmem > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_staged_forward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    set_max_lds(reinterpret_cast<const void *>(&lqr_staged_forward_kernel), (int)shmem);
   DMPC_LAUNCH_GGL(lqr_staged_forward_kernel, dim3(a.B), dim3(64), shmem, stream, a, nx, nu);
   return (int)hipGetLastError();
 }

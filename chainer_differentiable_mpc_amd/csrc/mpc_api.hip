@@ -224,8 +224,8 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   if (nx == NX_ && nu == NU_) {                                                                                \
     constexpr size_t lds = LqrWideLayout<NX_, NU_, 2, 2>::lds_bytes();                                         \
     if (lds > 64 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, 2, 2, false, false, true>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      set_max_lds(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, 2, 2, false, false, true>), \
+                                (int)lds);                         \
     DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, 2, 2, false, false, true>), dim3((s.B + 15) / 16), dim3(256), lds, stream, s); \
     return (int)hipGetLastError();                                                                             \
   }
@@ -240,8 +240,8 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   if (nx <= NX_ && nu <= NU_) {                                                                                \
     constexpr size_t lds = LqrWideLayout<NX_, NU_, 2, 2>::lds_bytes();                                         \
     if (lds > 64 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, 2, 2, true, false, true>), \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      set_max_lds(reinterpret_cast<const void *>(&lqr_wide_kernel<NX_, NU_, 2, 2, true, false, true>), \
+                                (int)lds);                         \
     DMPC_LAUNCH_GGL((lqr_wide_kernel<NX_, NU_, 2, 2, true, false, true>), dim3((s.B + 15) / 16), dim3(256), lds, stream, s); \
     return (int)hipGetLastError();                                                                             \
   }
@@ -411,8 +411,8 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     using Lay = MpcWideFwdLayout<NX_, NU_, 2>;                                                                 \
     static_assert(Lay::lds_bytes() <= 160 * 1024, "ring beyond a CU's LDS");                                   \
     if (Lay::lds_bytes() > 64 * 1024)                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc_wide_forward_kernel<NX_, NU_, 2>),         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+      set_max_lds(reinterpret_cast<const void *>(&mpc_wide_forward_kernel<NX_, NU_, 2>), \
+                                (int)Lay::lds_bytes());           \
     DMPC_LAUNCH_GGL((mpc_wide_forward_kernel<NX_, NU_, 2>), dim3((a.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, a); \
     return (int)hipGetLastError();                                                                             \
   }
@@ -426,8 +426,8 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
   if (nx <= NX_ && nu <= NU_) {                                                                                \
     using Lay = MpcWideFwdLayout<NX_, NU_, 2>;                                                                 \
     if (Lay::lds_bytes() > 64 * 1024)                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc_wide_forward_kernel<NX_, NU_, 2, true>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lay::lds_bytes());           \
+      set_max_lds(reinterpret_cast<const void *>(&mpc_wide_forward_kernel<NX_, NU_, 2, true>), \
+                                (int)Lay::lds_bytes());           \
     DMPC_LAUNCH_GGL((mpc_wide_forward_kernel<NX_, NU_, 2, true>), dim3((p.B + 15) / 16), dim3(256), Lay::lds_bytes(), stream, p); \
     return (int)hipGetLastError();                                                                             \
   }
@@ -452,8 +452,7 @@ static int launch_mpc_fwd(int nx, int nu, const MpcFwdArgs &a_in, hipStream_t st
     const size_t shmem = mpc_staged_fwd_lds_bytes(nx, nu);
     if (shmem <= 150 * 1024) {
       if (shmem > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&mpc_staged_forward_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        set_max_lds(reinterpret_cast<const void *>(&mpc_staged_forward_kernel), (int)shmem);
       DMPC_LAUNCH_GGL(mpc_staged_forward_kernel, dim3(a.B), dim3(64), shmem, stream, a, nx, nu);
       return (int)hipGetLastError();
     }

@@ -73,8 +73,9 @@ int dmpc_lqr_kernel_family(int nx, int nu);
  *   8 lqr_tiled_kernel (any size: a workgroup per trajectory, matrices in `ws`)
  *   9 lqr_wide_kernel (17 to 32 augmented columns, at most 16 states - (16,4), (16,8), (12,4), (12,8), and padded inside
  *     them every shape with nx <= 16, nu <= 8, nx + nu >= 16 when B % 4 == 0: four trajectories per wavefront, two
- *     registers per matrix row, outer products on the matrix cores; needs `ws` - without it, a masked solve or B < 4
- *     takes path 7)                                                         <0 unsupported */
+ *     registers per matrix row, outer products on the matrix cores; plain and masked (LQR_active) solves alike; needs `ws` -
+ *     without it, with B < 4, T < 2 or B (nx+nu)^2 floats beyond 2^31 bytes the solve takes path 7 / 5)   <0 unsupported
+ *   (round 5: the plain sweep of path 5 at (32,8), (24,8), (32,4), (24,4) is lqr_tile16_kernel - 16x16x4 tiles) */
 int dmpc_lqr_solve_path(int T, int B, int nx, int nu);
 
 /* ---- A. LqrRecursion (lqr/lqr_recursion.py:69-209) and LQR_active

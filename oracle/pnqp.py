@@ -34,7 +34,7 @@ def calc_obj(H, q, x):
     return 0.5 * bquad(x, H) + bdot(q, x)
 
 
-def _pnqp_coupled(H, q, lower, upper, x_init, n_iter):
+def _pnqp_coupled(H, q, lower, upper, x_init, n_iter, norm_log=None):
     assert (lower <= upper).all(), " lower is larger than upper"
     B, n = q.shape
     assert H.shape == (B, n, n) and lower.shape == (B, n) and upper.shape == (B, n)
@@ -67,6 +67,8 @@ def _pnqp_coupled(H, q, lower, upper, x_init, n_iter):
             H_lu_f = batch_lu_factor(H_f)                                    # :136
             dx = -batch_lu_solve(H_lu_f, g_f)                                # :137 (float32)
         norm = np.sqrt(np.sum(dx ** 2, axis=1))                              # :139
+        if norm_log is not None:      # (test infrastructure: how close each pass came to the threshold)
+            norm_log.append(np.array(norm, copy=True))
         batch_large = norm >= DX_TOL
         if np.sum(batch_large.astype(float)) == 0:                           # :143
             return x, (H_f if n == 1 else H_lu_f), Index_f, i, True
@@ -90,7 +92,8 @@ def _pnqp_coupled(H, q, lower, upper, x_init, n_iter):
 
 
 def pnqp(H, q, lower, upper, x_init=None, n_iter=20, batch_coupled=True,
-         return_info=False, warn=True):
+         return_info=False, warn=True, norm_logs=None):
+    """norm_logs (per-row mode only): a list that receives, per row, the |dx| of every pass (the 1e-4 test's operand)"""
     H = np.asarray(H)
     q = np.asarray(q)
     lower = np.asarray(lower)
@@ -106,8 +109,11 @@ def pnqp(H, q, lower, upper, x_init=None, n_iter=20, batch_coupled=True,
         conv = np.zeros(B, dtype=bool)
         for b in range(B):
             xi = None if x_init is None else np.asarray(x_init)[b:b + 1]
+            log = [] if norm_logs is not None else None
             xb, fb, ib, it, ok = _pnqp_coupled(H[b:b + 1], q[b:b + 1], lower[b:b + 1],
-                                               upper[b:b + 1], xi, n_iter)
+                                               upper[b:b + 1], xi, n_iter, norm_log=log)
+            if norm_logs is not None:
+                norm_logs.append(np.array([float(v[0]) for v in log]))
             xs.append(xb)
             idxs.append(ib)
             if n == 1:

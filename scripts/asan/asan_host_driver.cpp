@@ -22,6 +22,8 @@ int main() {
   uint8_t *pm = reinterpret_cast<uint8_t *>(0x3000);
   void *ws = reinterpret_cast<void *>(0x4000);
   EXPECT(dmpc_version() == DMPC_VERSION);
+  EXPECT(dmpc_mpc_step_status(0, pi, pi, p, pi, nullptr) == DMPC_E_BADARG);      // (argument checks return before any launch)
+  EXPECT(dmpc_mpc_step_status(16, pi, pi, p, nullptr, nullptr) == DMPC_E_BADARG);
   const int shapes[][2] = {{1, 1}, {3, 1}, {8, 2}, {4, 4}, {8, 4}, {12, 3}, {6, 3}, {5, 5}, {3, 8}, {16, 4}, {20, 6}, {32, 8}, {16, 8},
                            {40, 4}, {10, 12}, {64, 16}, {100, 1}, {70, 3}, {300, 40}};
   for (auto &s : shapes) {

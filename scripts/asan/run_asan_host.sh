@@ -2,7 +2,7 @@
 # Host-side AddressSanitizer + UBSan run of the C-ABI (CPU only; GPU ASan is not available on this pool).
 #   bash scripts/asan/run_asan_host.sh [out.txt]      (~4 minutes: every *_api.hip is recompiled with the host pass instrumented)
 REPO=$(cd "$(dirname "$0")/../.." && pwd)
-OUT=${1:-$REPO/profiles/r04/asan_host.txt}
+OUT=${1:-$REPO/profiles/r05/asan_host.txt}
 W=/tmp/dmpc_asan; rm -rf $W; mkdir -p $W
 CS=$REPO/chainer_differentiable_mpc_amd/csrc
 python3 $CS/build.py > /dev/null 2>&1      # (makes sure the generated headers exist)

@@ -77,7 +77,7 @@ def test_pendulum_box_ddp_config2_against_oracle():
     # (1) the first two outer iterations against the oracle
     x, u, costs = product(2)
     xr, ur, cr, *_ = obox.box_ddp(x0, cost_o, obox.pendulum_step, T, dx.lower, dx.upper, 3, 1, max_iter=2, **okw)
-    assert_close(npy(costs), cr, 1e-3, "costs after 2 iterations")
+    assert_close(npy(costs), cr, TOL_PRIMAL, "costs after 2 iterations")      # (measured 3.1e-5, profiles/r04/parity_margins.txt)
     assert np.mean(np.abs(npy(u) - ur) < 1e-3) > 0.99
 
     # (2) one iLQR step (linearise, PNQP backward pass, clamped line search on the true pendulum) from common
@@ -159,11 +159,24 @@ def test_box_ddp_quadrotor_sized_against_oracle(dims):
         assert solver.status.strip() == status.strip() and solver.n_iter == n_iter, (solver.status, solver.n_iter, status, n_iter)
         assert float((u.abs() == 0.25).float().mean()) > 0.02
         # The loop stops once a step is shorter than eps = 1e-3 (the pendulum experiments' mpc_eps), i.e. within a fraction of
-        # eps of its fixed point - and that is how far a float32 and a float64 run of it may end apart (measured 1.2e-4 here;
-        # one MPC step from a common iterate is held to 1e-4 by tests/test_mpc_step_gpu.py at these shapes)
-        assert_close(npy(u), ur, 3e-4, "u")
-        assert_close(npy(x), xr, 3e-4, "x")
-        assert_close(npy(costs), cr, 3e-4, "costs")
+        # eps of its fixed point.  Where two runs of it END is therefore resolved to eps, not to the float32 contract - that is
+        # the loop's own stopping resolution and is checked as such (measured: 2.6e-4 in x); PARITY is the next block.
+        assert np.abs(npy(u) - ur).max() <= 1e-3 and np.abs(npy(x) - xr).max() <= 1e-3 * max(1.0, np.abs(xr).max())
+        assert_close(npy(costs), cr, TOL_PRIMAL, "costs")
+        # ... parity at the contract's tolerance: the loop's FIRST iteration (from the common initial controls), both sides.  The
+        # loop converges in a handful of iterations here; from its second iterate on most rows lower the cost by less than
+        # float32 resolves (line-search ties, tests/helpers.py: 4 of 12 rows after two iterations, all 12 one iteration before the
+        # stop), so a later common iterate compares tie-breaking, not arithmetic.  (One MPC step at these shapes from synthetic
+        # iterates is held to 1e-4 by tests/test_mpc_step_gpu.py.)
+        cost_o, lin_o = ompc.QuadCost(p["C"], p["c"]), ompc.LinDx(p["F"], p["f"])
+        x1r, u1r, c1r, *_ = obox.box_ddp(p["x_init"], cost_o, lin_o, T, -0.25, 0.25, nx, nu, batch_coupled=False, eps=1e-3, max_iter=1)
+        one = BoxDDP(T, -0.25, 0.25, B, nx, nu, None, max_iter=1, quiet=True, eps=1e-3, device_loop=device_loop, exit_unconverged=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x1, u1, c1 = one((dev(p["x_init"]), QuadCost(dev(p["C"]), dev(p["c"])), LinDx(dev(p["F"]), dev(p["f"]))))
+        assert_close(npy(u1), u1r, TOL_PRIMAL, "first iteration: u")
+        assert_close(npy(x1), x1r, TOL_PRIMAL, "first iteration: x")
+        assert_close(npy(c1), c1r, TOL_PRIMAL, "first iteration: costs")
 
 
 def test_box_ddp_beyond_8_controls_runs_its_host_loop_against_oracle():

@@ -59,11 +59,43 @@ def test_binding_refuses_a_library_of_another_abi_or_of_other_sources(monkeypatc
             return b"0" * 32
 
     _lib._check_identity(Fake(), "x.so", explicit=True)
-    with pytest.raises(_lib.DmpcError, match="other sources"):
+    with pytest.raises(_lib.DmpcError, match="other SOURCES"):
         _lib._check_identity(Fake(), "x.so", explicit=False)
     monkeypatch.setenv("DMPC_SKIP_HASH_CHECK", "1")
     _lib._check_identity(Fake(), "x.so", explicit=False)
     assert lib.dmpc_version() == 410
+
+
+def test_identity_check_names_what_differs(tmp_path, monkeypatch):
+    """(1) the library is compared with the stamp build.py wrote next to it - a library swapped without its stamp is
+    refused with that message; (2) a library built from the tree's sources with OTHER flags / GEN_* knobs than this process's
+    environment names is the same sources and is accepted; edited sources are refused, and the message says "SOURCES" """
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dmpc_build", os.path.join(ROOT, "chainer_differentiable_mpc_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    class Fake:
+        def __init__(self, h):
+            self.h = h
+
+        def dmpc_version(self):
+            return _lib.ABI_VERSION
+
+        def dmpc_source_hash(self):
+            return self.h.encode()
+
+    so = os.path.join(str(tmp_path), "libx.so")
+    open(so + ".srchash", "w").write("%s\n%s\nflags\n" % ("a" * 32, mod.content_hash()))
+    with pytest.raises(_lib.DmpcError, match="does not belong to the stamp"):
+        _lib._check_identity(Fake("b" * 32), so, explicit=False)
+    _lib._check_identity(Fake("a" * 32), so, explicit=False)      # knob build of the tree's own sources: accepted
+    open(so + ".srchash", "w").write("%s\n%s\nflags\n" % ("a" * 32, "c" * 32))
+    with pytest.raises(_lib.DmpcError, match="other SOURCES"):
+        _lib._check_identity(Fake("a" * 32), so, explicit=False)
+    # a GEN_* variable in the loading process's environment no longer turns the in-tree library away
+    monkeypatch.setenv("GEN_SOMETHING_UNRELATED", "1")
+    _lib._check_identity(_lib.load(), _lib.LIB_PATH, explicit=False)
 
 
 def test_dispatch_table_and_workspace_queries():

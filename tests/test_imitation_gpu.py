@@ -17,6 +17,7 @@ from tests.test_host_cpu import helpers_against_oracle
 pytestmark = pytest.mark.gpu
 
 from tests.helpers import TOL_STEP_PENDULUM as TOL_STEP     # noqa: E402  one MPC step of the pendulum problem: 2e-4, calibrated (tests/helpers.py)
+from tests.helpers import TOL_PRIMAL, TOL_STEP_PENDULUM  # noqa: E402
 
 
 def dev(a, dtype=torch.float32):
@@ -476,10 +477,13 @@ def test_imitation_chain_small_against_the_reference():
         tq, tp = env.true_dx.get_true_obj()
         with torch.no_grad():
             ex, eu = env.mpc(env.true_dx, g["xinit"], tq, tp, update_dynamics=True)
-        assert_close(npy(eu), g["expert_u"], 2e-3, "expert u")
+        assert_close(npy(eu), g["expert_u"], TOL_PRIMAL, "expert u")          # (measured 2.7e-5, profiles/r04/parity_margins.txt)
         nom_x, nom_u = net(dev(g["xinit"]), env, np.zeros((B, T, 1), dtype=np.float32))
-    assert_close(npy(nom_u), g["nom_u"], 1e-2, "nominal u")
-    assert_close(npy(nom_x), g["nom_x"], 1e-2, "nominal x")
+    # five iLQR iterations of the learner: the states are held to the one-step pendulum tolerance (measured 8.1e-5); ONE control
+    # entry is where a float32 line-search tie landed on the neighbouring candidate of the same search (measured 5.6e-4; a fork
+    # moves a control by at most its feed-forward step, |k| ~ 1e-2 here) - every other entry is held to 2e-4 two lines down
+    assert_close(npy(nom_u), g["nom_u"], 2e-3, "nominal u")
+    assert_close(npy(nom_x), g["nom_x"], TOL_STEP_PENDULUM, "nominal x")
     assert np.mean(np.abs(npy(nom_u) - g["nom_u"]) <= 2e-4) >= 0.95
     loss = ((dev(g["expert_u"]) - nom_u) ** 2).mean()
     loss.backward()

@@ -29,9 +29,11 @@ def test_notebook_anchor():
     assert list(LU.shape) == [2, 4, 4] and piv.dtype == torch.int32
 
 
-# rows (of 16) whose iteration count may differ by one from the float64 reference (threshold ties), per case
-MAX_TIE_ROWS = {(1, "cold"): 0, (1, "warm"): 0, (2, "cold"): 2, (2, "warm"): 2, (4, "cold"): 2, (4, "warm"): 2,
-                (8, "cold"): 3, (8, "warm"): 3}
+# PNQP stops when |dx| < 1e-4 (pnqp.py:139-143).  A row is a THRESHOLD TIE when, at the pass where the two counts part, the
+# reference's own |dx| lies within this factor of 1e-4: its dx comes out of a float32 LU solve (util.py:522-527), i.e. carries
+# ~1e-6 |x| of rounding noise, and near a fixed point |dx| IS that noise - whether it reads 0.9e-4 or 1.1e-4 is decided by the
+# last bits of x, in the reference as much as here.  Iteration counts are exact on every other row; the tie rows are listed.
+TIE_BAND = 1.5
 
 
 @pytest.mark.parametrize("n", [1, 2, 4, 8])
@@ -48,11 +50,22 @@ def test_per_row_golden(n, tag):
     np.testing.assert_array_equal(npy(idx_f), g[tag + "_row_idx_f"])          # identical active sets
     assert_close(npy(x), g[tag + "_row_x"], 1e-4, "x")
     iters = PNQP.last_info["iters"].cpu().numpy()
-    # iteration counts are exact except where the reference's final |dx| sits within float32 resolution of the 1e-4
-    # threshold (then one more / one fewer pass is a tie, not an error): such rows are counted and bounded
-    off = iters != g[tag + "_row_it"]
-    assert np.all(np.abs(iters - g[tag + "_row_it"])[off] == 1), (iters, g[tag + "_row_it"])
-    assert off.sum() <= MAX_TIE_ROWS[(n, tag)], (n, tag, int(off.sum()), np.nonzero(off)[0])
+    # iteration counts: exact, except on the rows the oracle itself identifies as threshold ties (see TIE_BAND)
+    from oracle import pnqp as opnqp
+    logs = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, _, _, _, oi = opnqp.pnqp(p["H"], p["q"], p["lower"], p["upper"], x_init=None if tag == "cold" else g["warm"], n_iter=20,
+                                    batch_coupled=False, return_info=True, warn=False, norm_logs=logs)
+    np.testing.assert_array_equal(oi["iters"], g[tag + "_row_it"])           # (the oracle reproduces the reference's counts)
+    off = np.nonzero(iters != g[tag + "_row_it"])[0]
+    for b in off:
+        assert abs(int(iters[b]) - int(g[tag + "_row_it"][b])) == 1, (b, iters[b], g[tag + "_row_it"][b])
+        k = min(int(iters[b]), int(g[tag + "_row_it"][b]))                  # the pass at which one side stopped and the other went on
+        nrm = logs[b][min(k, len(logs[b]) - 1)]
+        assert 1e-4 / TIE_BAND <= nrm <= 1e-4 * TIE_BAND, "row %d: counts %d vs %d but |dx| = %.3e at pass %d is no threshold tie" % (
+            b, iters[b], g[tag + "_row_it"][b], nrm, k)
+    print("PNQP n=%d %s: threshold-tie rows %s" % (n, tag, list(off)))
     assert (len(w) > 0) == bool(g[tag + "_row_warned"].any())
     # box feasibility is exact
     assert (npy(x) >= p["lower"] - 1e-7).all() and (npy(x) <= p["upper"] + 1e-7).all()
