@@ -198,6 +198,62 @@ SETTLE_MS = 60.0       # how long the device is kept busy before a measurement (
                        # steady 33 us from ~30 ms on, for as many seconds as the load lasts)
 
 
+class ClockSampler:
+    """sclk / mclk / board power of one GPU read from sysfs (hwmon freq1_input, freq2_input, power1_input, power1_cap) by a
+    thread every ~2 ms while the timed blocks run: the power state the number was measured in travels with it (boxes of the
+    pool differ by 10 % on the same binary, MI355X_MICROARCH.md DVFS items 5-6).  Everything is optional: a box that does not show
+    the files reports null."""
+
+    def __init__(self, index=0):
+        import glob
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        self.dir = None
+        if cards:
+            hw = glob.glob(os.path.join(cards[min(index, len(cards) - 1)], "hwmon", "hwmon*"))
+            self.dir = hw[0] if hw else None
+        self.samples = []
+        self._stop = False
+        self._thread = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as fh:
+                return float(fh.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop:
+            self.samples.append((self._read("freq1_input"), self._read("freq2_input"), self._read("power1_input")))
+            time.sleep(0.002)
+
+    def __enter__(self):
+        if self.dir is not None:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        return False
+
+    def summary(self):
+        if self.dir is None or not self.samples:
+            return None
+
+        def stat(i, scale):
+            v = sorted(x[i] * scale for x in self.samples if x[i] is not None)
+            return None if not v else {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        cap = self._read("power1_cap")
+        return {"samples": len(self.samples), "sclk_mhz": stat(0, 1e-6), "mclk_mhz": stat(1, 1e-6), "power_w": stat(2, 1e-6),
+                "power_cap_w": None if cap is None else cap * 1e-6,
+                "what": "hwmon freq1_input / freq2_input / power1_input of this rank's GPU, sampled every ~2 ms during the timed "
+                        "blocks (sysfs reads up to ~10 % above the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back item 6)"}
+
+
 def settle(fn, min_ms=SETTLE_MS, max_ms=600.0, block=25, fixed_blocks=None):
     """Bring the GPU to the power state of a running job before timing anything: fn() back to back in blocks of `block`
     for at least `min_ms`, until two consecutive blocks take the same time within 3 % (at most `max_ms`).  A freshly
@@ -416,6 +472,77 @@ def secondary_metrics(device, d_headline):
     return out
 
 
+def secondary_cpu_baselines(p_headline, budget_s=4.0):
+    """the CPU path timed beside every GPU number.  The numpy oracle (kind "port", one thread, float64) on a
+    BOUNDED sample of each secondary leg's workload - a slice of the batch that finishes within ~`budget_s` seconds each; every
+    entry says what the sample was and reports the leg's own unit (timestep-solves per second), so it scales to the full batch."""
+    import warnings
+    from oracle import box_ddp as obox
+    from oracle import kkt as okkt
+    from oracle import lqr as olqr
+    from oracle import mpc as ompc
+    out = {}
+    B, T, nx, nu = WORKLOADS["headline"]
+
+    def timed(fn, units, sample):
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            fn()
+            n += 1
+            if time.perf_counter() - t0 >= budget_s or n >= 5:
+                break
+        dt = (time.perf_counter() - t0) / n
+        return {"value": units / dt, "unit": "timestep-solves/s", "cores": 1, "kind": "port", "seconds_per_sample": dt, "sample": sample}
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # DiffLqr forward + backward: the first 256 trajectories of the headline batch
+        b = 256
+        q = {k: (v[:b] if k == "x_init" else v[:, :b]) for k, v in p_headline.items()}
+        gx, gu = np.ones((T, b, nx)), np.ones((T, b, nu))
+
+        def difflqr():
+            xr, ur = olqr.lqr_solve(q["x_init"], q["C"], q["c"], q["F"], q["f"], T, nx, nu)
+            okkt.difflqr_backward(q["x_init"], q["C"], q["c"], q["F"], xr, ur, gx, gu, T, nx, nu)
+        out["difflqr_fwd_bwd_cfg3"] = timed(difflqr, b * T, "oracle/lqr.py + oracle/kkt.py, forward solve + KKT gradient, %d of the %d trajectories, T=%d" % (b, B, T))
+        # MPCstep.forward: the first 64 trajectories (need_expand, bounds +-0.5, the nominal controls of the GPU leg's recipe)
+        b = 64
+        q = {k: (v[:b] if k == "x_init" else v[:, :b]) for k, v in p_headline.items()}
+        rng = np.random.RandomState(0)
+        un = np.clip(0.5 * rng.randn(T, b, nu), -0.5, 0.5)
+        lin = ompc.LinDx(q["F"], q["f"])
+        xn = obox.get_traj(T, un, q["x_init"], lin)
+        lo, hi = np.full((T, b, nu), -0.5), np.full((T, b, nu), 0.5)
+        cost = ompc.QuadCost(q["C"], q["c"])
+        out["mpc_step_forward_cfg3"] = timed(
+            lambda: ompc.mpc_forward(q["C"], q["c"], q["F"], q["f"], un, xn, lo, hi, cost, lin, 0.2, 5, T, nx, nu, need_expand=True,
+                                     batch_coupled=False),
+            b * T, "oracle/mpc.py mpc_forward (re-centring, one PNQP per timestep, line search), %d of the %d trajectories, T=%d" % (b, B, T))
+        # box-DDP on the pendulum: config 2 at its own batch, config 4 on a quarter of its batch; 10 iLQR iterations, T = 20
+        from chainer_differentiable_mpc_amd import PendulumDx
+        from chainer_differentiable_mpc_amd.pendulum import sample_xinit
+        dx = PendulumDx()
+        qv, pv = (t.numpy().astype(np.float64) for t in dx.get_true_obj())
+        for name, b, full in (("config2_box_ddp_b128", 128, 128), ("config4_box_ddp_b1024", 256, 1024)):
+            Q = np.broadcast_to(np.diag(qv), (20, b, 4, 4)).copy()
+            pp = np.broadcast_to(pv, (20, b, 4)).copy()
+            x0 = np.asarray(sample_xinit(b, seed=0), dtype=np.float64)
+            res = {}
+
+            def ddp():
+                r = obox.box_ddp(x0, ompc.QuadCost(Q, pp), obox.pendulum_step, 20, dx.lower, dx.upper, 3, 1, eps=dx.mpc_eps,
+                                 max_iter=10, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter,
+                                 linearize=obox.pendulum_linearize, batch_coupled=False)
+                res["n_iter"] = int(r[4])
+            e = timed(ddp, 1, "oracle/box_ddp.py, pendulum, true cost, T=20, up to 10 iLQR iterations, %d of the %d trajectories" % (b, full))
+            e["value"] = b * 20 * res["n_iter"] / e["seconds_per_sample"]
+            e["unit"] = "iLQR timestep-solves/s"
+            e["ms_per_solve_of_the_sample"] = e["seconds_per_sample"] * 1e3
+            out[name] = e
+    return out
+
+
 def secondary_cfg5(device):
     """one shard of config 5: B=8192, T=50, (32,8) - time per solve, fraction of the HBM roof and of the fp32 MFMA peak"""
     B, T, nx, nu = WORKLOADS["cfg5-shard"]
@@ -512,7 +639,7 @@ def main():
             raise SystemExit("--workload %s splits %d trajectories over the ranks: --gpus %d does not divide it" % (args.workload, strong_total, world))
         B = strong_total // world
     # the CPU legs run first, on rank 0 at N = 1 only: the worker pool is forked before this process touches the GPU
-    cb = cb_mp = xr = ur = p_host = None
+    cb = cb_mp = xr = ur = p_host = cb_sec = None
     want_cpu = not args.no_cpu_baseline and world == 1 and B * T * (nx + nu) ** 2 <= 64 * 1024 * 1024
     if want_cpu:
         p_host = synthetic.make_lqr_problem(B, T, nx, nu, seed=rank)
@@ -523,6 +650,11 @@ def main():
             except Exception as e:  # pragma: no cover - e.g. a box that does not allow that many processes
                 cb_mp = dict(value=None, unit="timestep-solves/s", cores=procs, kind="port", sample="failed: %r" % (e,))
         cb, xr, ur = cpu_baseline(p_host, T, nx, nu, args.cpu_seconds)
+        if args.workload == "headline" and not args.no_secondary:
+            try:
+                cb_sec = secondary_cpu_baselines(p_host)
+            except Exception as e:  # pragma: no cover - the GPU legs stand without them
+                cb_sec = {"error": repr(e)}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     dist, device, backend, red_dev = init_distributed(world, rank, local_rank)
@@ -581,25 +713,42 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    # kernel duration: ONE pair of HIP events on the launch stream (torch's current stream) around the K
-    # back-to-back launches of the timed region; span / K = average launch duration incl. boundaries
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    kern_s = ev0.elapsed_time(ev1) * 1e-3 / args.steps
+    # The timed region, kBlocks times: EXACTLY K steps bracketed by a barrier + torch.cuda.synchronize() on both sides, the MAX
+    # over ranks of each block's time; `value` is the MEDIAN block (one block of K = 20 is 0.7 ms of a 20 s run: one number from
+    # it says little, the spread of eleven says whether a box is steady), min and max travel in `roofline.blocks`.  Kernel
+    # duration: ONE pair of HIP events on the launch stream (torch's current stream) around the K back-to-back launches of each
+    # block; span / K = average launch duration incl. boundaries.
+    kBlocks = 11
+    block_wall, block_ev = [], []
+    with ClockSampler(device.index or 0) as clocks:
+        for _ in range(kBlocks):
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            for _ in range(args.steps):
+                step()
+            ev1.record()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                tmax = torch.tensor([el], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            block_wall.append(el)
+            block_ev.append(ev0.elapsed_time(ev1) * 1e-3 / args.steps)
+    order = sorted(range(kBlocks), key=lambda i: block_wall[i])
+    mid = order[kBlocks // 2]
+    elapsed = block_wall[mid]
+    kern_s = block_ev[mid]
+    clock_info = clocks.summary()
     kern_name = kernel_name() if gx is None else None      # (with --gather the last launch is RCCL's, not ours)
     gather_info = None
     if pipe is not None:
@@ -665,9 +814,13 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.workload, {}).get("hbm_bytes_per_launch")
+                rec = tj.get(args.workload, {})
+                traffic = rec.get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_src = "recorded, not measured in this run: " + str(tj.get("_source", tpath))
+                    if rec.get("batch") and rec["batch"] != B:      # counters of another batch size: traffic is linear in B
+                        traffic = int(traffic * B / rec["batch"])
+                        traffic_src += " (collected at B = %d, scaled to B = %d)" % (rec["batch"], B)
             except Exception:
                 traffic = None
         out = {
@@ -697,6 +850,14 @@ def main():
                          "frac_wall": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kern_name,
+                         "blocks": {"n": kBlocks, "steps_each": args.steps,
+                                    "ms_per_step_min": min(block_wall) / args.steps * 1e3,
+                                    "ms_per_step_median": elapsed / args.steps * 1e3,
+                                    "ms_per_step_max": max(block_wall) / args.steps * 1e3,
+                                    "kernel_ms_min": min(block_ev) * 1e3, "kernel_ms_max": max(block_ev) * 1e3,
+                                    "what": "value / ms_per_step / frac are the MEDIAN of n timed regions of exactly K steps each "
+                                            "(barrier + synchronize on both sides, max over ranks)"},
+                         "clocks": clock_info,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
                          "kernel_ms_wall": elapsed / args.steps * 1e3,
                          "protocol": "value/frac are taken AFTER an untimed run-up of the same step to the device's steady "
@@ -773,6 +934,12 @@ def main():
             except Exception as e:  # pragma: no cover
                 sec["cfg5_full_1gpu"] = {"error": repr(e)}
             torch.cuda.empty_cache()
+            if cb_sec is not None:        # the oracle timed beside every secondary GPU number
+                if "error" in cb_sec:
+                    sec["cpu_baselines_error"] = cb_sec["error"]
+                for leg, e in cb_sec.items():
+                    if leg != "error" and isinstance(sec.get(leg), dict):
+                        sec[leg]["cpu_baseline"] = e
             out["secondary"] = sec
             secondary_failed = "error" in sec or any(isinstance(v, dict) and "error" in v for v in sec.values())
         print(json.dumps(out))
