@@ -1,6 +1,6 @@
-"""CPU: the committed evidence is self-consistent: every kernel named in profiles/r04/bench_line.json is
+"""CPU: the committed evidence is self-consistent: every kernel named in profiles/r05/bench_line.json is
 a kernel the rocprofv3 summaries beside it list (so a line and its CSVs come from the same tree), and the counter traffic
-bench.py quotes is the one profiles/r04/pmc_summary.txt holds."""
+bench.py quotes is the one profiles/r05/pmc_summary.txt holds."""
 import csv
 import glob
 import json
@@ -10,7 +10,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R04 = os.path.join(ROOT, "profiles", "r04")
+R05 = os.path.join(ROOT, "profiles", "r05")
 
 
 def kernel_strings(obj):
@@ -32,25 +32,25 @@ def norm(name):
     return name.replace(" ", "")
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(R04, "bench_line.json")), reason="profiles/r04 not generated yet")
+@pytest.mark.skipif(not os.path.exists(os.path.join(R05, "bench_line.json")), reason="profiles/r05 not generated yet")
 def test_every_kernel_of_the_bench_line_is_in_the_profiler_summaries():
-    line = json.load(open(os.path.join(R04, "bench_line.json")))
+    line = json.load(open(os.path.join(R05, "bench_line.json")))
     named = sorted(set(norm(k) for k in kernel_strings(line)))
     assert named, "bench_line.json names no kernel"
     listed = set()
-    for path in glob.glob(os.path.join(R04, "*kernel_stats.csv")):
+    for path in glob.glob(os.path.join(R05, "*kernel_stats.csv")):
         for row in csv.DictReader(open(path)):
             listed.add(norm(row.get("Name", "")))
     assert listed, "no rocprofv3 kernel_stats.csv next to bench_line.json"
     missing = [k for k in named if k not in listed]
-    assert not missing, "kernels of bench_line.json that no profiles/r04/*kernel_stats.csv lists: %s" % missing
+    assert not missing, "kernels of bench_line.json that no profiles/r05/*kernel_stats.csv lists: %s" % missing
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(R04, "pmc_summary.txt")), reason="profiles/r04 not generated yet")
+@pytest.mark.skipif(not os.path.exists(os.path.join(R05, "pmc_summary.txt")), reason="profiles/r05 not generated yet")
 def test_quoted_counter_traffic_is_the_recorded_one():
     tj = json.load(open(os.path.join(ROOT, "profiles", "lqr_solve_traffic.json")))
-    assert "r04" in tj["_source"]
-    txt = open(os.path.join(R04, "pmc_summary.txt")).read()
+    assert "r05" in tj["_source"]
+    txt = open(os.path.join(R05, "pmc_summary.txt")).read()
     for key in ("headline", "cfg5-shard"):
         e = tj[key]
         assert e["hbm_bytes_per_launch"] == int(e["fetch_size_kib"] * 2048 + e["write_size_kib"] * 1024)
