@@ -721,13 +721,17 @@ def main():
     kBlocks = 11
     block_wall, block_ev = [], []
     with ClockSampler(device.index or 0) as clocks:
-        for _ in range(kBlocks):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(kBlocks)]
+        for blk in range(kBlocks):
+            # every block is the contract's whole protocol: W untimed warm-up steps, barrier + synchronize, K timed steps,
+            # synchronize + barrier (the device goes from its warm-up straight into the timed steps, as in a running job)
+            for _ in range(args.warmup if blk > 0 else 0):       # (block 0's warm-up ran above)
+                step()
             torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize()
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0, ev1 = evs[blk]
             t0 = time.perf_counter()
             ev0.record()
             for _ in range(args.steps):
