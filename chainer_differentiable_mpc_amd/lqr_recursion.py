@@ -261,8 +261,9 @@ def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False,
 
 
 def solve_device_f64(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False, info=None):
-    """The fused solve in float64 on float64 device tensors (`dmpc_lqr_solve_f64`: the reference's precision; one lane per
-    trajectory, any shape with nx + nu + 1 <= 64).  Returns (x, u, Ks|None, ks|None)."""
+    """The fused solve in float64 on float64 device tensors (`dmpc_lqr_solve_f64`: the reference's precision).  Any shape: the
+    register-resident column-per-lane kernels for the instantiated ones ((1,1) ... (12,3), (16,4), (16,8), (32,8);
+    f64_row_kernels.hpp), one lane per trajectory for every other.  Returns (x, u, Ks|None, ks|None)."""
     lib = _lib.load()
     _lib.require_gpu()
     dev = C.device
