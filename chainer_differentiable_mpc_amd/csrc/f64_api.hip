@@ -20,6 +20,7 @@
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
 #include "f64_row_kernels.hpp"
+#include "lqr_tile16_f64.hpp"
 
 namespace dmpc {
 
@@ -310,6 +311,25 @@ static int launch_f64_row_costate(int nx, int nu, const F64RowCostate &a, hipStr
   return DMPC_E_UNSUPPORTED;
 }
 
+// the plain fused solve of the large shapes on v_mfma_f64_16x16x4_f64 tiles (lqr_tile16_f64.hpp); DMPC_E_UNSUPPORTED - nothing
+// launched - for other shapes, the clamped solve and the split-c second solve.  DMPC_NO_F64_TILE16=1: off (A/B timing).
+static int launch_f64_tile16(int nx, int nu, const F64RowSolve &a, hipStream_t stream) {
+  static const bool off = [] { const char *e = getenv("DMPC_NO_F64_TILE16"); return e && e[0] == '1'; }();
+  if (off || a.mask != nullptr || a.Ks == nullptr || a.ks == nullptr) return DMPC_E_UNSUPPORTED;
+  if (!aligned16(a.C) || !aligned16(a.c) || !aligned16(a.c_u) || !aligned16(a.F) || !aligned16(a.f)) return DMPC_E_UNSUPPORTED;
+#define X(NX_, NU_)                                                                                                    \
+  if (nx == NX_ && nu == NU_) {                                                                                        \
+    constexpr size_t lds = Tile16F64Layout<NX_, NU_>::lds_bytes();                                                     \
+    static_assert(lds <= 160 * 1024, "one workgroup per CU");                                                          \
+    allow_lds(lqr_tile16_f64_kernel<NX_, NU_>, lds);                                                                   \
+    DMPC_LAUNCH_GGL((lqr_tile16_f64_kernel<NX_, NU_>), dim3((a.B + 3) / 4), dim3(256), lds, stream, a);                \
+    return (int)hipGetLastError();                                                                                     \
+  }
+  X(32, 8) X(16, 8) X(32, 4) X(16, 4)
+#undef X
+  return DMPC_E_UNSUPPORTED;
+}
+
 static bool f64_row_off() {
   static const bool off = [] { const char *e = getenv("DMPC_NO_F64_ROW"); return e && e[0] == '1'; }();
   return off;
@@ -360,6 +380,16 @@ int dmpc_lqr_solve_f64(int T, int B, int nx, int nu, const double *C, const doub
       r.Ks = gains;
       r.ks = gains + (size_t)T * B * nu * nx;
     }
+    {   // the large shapes: 16x16x4 float64 tiles (gains through the caller's arrays or the workspace)
+      F64RowSolve rt = r;
+      if (rt.Ks == nullptr) {
+        rt.Ks = gains;
+        rt.ks = gains + (size_t)T * B * nu * nx;
+      }
+      rt.k_lds = 0;
+      const int rct = launch_f64_tile16(nx, nu, rt, static_cast<hipStream_t>(stream));
+      if (rct != DMPC_E_UNSUPPORTED) return rct;
+    }
     const int rc = launch_f64_row_solve(nx, nu, r, static_cast<hipStream_t>(stream));
     if (rc != DMPC_E_UNSUPPORTED) return rc;
   }
@@ -393,7 +423,15 @@ int dmpc_lqr_kkt_grad_f64(int T, int B, int nx, int nu, const double *C, const d
       r.Ks = gains;
       r.ks = gains + (size_t)T * B * nu * nx;
     }
-    int rc = launch_f64_row_solve(nx, nu, r, s);
+    int rc;
+    {   // the second solve on the float64 tile kernel where the shape has one (gains through the workspace)
+      F64RowSolve rt = r;
+      rt.Ks = gains;
+      rt.ks = gains + (size_t)T * B * nu * nx;
+      rt.k_lds = 0;
+      rc = launch_f64_tile16(nx, nu, rt, s);
+    }
+    if (rc == DMPC_E_UNSUPPORTED) rc = launch_f64_row_solve(nx, nu, r, s);
     if (rc != DMPC_E_UNSUPPORTED) {
       if (rc != 0) return rc;
       F64RowCostate k{T, B, C, c, F, x, u, dxs, dus, grad_x, strict_math, d_x_init, dC, dc, dF, df};

@@ -37,6 +37,12 @@
 
 namespace dmpc {
 
+// Between an LDS write and the read of the same words by OTHER lanes of the wavefront: the hardware executes a wavefront's LDS
+// operations in order, but the compiler sees one thread - without this it may hand a lane the value that lane itself stored
+// to the address earlier (store-to-load forwarding; seen in the float64 kernel: the rows of lane group 3 came back as the control
+// rows the group had written before the gain solve, not as the gains other lanes wrote after it).
+__device__ __forceinline__ void lds_lanes_exchange() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ f4v mfma16(float a, float b, f4v c) {
 #ifdef DMPC_T16_KNOB_NOMFMA   // timing knob (wrong results): the sweep without its matrix instructions
   c[0] += a * b;
@@ -63,15 +69,17 @@ __device__ __forceinline__ void tile16_dma_masked(unsigned voff, unsigned long l
 // [g < gv][4 cv columns] - gv * 4 cv consecutive floats -, the four segments of a tile follow one another, the full tiles come
 // first (they share one DMA lane pattern), then the others in row-major order.  The image is exactly ROWS * COLS floats: the
 // LDS-DMA moves the arrays' own bytes and nothing else.  A 16-byte chunk of the image is four consecutive columns of one row.
-template <int ROWS, int COLS, int RT, int CT>
+// CPC: columns per 16-byte chunk (4 floats; 2 doubles - lqr_tile16_f64.hpp)
+template <int ROWS, int COLS, int RT, int CT, int CPC = 4>
 struct PackedImage {
-  static_assert(ROWS % 4 == 0 && COLS % 4 == 0, "whole row groups and 16-byte chunks");
-  static constexpr int clamp04(int v) { return v < 0 ? 0 : (v > 4 ? 4 : v); }
-  static constexpr int gv(int ib) { return clamp04((ROWS - 16 * ib) / 4); }
-  static constexpr int cv(int jb) { return clamp04((COLS - 16 * jb) / 4); }
-  static constexpr bool full(int ib, int jb) { return gv(ib) == 4 && cv(jb) == 4; }
+  static_assert(ROWS % 4 == 0 && COLS % CPC == 0, "whole row groups and 16-byte chunks");
+  static constexpr int kCols = CPC, kChunkCols = 16 / CPC;      // chunk columns of a full tile
+  static constexpr int clampv(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+  static constexpr int gv(int ib) { return clampv((ROWS - 16 * ib) / 4, 4); }
+  static constexpr int cv(int jb) { return clampv((COLS - 16 * jb) / CPC, kChunkCols); }
+  static constexpr bool full(int ib, int jb) { return gv(ib) == 4 && cv(jb) == kChunkCols; }
   static constexpr int chunks(int ib, int jb) { return 4 * gv(ib) * cv(jb); }
-  static constexpr int seg_floats(int ib, int jb) { return gv(ib) * 4 * cv(jb); }
+  static constexpr int seg_floats(int ib, int jb) { return gv(ib) * CPC * cv(jb); }      // elements of one register's segment
   static constexpr int base_chunk(int ib, int jb) {
     int n = 0;
     const bool f = full(ib, jb);
@@ -88,8 +96,9 @@ struct PackedImage {
       for (int jj = 0; jj < CT; ++jj) n += full(i, jj) ? 1 : 0;
     return n;
   }
-  static constexpr int total_chunks() { return ROWS * COLS / 4; }
-  static constexpr int tail_instrs() { return (total_chunks() - 64 * n_full() + 63) / 64; }
+  static constexpr int total_chunks() { return ROWS * COLS / CPC; }
+  static constexpr int tail_instrs() { return (total_chunks() - (256 / CPC) * n_full() + 63) / 64; }
+  static constexpr int total_instrs() { return (total_chunks() + 63) / 64; }
   // (ib, jb) of the k-th full tile
   static constexpr int full_tile(int k) {
     int n = 0;
@@ -101,7 +110,7 @@ struct PackedImage {
         }
     return -1;
   }
-  // float offset inside the matrix of image chunk n (a chunk of a partial tile); 0 past the end (those lanes are masked off)
+  // element offset inside the matrix of image chunk n (a chunk of a partial tile); 0 past the end (those lanes are masked off)
   static __device__ __forceinline__ int tail_src_offset(int n) {
     int off = 0;
     static_for<0, RT * CT>([&](auto tl) {
@@ -110,7 +119,22 @@ struct PackedImage {
         constexpr int base = base_chunk(ib, jb), cnt = chunks(ib, jb), gvv = gv(ib), cvv = cv(jb);
         if (n >= base && n < base + cnt) {
           const int q = n - base, r = q / (gvv * cvv), gg = (q / cvv) % gvv, cq = q % cvv;
-          off = (16 * ib + 4 * gg + r) * COLS + 16 * jb + 4 * cq;
+          off = (16 * ib + 4 * gg + r) * COLS + 16 * jb + CPC * cq;
+        }
+      }
+    });
+    return off;
+  }
+  // the same for ANY chunk of the image, full tiles included (the float64 kernel keeps one lane-offset register per instruction)
+  static __device__ __forceinline__ int src_offset(int n) {
+    int off = 0;
+    static_for<0, RT * CT>([&](auto tl) {
+      constexpr int ib = tl.value / CT, jb = tl.value % CT;
+      if constexpr (chunks(ib, jb) > 0) {
+        constexpr int base = base_chunk(ib, jb), cnt = chunks(ib, jb), gvv = gv(ib), cvv = cv(jb);
+        if (n >= base && n < base + cnt) {
+          const int q = n - base, r = q / (gvv * cvv), gg = (q / cvv) % gvv, cq = q % cvv;
+          off = (16 * ib + 4 * gg + r) * COLS + 16 * jb + CPC * cq;
         }
       }
     });
@@ -328,6 +352,7 @@ __global__ __launch_bounds__(256, DMPC_T16_OCC) void lqr_tile16_kernel(const Lqr
     // (lanes beyond the row's 16 CA columns read a duplicate: finite, never used)
     float Kr[NU];
     auto read_rows = [&] {
+      lds_lanes_exchange();
 #pragma unroll
       for (int m = 0; m < NU; ++m) Kr[m] = slot[Lay::kU + m * SU + (lane < 16 * CA ? lane : 0)];
     };
@@ -344,6 +369,7 @@ __global__ __launch_bounds__(256, DMPC_T16_OCC) void lqr_tile16_kernel(const Lqr
           });
         });
       }
+      lds_lanes_exchange();
       static_for<0, RX>([&](auto ib) {
         static_for<0, RU>([&](auto r2) {
           const int i = 16 * ib.value + j;
@@ -436,6 +462,7 @@ __global__ __launch_bounds__(256, DMPC_T16_OCC) void lqr_tile16_kernel(const Lqr
 #pragma unroll
         for (int m = 0; m < NU; ++m) slot[Lay::kU + m * SU + lane] = k_lane ? Kt[m] : 0.f;
       }
+      lds_lanes_exchange();
       f4v Kc[CA];
       static_for<0, CA>([&](auto jb) {
         static_for<0, RU>([&](auto r2) { Kc[jb.value][r2.value] = slot[Lay::kU + (4 * r2.value + g) * SU + 16 * jb.value + j]; });
