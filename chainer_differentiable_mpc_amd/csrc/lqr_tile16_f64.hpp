@@ -1,7 +1,7 @@
 // lqr_tile16_f64.hpp - the fused solve of the large shapes in the reference's own precision (float64: lqr/differentiable_lqr.py:
-// 169-172) on v_mfma_f64_16x16x4_f64: lqr_tile16_kernel (lqr_tile16.hpp) with doubles.  Same tile layout (a 16 x 16 tile = four
-// 64-bit registers, register r of lane 16 g + j = element (4 g + r, j)), same three products in the X^T Y shape, the same packed
-// LDS image by gather LDS-DMA (a 16-byte chunk is TWO columns here: PackedImage<..., 2>), the gain solve on the rows brought
+// 169-172) on v_mfma_f64_16x16x4_f64: lqr_tile16_kernel (lqr_tile16.hpp) with doubles.  A 16 x 16 tile is four 64-bit registers
+// per lane, the three products keep the X^T Y shape, the step's inputs arrive as a packed LDS image by gather LDS-DMA (a 16-byte
+// chunk is TWO columns here), the gain solve runs on the rows brought
 // through LDS into the column-per-lane layout with LAPACK's pivot order (getf2: true divisions), the rollout in the same launch.
 // One wavefront per trajectory and per SIMD (a step's image is 23.6 KB, its registers twice the float32 kernel's).
 //
@@ -300,18 +300,6 @@ __global__ __launch_bounds__(256, 1) void lqr_tile16_f64_kernel(const F64RowSolv
           }
         });
       });
-#ifdef DMPC_T16F64_DEBUG   // scripts/debug_f64_tile16.py: [V | v] after the first value update of trajectory 0, into the gains of t = 30..
-      if (t == T - 1 && T >= 40) {
-        double *dbg = a.Ks + (size_t)(30 + 2 * b) * B * NU * NX;
-        static_for<0, RX>([&](auto ib) {
-          static_for<0, RX>([&](auto jb) {
-            static_for<0, 4>([&](auto r) { dbg[(16 * ib.value + 4 * r.value + g) * NX + 16 * jb.value + j] = V[ib.value][jb.value][r.value]; });
-          });
-          static_for<0, 4>([&](auto r) { if (j == JA) dbg[NX * NX + 16 * ib.value + 4 * r.value + g] = Vaff[ib.value][r.value]; });
-        });
-        return;   // (nothing may overwrite the dump)
-      }
-#endif
     }
   }
 
