@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libdmpc_hip.so"
 LIB_PATH = os.environ.get("DMPC_LIB", os.path.join(_HERE, LIB_NAME))
 
-ABI_VERSION = 410           # include/dmpc.h: DMPC_VERSION the signatures below were written for
+ABI_VERSION = 411           # include/dmpc.h: DMPC_VERSION the signatures below were written for
 E_BADARG, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3
 INFO_SINGULAR, INFO_NONFINITE, INFO_QP_ITERCAP, INFO_LS_ITERCAP = 1, 2, 4, 8
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "dmpc_batch_lu_factor": (_c_i, [_c_i, _c_i] + [_c_f] * 5),
     "dmpc_batch_lu_solve": (_c_i, [_c_i, _c_i, _c_i] + [_c_f] * 5),
     "dmpc_coupled_workspace_bytes": (_c_sz, [_c_i, _c_i]),
+    "dmpc_pnqp_workspace_bytes": (_c_sz, [_c_i, _c_i, _c_i, _c_i]),
     "dmpc_pnqp": (_c_i, [_c_i, _c_i] + [_c_f] * 5 + [_c_i, _c_i] + [_c_f] * 5 + [_c_f, _c_sz, _c_f, _c_f]),
     "dmpc_mpc_step_workspace_bytes": (_c_sz, [_c_i] * 4),
     "dmpc_mpc_step_forward": (_c_i, [_c_i] * 4 + [_c_f] * 12 + [_c_i, ctypes.c_float, _c_i, _c_i, _c_i]
@@ -114,7 +115,10 @@ def _check_identity(lib, p, explicit):
     # (1) the library against the stamp csrc/build.py wrote next to it: no source is read, nothing is executed
     got = lib.dmpc_source_hash().decode()
     stamp_path = p + ".srchash"
-    stamp = open(stamp_path).read().split("\n") if os.path.exists(stamp_path) else None
+    stamp = None
+    if os.path.exists(stamp_path):
+        with open(stamp_path) as fh:
+            stamp = fh.read().split("\n")
     if stamp is not None and stamp[0].strip() != got:
         raise DmpcError("%s (source hash %s) does not belong to the stamp next to it (%s: %s) - the library was replaced without "
                         "its stamp; rebuild it (python %s)" % (p, got, stamp_path, stamp[0].strip(), os.path.join(_HERE, "csrc", "build.py")))

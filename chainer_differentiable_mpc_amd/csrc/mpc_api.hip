@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "../../include/dmpc.h"
 #include "api_util.hpp"
 #include "costate_args.hpp"
@@ -17,6 +19,7 @@
 #include "lqr_wave_api.hpp"
 #include "mpc_generic.hpp"
 #include "mpc_tiled.hpp"
+#include "mpc_coupled.hpp"
 #include "mpc_kernels.hpp"
 
 namespace dmpc {
@@ -69,19 +72,72 @@ __global__ __launch_bounds__(256) void pnqp_kernel(const PnqpArgs a) {
   if (a.info != nullptr && !res.converged) atomicOr(&a.info[b], DMPC_INFO_QP_ITERCAP);
 }
 
-// A kernel whose workgroups meet at grid barriers needs all of them resident: cooperative launch (the runtime
-// refuses a grid that does not fit instead of letting it deadlock).
+// A kernel whose workgroups meet at grid barriers needs all of them resident: cooperative launch (the runtime refuses a grid
+// that does not fit instead of letting it deadlock).  The runtime's own limit - hipOccupancyMaxActiveBlocksPerMultiprocessor x
+// CUs - is not safe on gfx950: mpc_coupled.hpp's kernel (7 workgroups per CU by that count) was ACCEPTED at 1,792 workgroups
+// and deadlocked at its first barrier, and ran at 1,024 (round 5, scripts/coupled_grid_probe.py).  So the grids here stay at
+// HALF the workgroups per CU the runtime counts (at least one).
+static long long resident_workgroups(const void *kernel, int threads, size_t lds) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || cus <= 0 || per_cu <= 0) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return (long long)cus * std::max(1, per_cu / 2);
+}
+
 static int launch_cooperative(const void *kernel, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t stream) {
+  if ((long long)grid.x > resident_workgroups(kernel, (int)block.x, lds)) return DMPC_E_UNSUPPORTED;   // -> mpc_coupled.hpp's fixed grid
   note_kernel(kernel);
   const hipError_t e = hipLaunchCooperativeKernel(kernel, grid, block, args, (unsigned)lds, stream);
   if (e == hipErrorCooperativeLaunchTooLarge) {
     (void)hipGetLastError();
-    return DMPC_E_UNSUPPORTED;   // batch too large to be coupled in one launch: shard it, or use per-row termination
+    return DMPC_E_UNSUPPORTED;
   }
   return (int)e;
 }
 
+// DMPC_NO_COOP_REGISTER=1 (read at every call: tests switch it): batch-coupled problems skip the register kernels'
+// whole-batch-resident launch and run on mpc_coupled.hpp's fixed grid, as they do when that launch does not fit
+static bool coupled_register_disabled() {
+  const char *e = getenv("DMPC_NO_COOP_REGISTER");
+  return e && e[0] == '1';
+}
+
+// mpc_coupled.hpp's kernels: a grid that is resident whatever the batch - resident_workgroups() of this kernel, at most one per
+// row; halved if the runtime still refuses
+static int launch_fixed_grid(const void *kernel, int rows, void **args, hipStream_t stream) {
+  long long cap = resident_workgroups(kernel, kTiledThreads, 0);
+  if (cap <= 0) return DMPC_E_UNSUPPORTED;
+  if (const char *e = getenv("DMPC_FIXED_GRID_MAX")) {   // (experiments; read at every call)
+    const long long v = atoll(e);
+    if (v >= 1) cap = v;
+  }
+  note_kernel(kernel);
+  for (long long g = std::min<long long>(cap, rows); g >= 1; g /= 2) {
+    const hipError_t e = hipLaunchCooperativeKernel(kernel, dim3((unsigned)g), dim3(kTiledThreads), args, 0, stream);
+    if (e != hipErrorCooperativeLaunchTooLarge) return (int)e;
+    (void)hipGetLastError();
+  }
+  return DMPC_E_UNSUPPORTED;
+}
+
 static size_t coupled_bytes(int T, int n_qp_iter) { return round_up((size_t)T * pnqp_sync_slots(n_qp_iter) * 2 * sizeof(unsigned), 256); }
+// the fixed-grid form's rows, behind the decision slots
+static size_t coupled_traj_bytes(int B, int nx, int nu) { return round_up((size_t)B * mpc_coupled_traj_floats(nx, nu) * sizeof(float), 256); }
+static size_t pnqp_coupled_row_bytes(int B, int n) { return round_up((size_t)B * pnqp_coupled_row_floats(n) * sizeof(float), 256); }
+
+// MPCstep.backward_rec, batch-coupled, any size and any batch (mpc_coupled.hpp); a.sync zeroed, a.tiled_scratch =
+// [B][mpc_coupled_traj_floats]
+static int launch_mpc_back_fixed_grid(int nx, int nu, const MpcBackArgs &a, hipStream_t stream) {
+  if (a.sync == nullptr) return DMPC_E_BADARG;
+  if (a.tiled_scratch == nullptr) return DMPC_E_WORKSPACE;
+  MpcBackArgs aa = a;
+  float *scratch = a.tiled_scratch;
+  void *args[] = {&aa, &nx, &nu, &scratch};
+  return launch_fixed_grid(reinterpret_cast<const void *>(&mpc_coupled_backward_kernel), a.B, args, stream);
+}
 
 #ifdef DMPC_EXPERIMENT_ONLY_8_2
 #define DMPC_MPC_SHAPES(X) X(8, 2, 16)
@@ -149,6 +205,7 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     if (e != hipSuccess) return (int)e;
   }
   void *args1[] = {&a};
+  const bool coop_off = a.sync != nullptr && coupled_register_disabled();
   // per-trajectory termination, whole wavefronts of four trajectories, 16-byte aligned runs: inputs through the LDS-DMA
   // ring of mpc_dma_kernels.hpp (DMPC_NO_MPC_DMA=1: the register-bank kernel, for A/B timing)
   const bool dma_ok = mpc_back_dma_ok(a);
@@ -194,9 +251,12 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
         }                                                                                                     \
       }                                                                                                       \
     }                                                                                                         \
-    if (a.sync != nullptr)                                                                                    \
-      return launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, L_>),       \
-                                dim3((a.B + GPB - 1) / GPB), dim3(256), args1, 0, stream);                    \
+    if (a.sync != nullptr) {                                                                                  \
+      const int rc = coop_off ? DMPC_E_UNSUPPORTED                                                            \
+                              : launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, L_>), \
+                                                   dim3((a.B + GPB - 1) / GPB), dim3(256), args1, 0, stream); \
+      return rc == DMPC_E_UNSUPPORTED ? launch_mpc_back_fixed_grid(nx, nu, a, stream) : rc;                   \
+    }                                                                                                         \
     DMPC_LAUNCH_GGL((mpc_backward_rec_kernel<NX_, NU_, L_>), dim3((a.B + GPB - 1) / GPB), dim3(256), 0, stream, \
                        a);                                                                                    \
     return (int)hipGetLastError();                                                                            \
@@ -282,9 +342,13 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     a.nu_log = nu;
 #define X(NX_, NU_)                                                                                           \
   if (nx <= NX_ && nu <= NU_) {                                                                               \
-    if (a.sync != nullptr)                                                                                    \
-      return launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, 16, true>), \
-                                dim3((a.B + 15) / 16), dim3(256), args1, 0, stream);                          \
+    if (a.sync != nullptr) {                                                                                  \
+      const int rc = coop_off ? DMPC_E_UNSUPPORTED                                                            \
+                              : launch_cooperative(reinterpret_cast<const void *>(&mpc_backward_rec_kernel<NX_, NU_, 16, true>), \
+                                                   dim3((a.B + 15) / 16), dim3(256), args1, 0, stream);       \
+      a.nx_log = a.nu_log = 0;                                                                                \
+      return rc == DMPC_E_UNSUPPORTED ? launch_mpc_back_fixed_grid(nx, nu, a, stream) : rc;                   \
+    }                                                                                                         \
     DMPC_LAUNCH_GGL((mpc_backward_rec_kernel<NX_, NU_, 16, true>), dim3((a.B + 15) / 16), dim3(256), 0, stream, a); \
     return (int)hipGetLastError();                                                                            \
   }
@@ -302,9 +366,12 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
     void *args2[] = {&a, &nx};
 #define G(NU_)                                                                                                    \
   case NU_:                                                                                                       \
-    if (a.sync != nullptr)                                                                                        \
-      return launch_cooperative(reinterpret_cast<const void *>(&mpc_generic_backward_kernel<NU_>), dim3(a.B),     \
-                                dim3(64), args2, mpc_generic_back_lds_bytes<NU_>(nx), stream);                    \
+    if (a.sync != nullptr) {                                                                                      \
+      const int rc = coop_off ? DMPC_E_UNSUPPORTED                                                                \
+                              : launch_cooperative(reinterpret_cast<const void *>(&mpc_generic_backward_kernel<NU_>), dim3(a.B), \
+                                                   dim3(64), args2, mpc_generic_back_lds_bytes<NU_>(nx), stream); \
+      return rc == DMPC_E_UNSUPPORTED ? launch_mpc_back_fixed_grid(nx, nu, a, stream) : rc;                       \
+    }                                                                                                             \
     DMPC_LAUNCH_GGL((mpc_generic_backward_kernel<NU_>), dim3(a.B), dim3(64), mpc_generic_back_lds_bytes<NU_>(nx), \
                        stream, a, nx);                                                                            \
     return (int)hipGetLastError();
@@ -312,14 +379,18 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
 #undef G
   }
   // any other size (more than 8 controls, more than 64 columns): a workgroup per trajectory, matrices in the caller's
-  // workspace (mpc_tiled.hpp); per-trajectory termination of the QP only
-  if (a.sync == nullptr && a.tiled_scratch != nullptr) {
+  // workspace (mpc_tiled.hpp; batch-coupled: mpc_coupled.hpp)
+  if (a.sync != nullptr) {
+    a.nx_log = a.nu_log = 0;
+    return launch_mpc_back_fixed_grid(nx, nu, a, stream);
+  }
+  if (a.tiled_scratch != nullptr) {
     const size_t shmem = (pnqp_tiled_lds_floats(nu) + (size_t)(nx + nu)) * sizeof(float);
     if (shmem > 60 * 1024) return DMPC_E_UNSUPPORTED;
     DMPC_LAUNCH_GGL(mpc_tiled_backward_kernel, dim3(a.B), dim3(kTiledThreads), shmem, stream, a, nx, nu, a.tiled_scratch);
     return (int)hipGetLastError();
   }
-  return a.sync == nullptr ? DMPC_E_WORKSPACE : DMPC_E_UNSUPPORTED;
+  return DMPC_E_WORKSPACE;
 }
 
 // shapes that only the tiled kernels take
@@ -515,7 +586,7 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
   w.du = take((size_t)T * B * nu * sizeof(float));
   w.mask = take((size_t)T * B * nu);
   w.sync = take(coupled_bytes(T, kSyncQpIterMax));
-  w.tiled = take(mpc_needs_tiles(nx, nu) ? (size_t)B * mpc_tiled_scratch_floats(nx, nu) * sizeof(float) : 0);
+  w.tiled = take(coupled_traj_bytes(B, nx, nu));     // the tiled sweep's matrices (+ the QP's vectors of its batch-coupled form)
   w.lqr = off;
   off += round_up(dmpc_lqr_workspace_bytes(T, B, nx, nu), 256);
   w.total = off;
@@ -524,7 +595,7 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
 
 // workspace of the device-driven box-DDP loop (dmpc_box_ddp)
 struct DdpWs {
-  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, info_back, sel_sync, sync, total;
+  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, info_back, sel_sync, sync, tiled, total;
 };
 static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   const size_t ns = nx + nu, TB = (size_t)T * B, fl = sizeof(float);
@@ -554,6 +625,7 @@ static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   w.info_back = take((size_t)B * sizeof(int32_t));
   w.sel_sync = take(4 * sizeof(unsigned));
   w.sync = take(coupled_bytes(T, kSyncQpIterMax));
+  w.tiled = take(coupled_traj_bytes(B, nx, nu));
   w.total = off;
   return w;
 }
@@ -607,6 +679,11 @@ size_t dmpc_coupled_workspace_bytes(int T, int n_qp_iter_max) {
   return coupled_bytes(T, n_qp_iter_max);
 }
 
+size_t dmpc_pnqp_workspace_bytes(int B, int n, int n_iter, int batch_coupled) {
+  if (B <= 0 || n <= 0 || n_iter <= 0 || !batch_coupled) return 0;
+  return coupled_bytes(1, n_iter) + pnqp_coupled_row_bytes(B, n);
+}
+
 int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
               const float *x_init, int n_iter, int batch_coupled, float *x, float *fac, int32_t *piv, float *index_f,
               int32_t *n_iter_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream_) {
@@ -623,17 +700,29 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
   }
   PnqpArgs a{B, H, q, lower, upper, x_init, n_iter, x, fac, piv, index_f, n_iter_out, info, sync};
   void *args[] = {&a};
+  // batch-coupled on a grid that always fits (mpc_coupled.hpp): any n, any B; needs dmpc_pnqp_workspace_bytes
+  auto fixed_grid = [&]() -> int {
+    if (ws_bytes < dmpc_pnqp_workspace_bytes(B, n, n_iter, 1)) return DMPC_E_WORKSPACE;
+    PnqpTiledArgs ta{B, n, H, q, lower, upper, x_init, n_iter, x, fac, piv, index_f, n_iter_out, info};
+    float *vecs = reinterpret_cast<float *>(static_cast<char *>(ws) + coupled_bytes(1, n_iter));
+    void *targs[] = {&ta, &vecs, &sync};
+    return launch_fixed_grid(reinterpret_cast<const void *>(&pnqp_coupled_kernel), B, targs, stream);
+  };
   switch (n) {
 #define CASE(N)                                                                                                  \
   case N:                                                                                                        \
-    if (sync != nullptr)                                                                                         \
-      return launch_cooperative(reinterpret_cast<const void *>(&pnqp_kernel<N>), grid, block, args, 0, stream);  \
+    if (sync != nullptr) {                                                                                       \
+      const int rc = coupled_register_disabled()                                                                 \
+                         ? DMPC_E_UNSUPPORTED                                                                    \
+                         : launch_cooperative(reinterpret_cast<const void *>(&pnqp_kernel<N>), grid, block, args, 0, stream); \
+      return rc == DMPC_E_UNSUPPORTED ? fixed_grid() : rc;                                                       \
+    }                                                                                                            \
     DMPC_LAUNCH_GGL((pnqp_kernel<N>), grid, block, 0, stream, a);                                             \
     break;
     CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
-    default: {   // any n: a workgroup per QP (mpc_tiled.hpp); per-row termination only
-      if (sync != nullptr) return DMPC_E_UNSUPPORTED;
+    default: {   // any n: a workgroup per QP (mpc_tiled.hpp; batch-coupled: mpc_coupled.hpp)
+      if (sync != nullptr) return fixed_grid();
       const size_t shmem = pnqp_tiled_lds_floats(n) * sizeof(float);
       if (shmem > 60 * 1024) return DMPC_E_UNSUPPORTED;
       PnqpTiledArgs ta{B, n, H, q, lower, upper, x_init, n_iter, x, fac, piv, index_f, n_iter_out, info};
@@ -645,7 +734,7 @@ int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, 
 
 size_t dmpc_mpc_backward_rec_workspace_bytes(int T, int B, int nx, int nu, int n_qp_iter_max, int batch_coupled) {
   if (T <= 0 || B <= 0 || nx <= 0 || nu <= 0) return 0;
-  if (batch_coupled) return coupled_bytes(T, n_qp_iter_max);
+  if (batch_coupled) return coupled_bytes(T, n_qp_iter_max) + coupled_traj_bytes(B, nx, nu);
   return mpc_needs_tiles(nx, nu) ? (size_t)B * mpc_tiled_scratch_floats(nx, nu) * sizeof(float) : 0;
 }
 
@@ -657,9 +746,10 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
   if (!C_hat || !c_hat || !F_hat || !controls || !u_lower || !u_upper || !Ks_out || !ks_out || !n_qp_iter)
     return DMPC_E_BADARG;
   if (!aligned16(C_hat) || !aligned16(c_hat) || !aligned16(F_hat) || !aligned16(f_hat)) return DMPC_E_BADARG;
-  if (batch_coupled && (!ws || ws_bytes < coupled_bytes(T, n_qp_iter_max))) return DMPC_E_WORKSPACE;
+  if (batch_coupled && (!ws || ws_bytes < dmpc_mpc_backward_rec_workspace_bytes(T, B, nx, nu, n_qp_iter_max, 1))) return DMPC_E_WORKSPACE;
   MpcBackArgs ba{T, B, C_hat, c_hat, F_hat, f_hat, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
                  n_qp_iter, info, nullptr, batch_coupled ? static_cast<unsigned *>(ws) : nullptr, nullptr};
+  if (batch_coupled) ba.tiled_scratch = reinterpret_cast<float *>(static_cast<char *>(ws) + coupled_bytes(T, n_qp_iter_max));
   if (!batch_coupled && mpc_needs_tiles(nx, nu)) {
     if (!ws || ws_bytes < dmpc_mpc_backward_rec_workspace_bytes(T, B, nx, nu, n_qp_iter_max, 0)) return DMPC_E_WORKSPACE;
     ba.tiled_scratch = static_cast<float *>(ws);
@@ -741,7 +831,7 @@ int dmpc_mpc_step_forward(int T, int B, int nx, int nu, const float *C_hat, cons
   MpcBackArgs ba{T, B, C_hat, c_use, F_hat, f_use, controls, u_lower, u_upper, n_qp_iter_max, Ks_out, ks_out,
                  n_qp_iter, info, nullptr, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
                  need_expand ? states : nullptr};
-  if (mpc_needs_tiles(nx, nu)) ba.tiled_scratch = reinterpret_cast<float *>(base + w.tiled);
+  if (mpc_needs_tiles(nx, nu) || batch_coupled) ba.tiled_scratch = reinterpret_cast<float *>(base + w.tiled);
   MpcFwdArgs fa{T, B, Ks_out, ks_out, controls, states, u_lower, u_upper, C_true, c_true, F_true, f_true, ls_decay,
                 max_ls_iter, /*ls_cap=*/64, x_out, u_out, u_first, costs, old_costs, alphas, objs, n_ls_iter, info};
   {
@@ -843,6 +933,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     MpcBackArgs ba{T, B, C, dyn_kind == 1 ? c_back : c, F_hat, nullptr, u_cur, u_lower, u_upper, n_qp_iter_max, Ks, ks,
                    ip(w.nqp), info, done, batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr,
                    dyn_kind == 1 ? nullptr : xs_it, 0};
+    if (mpc_needs_tiles(nx, nu) || batch_coupled) ba.tiled_scratch = fp(w.tiled);
     if (it == 0) fused_select = fuse_lin && nx == 3 && nu == 1 && copy_here && mpc_back_dma_ok(ba);
     if (fused_select && info != nullptr) {   // the sweep may run ahead of `done`: its flags count only if the search follows
       ba.info = ip(w.info_back);

@@ -5,8 +5,8 @@
 // columns in one wavefront (n_state + n_ctrl + 1 <= 64), and `MPCstep` beyond that was refused.  Here, as in
 // lqr_tiled.hpp: one workgroup of 256 threads per trajectory (per QP for the standalone solver), runtime dimensions, the
 // matrices in a per-trajectory area of the caller's workspace, the QP's vectors in LDS, every phase spread over the
-// threads by output element, `__syncthreads()` between phases.  Per-trajectory termination of the QP only (the
-// batch-coupled parity mode needs the whole batch resident in registers-and-LDS kernels: DMPC_E_UNSUPPORTED here).
+// threads by output element, `__syncthreads()` between phases.  Per-trajectory termination of the QP here; the
+// batch-coupled form of the same pieces, for any size and any batch, is mpc_coupled.hpp.
 // Same algorithm and operation order as pnqp_device.hpp / mpc_generic.hpp / the oracle; slow, and correct.
 #pragma once
 #include "lqr_tiled.hpp"
@@ -83,99 +83,141 @@ struct PnqpTiledOut {
   bool converged;
 };
 
+// The vectors of one QP (pnqp_tiled_lds_floats(n) floats, in LDS or in the caller's workspace) and the pieces of a QP
+// iteration on them.  Each piece is executed by the whole workgroup and ends behind a __syncthreads(); its verdict is
+// workgroup-uniform.  pnqp_tiled (per-row termination) and the batch-coupled kernels of mpc_coupled.hpp are put together from
+// the same pieces: same arithmetic, same order.
+struct PnqpTiledVecs {
+  float *x, *g, *gf, *dx, *xh, *d, *hd;
+  const float *lo, *hi, *q;
+  int *free_, *piv, *s_ctl;   // s_ctl: [0] pivot exchange, [1] verdict of the last piece, [2] = it, [3] = converged
+  float *s_f;                 // [0] alpha, [1] != 0: this row still moves (batch-coupled search only)
+  __device__ __forceinline__ PnqpTiledVecs(float *v, int n)
+      : x(v), g(v + n), gf(v + 2 * n), dx(v + 3 * n), xh(v + 4 * n), d(v + 5 * n), hd(v + 6 * n), lo(v + 7 * n), hi(v + 8 * n),
+        q(v + 9 * n), free_(reinterpret_cast<int *>(v + 10 * n)), piv(free_ + n), s_ctl(piv + n),
+        s_f(reinterpret_cast<float *>(s_ctl + 4)) {}
+};
+
+// x_init = -H^-1 q unless warm (pnqp.py:75-83), projected on the box (:93); it = n_iter - 1, not converged
+__device__ __forceinline__ void pnqp_tiled_start(const float *H, int ldh, int n, float *fac, const PnqpTiledVecs &w, bool warm,
+                                                 int n_iter) {
+  const int tid = threadIdx.x;
+  constexpr int NT = kTiledThreads;
+  if (!warm) {
+    for (int e = tid; e < n * n; e += NT) fac[e] = H[(e / n) * ldh + (e % n)];
+    for (int r = tid; r < n; r += NT) w.x[r] = w.q[r];
+    __syncthreads();
+    tiled_lu_factor(fac, n, w.piv, w.s_ctl);
+    if (tid == 0) {
+      tiled_lu_solve(fac, w.piv, n, w.x, 1);
+      for (int r = 0; r < n; ++r) w.x[r] = -w.x[r];
+    }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += NT) w.x[r] = fminf(fmaxf(w.x[r], w.lo[r]), w.hi[r]);   // :93
+  if (tid == 0) { w.s_ctl[2] = n_iter - 1; w.s_ctl[3] = 0; }
+  __syncthreads();
+}
+
+// gradient, free set, H_f = LU, Newton step dx (:98-136); true iff ||dx|| >= 1e-4 (:139-140).  alpha = 1 for the search.
+__device__ __forceinline__ bool pnqp_tiled_newton(const float *H, int ldh, int n, float *fac, const PnqpTiledVecs &w) {
+  const int tid = threadIdx.x;
+  constexpr int NT = kTiledThreads;
+  const float tol_sq = __builtin_bit_cast(float, kPnqpDxTolSqBits);
+  for (int r = tid; r < n; r += NT) {   // grad = Hx + q                              :98
+    float acc = w.q[r];
+    for (int c = 0; c < n; ++c) acc = fmaf(H[r * ldh + c], w.x[c], acc);
+    w.g[r] = acc;
+    const bool cl = ((w.x[r] == w.lo[r]) && (acc > 0.f)) || ((w.x[r] == w.hi[r]) && (acc < 0.f));   // :110, exact equality
+    w.gf[r] = cl ? 0.f : acc;
+    w.free_[r] = cl ? 0 : 1;
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += NT) {   // H_f = H on free x free, 0 elsewhere, + 1e-11 I      :124-129
+    const int r = e / n, c = e % n;
+    float val = (w.free_[r] && w.free_[c]) ? H[r * ldh + c] : 0.f;
+    if (r == c) val += kPnqpReg;
+    fac[e] = val;
+  }
+  for (int r = tid; r < n; r += NT) w.dx[r] = w.gf[r];
+  __syncthreads();
+  tiled_lu_factor(fac, n, w.piv, w.s_ctl);                                               // :136
+  if (tid == 0) {
+    tiled_lu_solve(fac, w.piv, n, w.dx, 1);
+    float n2 = 0.f;
+    for (int r = 0; r < n; ++r) {
+      w.dx[r] = -w.dx[r];
+      n2 = fmaf(w.dx[r], w.dx[r], n2);
+    }
+    const bool large = n2 >= tol_sq;                                                 // :139-140
+    w.s_ctl[1] = large ? 1 : 0;
+    w.s_f[0] = 1.0f;
+    w.s_f[1] = large ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  const bool large = w.s_ctl[1] != 0;
+  __syncthreads();     // (s_ctl[1] is the next piece's verdict too)
+  return large;
+}
+
+// one trial of the backtracking search (:172-186): xh = the projected step of length alpha, lhs = 1 + 0.5 d'Hd / g'd as in
+// pnqp_device.hpp; true iff the trial FAILS (then alpha has been shortened).  `moving`: the row counts (a row of a coupled
+// batch that has already converged carries GAMMA + 1e-6, :174: it passes, and keeps its alpha)
+__device__ __forceinline__ bool pnqp_tiled_trial(const float *H, int ldh, int n, const PnqpTiledVecs &w, bool moving) {
+  const int tid = threadIdx.x;
+  constexpr int NT = kTiledThreads;
+  const float alpha = w.s_f[0];
+  for (int r = tid; r < n; r += NT) {
+    const float xr = fminf(fmaxf(fmaf(alpha, w.dx[r], w.x[r]), w.lo[r]), w.hi[r]);         // :173
+    w.xh[r] = xr;
+    w.d[r] = xr - w.x[r];
+  }
+  __syncthreads();
+  for (int r = tid; r < n; r += NT) {
+    float acc = 0.f;
+    for (int c = 0; c < n; ++c) acc = fmaf(H[r * ldh + c], w.d[c], acc);
+    w.hd[r] = acc;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float gd = 0.f, dHd = 0.f;
+    for (int r = 0; r < n; ++r) {
+      gd = fmaf(w.g[r], w.d[r], gd);
+      dHd = fmaf(w.d[r], w.hd[r], dHd);
+    }
+    const float lhs = fmaf(0.5f * dHd, fast_rcp(gd), 1.0f);                        // :175-176
+    const bool fails = moving && lhs <= kPnqpGamma;                                // false for NaN
+    if (fails) w.s_f[0] = alpha * kPnqpDecay;                                      // :185-186
+    w.s_ctl[1] = fails ? 1 : 0;
+  }
+  __syncthreads();
+  const bool fails = w.s_ctl[1] != 0;
+  __syncthreads();
+  return fails;
+}
+
+__device__ __forceinline__ void pnqp_tiled_accept(int n, const PnqpTiledVecs &w) {     // :190
+  for (int r = threadIdx.x; r < n; r += kTiledThreads) w.x[r] = w.xh[r];
+  __syncthreads();
+}
+
 // Projected-Newton box QP (pnqp.py:37-201, per-row termination = pnqp_solve_rows) by the workgroup.
 //   H: n x n, row stride ldh (read only).  fac: n x n scratch; on return the LU of the last free-set Hessian, piv its pivots.
 //   v: LDS vectors (pnqp_tiled_lds_floats); on entry v[7n..8n) = lo, v[8n..9n) = hi, v[9n..10n) = q, v[0..n) = x (warm start).
 __device__ __forceinline__ PnqpTiledOut pnqp_tiled(const float *H, int ldh, int n, float *fac, float *v, bool warm, int n_iter) {
-  const int tid = threadIdx.x;
-  constexpr int NT = kTiledThreads;
-  float *x = v, *g = v + n, *gf = v + 2 * n, *dx = v + 3 * n, *xh = v + 4 * n, *d = v + 5 * n, *hd = v + 6 * n;
-  const float *lo = v + 7 * n, *hi = v + 8 * n, *q = v + 9 * n;
-  int *free_ = reinterpret_cast<int *>(v + 10 * n);
-  int *piv = free_ + n;
-  int *s_ctl = piv + n;     // [0] pivot exchange, [1] loop flag, [2] = it, [3] = converged
-  float *s_f = reinterpret_cast<float *>(s_ctl + 4);   // [0] alpha
-  if (!warm) {   // x_init = -H^-1 q                                                     pnqp.py:75-83
-    for (int e = tid; e < n * n; e += NT) fac[e] = H[(e / n) * ldh + (e % n)];
-    for (int r = tid; r < n; r += NT) x[r] = q[r];
-    __syncthreads();
-    tiled_lu_factor(fac, n, piv, s_ctl);
-    if (tid == 0) {
-      tiled_lu_solve(fac, piv, n, x, 1);
-      for (int r = 0; r < n; ++r) x[r] = -x[r];
-    }
-    __syncthreads();
-  }
-  for (int r = tid; r < n; r += NT) x[r] = fminf(fmaxf(x[r], lo[r]), hi[r]);   // :93
-  if (tid == 0) { s_ctl[2] = n_iter - 1; s_ctl[3] = 0; }
-  __syncthreads();
-  const float tol_sq = __builtin_bit_cast(float, kPnqpDxTolSqBits);
+  const PnqpTiledVecs w(v, n);
+  pnqp_tiled_start(H, ldh, n, fac, w, warm, n_iter);
   for (int i = 0; i < n_iter; ++i) {
-    for (int r = tid; r < n; r += NT) {   // grad = Hx + q                              :98
-      float acc = q[r];
-      for (int c = 0; c < n; ++c) acc = fmaf(H[r * ldh + c], x[c], acc);
-      g[r] = acc;
-      const bool cl = ((x[r] == lo[r]) && (acc > 0.f)) || ((x[r] == hi[r]) && (acc < 0.f));   // :110, exact equality
-      gf[r] = cl ? 0.f : acc;
-      free_[r] = cl ? 0 : 1;
-    }
-    __syncthreads();
-    for (int e = tid; e < n * n; e += NT) {   // H_f = H on free x free, 0 elsewhere, + 1e-11 I      :124-129
-      const int r = e / n, c = e % n;
-      float val = (free_[r] && free_[c]) ? H[r * ldh + c] : 0.f;
-      if (r == c) val += kPnqpReg;
-      fac[e] = val;
-    }
-    for (int r = tid; r < n; r += NT) dx[r] = gf[r];
-    __syncthreads();
-    tiled_lu_factor(fac, n, piv, s_ctl);                                               // :136
-    if (tid == 0) {
-      tiled_lu_solve(fac, piv, n, dx, 1);
-      float n2 = 0.f;
-      for (int r = 0; r < n; ++r) {
-        dx[r] = -dx[r];
-        n2 = fmaf(dx[r], dx[r], n2);
-      }
-      const bool large = n2 >= tol_sq;                                                 // :139-140
-      s_ctl[1] = large ? 1 : 0;
-      if (!large) { s_ctl[2] = i; s_ctl[3] = 1; }                                      // :141-144
-      s_f[0] = 1.0f;
-    }
-    __syncthreads();
-    if (s_ctl[1] == 0) break;
-    // backtracking line search (:162-190); lhs = 1 + 0.5 d'Hd / g'd as in pnqp_device.hpp
-    for (int count = 0; count < kPnqpMaxLs; ++count) {
-      const float alpha = s_f[0];
-      for (int r = tid; r < n; r += NT) {
-        const float xr = fminf(fmaxf(fmaf(alpha, dx[r], x[r]), lo[r]), hi[r]);         // :173
-        xh[r] = xr;
-        d[r] = xr - x[r];
-      }
+    if (!pnqp_tiled_newton(H, ldh, n, fac, w)) {                                         // :141-144
+      if (threadIdx.x == 0) { w.s_ctl[2] = i; w.s_ctl[3] = 1; }
       __syncthreads();
-      for (int r = tid; r < n; r += NT) {
-        float acc = 0.f;
-        for (int c = 0; c < n; ++c) acc = fmaf(H[r * ldh + c], d[c], acc);
-        hd[r] = acc;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        float gd = 0.f, dHd = 0.f;
-        for (int r = 0; r < n; ++r) {
-          gd = fmaf(g[r], d[r], gd);
-          dHd = fmaf(d[r], hd[r], dHd);
-        }
-        const float lhs = fmaf(0.5f * dHd, fast_rcp(gd), 1.0f);                        // :175-176
-        const bool fails = lhs <= kPnqpGamma;                                          // false for NaN
-        if (fails) s_f[0] = alpha * kPnqpDecay;                                        // :185-186
-        s_ctl[1] = fails ? 1 : 0;
-      }
-      __syncthreads();
-      if (s_ctl[1] == 0) break;                                                        // :172: the row passed
+      break;
     }
-    for (int r = tid; r < n; r += NT) x[r] = xh[r];                                    // :190
-    __syncthreads();
+    for (int count = 0; count < kPnqpMaxLs; ++count)
+      if (!pnqp_tiled_trial(H, ldh, n, w, true)) break;                                  // :172: the row passed
+    pnqp_tiled_accept(n, w);
   }
-  PnqpTiledOut out{s_ctl[2], s_ctl[3] != 0};
+  PnqpTiledOut out{w.s_ctl[2], w.s_ctl[3] != 0};
   __syncthreads();
   return out;
 }
@@ -219,108 +261,136 @@ __global__ __launch_bounds__(kTiledThreads) void pnqp_tiled_kernel(const PnqpTil
 // ---- MPCstep.backward_rec (mpc_step.py:70-173): the tiled LQR sweep with the box QP in place of the gain solve
 __host__ __device__ inline size_t mpc_tiled_scratch_floats(int nx, int nu) { return tiled_scratch_floats(nx, nu); }
 
+// a trajectory's matrices in the workspace
+struct MpcTiledMats {
+  float *Vt, *Qt, *Wt, *LU, *Kt, *Rt;
+  __device__ __forceinline__ MpcTiledMats(float *base, int nx, int nu) {
+    const int ns = nx + nu, nc = ns + 1;
+    Vt = base;
+    Qt = Vt + (size_t)nx * nc;
+    Wt = Qt + (size_t)ns * nc;
+    LU = Wt + (size_t)nx * nc;
+    Kt = LU + (size_t)nu * nu;
+    Rt = Kt + (size_t)nu * nc;
+  }
+};
+
+// timestep t up to the box QP: Q~_t (:110,116, with need_expand's re-centring :305-317) and the QP's data in v
+// (lo, hi = bounds - u_t, q = qu; x stays the later timestep's solution: the warm start, :119-146).  tau: ns floats.
+__device__ __forceinline__ void mpc_tiled_before_qp(const MpcBackArgs &a, int nx, int nu, int b, int t, const MpcTiledMats &m,
+                                                    float *v, float *tau) {
+  const int ns = nx + nu, nc = ns + 1, tid = threadIdx.x;
+  constexpr int NT = kTiledThreads;
+  const size_t B = (size_t)a.B, tb = (size_t)t * B + b;
+  float *Vt = m.Vt, *Qt = m.Qt, *Wt = m.Wt;
+  const float *Cp = a.C + tb * ns * ns;
+  for (int e = tid; e < ns * ns; e += NT) Qt[(e / ns) * nc + (e % ns)] = Cp[e];
+  if (a.states != nullptr)
+    for (int j = tid; j < ns; j += NT) tau[j] = j < nx ? a.states[tb * nx + j] : a.controls[tb * nu + (j - nx)];
+  __syncthreads();
+  for (int i = tid; i < ns; i += NT) {
+    float ci = a.c[tb * ns + i];
+    if (a.states != nullptr)      // need_expand inside the sweep: c_hat = C [x_t; u_t] + c                  :305-317
+      for (int j = 0; j < ns; ++j) ci = fmaf(Qt[i * nc + j], tau[j], ci);
+    Qt[i * nc + ns] = ci;
+  }
+  __syncthreads();
+  if (t < a.T - 1) {                // Q~ = C~ + F^T (V F~ + v e_aff)                                        :110,116
+    const float *Fp = a.F + tb * nx * ns;
+    const float *fp = a.f ? a.f + tb * nx : nullptr;
+    for (int e = tid; e < nx * nc; e += NT) {
+      const int i = e / nc, j = e % nc;
+      float acc = (j == ns) ? Vt[i * nc + ns] : 0.f;
+      if (j < ns) {
+        for (int k = 0; k < nx; ++k) acc = fmaf(Vt[i * nc + k], Fp[(size_t)k * ns + j], acc);
+      } else if (fp != nullptr) {
+        for (int k = 0; k < nx; ++k) acc = fmaf(Vt[i * nc + k], fp[k], acc);
+      }
+      Wt[e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < ns * nc; e += NT) {
+      const int i = e / nc, j = e % nc;
+      float acc = Qt[e];
+      for (int k = 0; k < nx; ++k) acc = fmaf(Fp[(size_t)k * ns + i], Wt[k * nc + j], acc);
+      Qt[e] = acc;
+    }
+    __syncthreads();
+  }
+  // k_t: box QP on (Quu, qu), bounds lower - u, upper - u, warm-started from the later timestep        :119-146
+  for (int mm = tid; mm < nu; mm += NT) {
+    const float uc = a.controls[tb * nu + mm];
+    v[7 * nu + mm] = a.lower[tb * nu + mm] - uc;
+    v[8 * nu + mm] = a.upper[tb * nu + mm] - uc;
+    v[9 * nu + mm] = Qt[(nx + mm) * nc + ns];
+  }
+  __syncthreads();
+}
+
+// timestep t after the box QP (its solution and free set in v, the free-set LU in m.LU): gains (:147-157), R (:165-166),
+// value function (:159-171)
+__device__ __forceinline__ void mpc_tiled_after_qp(const MpcBackArgs &a, int nx, int nu, int b, int t, const MpcTiledMats &m,
+                                                   const float *v) {
+  const int ns = nx + nu, nc = ns + 1, tid = threadIdx.x;
+  constexpr int NT = kTiledThreads;
+  const size_t B = (size_t)a.B, tb = (size_t)t * B + b;
+  float *Vt = m.Vt, *Qt = m.Qt, *LU = m.LU, *Kt = m.Kt, *Rt = m.Rt;
+  const int *free_ = reinterpret_cast<const int *>(v + 10 * nu);
+  const int *piv = free_ + nu;
+  // K_t = -LU_free^-1 Qux with the rows of clamped controls zeroed; the affine column carries k_t      :147-157
+  for (int j = tid; j < nc; j += NT) {
+    if (j == ns) {
+      for (int mm = 0; mm < nu; ++mm) Kt[mm * nc + j] = v[mm];
+    } else {
+      for (int mm = 0; mm < nu; ++mm) Kt[mm * nc + j] = free_[mm] ? Qt[(nx + mm) * nc + j] : 0.f;
+      if (nu == 1) Kt[j] = Kt[j] / LU[0];
+      else tiled_lu_solve(LU, piv, nu, Kt + j, nc);
+      for (int mm = 0; mm < nu; ++mm) Kt[mm * nc + j] = -Kt[mm * nc + j];
+    }
+    if (j < nx || j == ns)
+      for (int mm = 0; mm < nu; ++mm) {
+        if (j == ns) a.ks[tb * nu + mm] = Kt[mm * nc + j];
+        else a.Ks[(tb * nu + mm) * nx + j] = Kt[mm * nc + j];
+      }
+    for (int mm = 0; mm < nu; ++mm) {   // R = Qu. + Quu K~ from the UNMASKED blocks                             :165-166
+      float acc = Qt[(nx + mm) * nc + j];
+      for (int l = 0; l < nu; ++l) acc = fmaf(Qt[(nx + mm) * nc + nx + l], Kt[l * nc + j], acc);
+      Rt[mm * nc + j] = acc;
+    }
+  }
+  __syncthreads();
+  if (t > 0)
+    for (int e = tid; e < nx * nc; e += NT) {
+      const int i = e / nc, j = e % nc;
+      float acc = Qt[i * nc + j];
+      for (int mm = 0; mm < nu; ++mm) acc = fmaf(Qt[i * nc + nx + mm], Kt[mm * nc + j], acc);
+      for (int mm = 0; mm < nu; ++mm) acc = fmaf(Kt[mm * nc + i], Rt[mm * nc + j], acc);
+      Vt[e] = acc;
+    }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(kTiledThreads) void mpc_tiled_backward_kernel(const MpcBackArgs a, const int nx, const int nu,
                                                                            float *scratch) {
   if (a.done != nullptr && *a.done != 0) return;
   const int ns = nx + nu, nc = ns + 1;
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  const int T = a.T;
-  const size_t B = (size_t)a.B;
   constexpr int NT = kTiledThreads;
-  float *Vt = scratch + (size_t)b * mpc_tiled_scratch_floats(nx, nu);
-  float *Qt = Vt + (size_t)nx * nc;
-  float *Wt = Qt + (size_t)ns * nc;
-  float *LU = Wt + (size_t)nx * nc;
-  float *Kt = LU + (size_t)nu * nu;
-  float *Rt = Kt + (size_t)nu * nc;
+  const MpcTiledMats m(scratch + (size_t)b * mpc_tiled_scratch_floats(nx, nu), nx, nu);
   extern __shared__ float v[];                 // the QP's vectors, then [ns] tau for the re-centring
   float *tau = v + pnqp_tiled_lds_floats(nu);
-  const int *free_ = reinterpret_cast<const int *>(v + 10 * nu);
-  const int *piv = free_ + nu;
   int n_total = 0, info_bits = 0;
 
-  for (int e = tid; e < nx * nc; e += NT) Vt[e] = 0.f;
-  for (int m = tid; m < nu; m += NT) v[m] = 0.f;     // warm start of the first QP is unused (cold)
+  for (int e = tid; e < nx * nc; e += NT) m.Vt[e] = 0.f;
+  for (int mm = tid; mm < nu; mm += NT) v[mm] = 0.f;     // warm start of the first QP is unused (cold)
   __syncthreads();
-  for (int t = T - 1; t >= 0; --t) {
-    const size_t tb = (size_t)t * B + b;
-    const float *Cp = a.C + tb * ns * ns;
-    for (int e = tid; e < ns * ns; e += NT) Qt[(e / ns) * nc + (e % ns)] = Cp[e];
-    if (a.states != nullptr)
-      for (int j = tid; j < ns; j += NT) tau[j] = j < nx ? a.states[tb * nx + j] : a.controls[tb * nu + (j - nx)];
-    __syncthreads();
-    for (int i = tid; i < ns; i += NT) {
-      float ci = a.c[tb * ns + i];
-      if (a.states != nullptr)      // need_expand inside the sweep: c_hat = C [x_t; u_t] + c                  :305-317
-        for (int j = 0; j < ns; ++j) ci = fmaf(Qt[i * nc + j], tau[j], ci);
-      Qt[i * nc + ns] = ci;
-    }
-    __syncthreads();
-    if (t < T - 1) {                // Q~ = C~ + F^T (V F~ + v e_aff)                                        :110,116
-      const float *Fp = a.F + tb * nx * ns;
-      const float *fp = a.f ? a.f + tb * nx : nullptr;
-      for (int e = tid; e < nx * nc; e += NT) {
-        const int i = e / nc, j = e % nc;
-        float acc = (j == ns) ? Vt[i * nc + ns] : 0.f;
-        if (j < ns) {
-          for (int k = 0; k < nx; ++k) acc = fmaf(Vt[i * nc + k], Fp[(size_t)k * ns + j], acc);
-        } else if (fp != nullptr) {
-          for (int k = 0; k < nx; ++k) acc = fmaf(Vt[i * nc + k], fp[k], acc);
-        }
-        Wt[e] = acc;
-      }
-      __syncthreads();
-      for (int e = tid; e < ns * nc; e += NT) {
-        const int i = e / nc, j = e % nc;
-        float acc = Qt[e];
-        for (int k = 0; k < nx; ++k) acc = fmaf(Fp[(size_t)k * ns + i], Wt[k * nc + j], acc);
-        Qt[e] = acc;
-      }
-      __syncthreads();
-    }
-    // k_t: box QP on (Quu, qu), bounds lower - u, upper - u, warm-started from the later timestep        :119-146
-    for (int m = tid; m < nu; m += NT) {
-      const float uc = a.controls[tb * nu + m];
-      v[7 * nu + m] = a.lower[tb * nu + m] - uc;
-      v[8 * nu + m] = a.upper[tb * nu + m] - uc;
-      v[9 * nu + m] = Qt[(nx + m) * nc + ns];
-    }
-    __syncthreads();
-    const PnqpTiledOut qp = pnqp_tiled(Qt + (size_t)nx * nc + nx, nc, nu, LU, v, /*warm=*/t != T - 1, a.n_qp_iter);
+  for (int t = a.T - 1; t >= 0; --t) {
+    mpc_tiled_before_qp(a, nx, nu, b, t, m, v, tau);
+    const PnqpTiledOut qp = pnqp_tiled(m.Qt + (size_t)nx * nc + nx, nc, nu, m.LU, v, /*warm=*/t != a.T - 1, a.n_qp_iter);
     n_total += 1 + qp.it;
     if (!qp.converged) info_bits |= 4;
-    // K_t = -LU_free^-1 Qux with the rows of clamped controls zeroed; the affine column carries k_t      :147-157
-    for (int j = tid; j < nc; j += NT) {
-      if (j == ns) {
-        for (int m = 0; m < nu; ++m) Kt[m * nc + j] = v[m];
-      } else {
-        for (int m = 0; m < nu; ++m) Kt[m * nc + j] = free_[m] ? Qt[(nx + m) * nc + j] : 0.f;
-        if (nu == 1) Kt[j] = Kt[j] / LU[0];
-        else tiled_lu_solve(LU, piv, nu, Kt + j, nc);
-        for (int m = 0; m < nu; ++m) Kt[m * nc + j] = -Kt[m * nc + j];
-      }
-      if (j < nx || j == ns)
-        for (int m = 0; m < nu; ++m) {
-          if (j == ns) a.ks[tb * nu + m] = Kt[m * nc + j];
-          else a.Ks[(tb * nu + m) * nx + j] = Kt[m * nc + j];
-        }
-      for (int m = 0; m < nu; ++m) {   // R = Qu. + Quu K~ from the UNMASKED blocks                             :165-166
-        float acc = Qt[(nx + m) * nc + j];
-        for (int l = 0; l < nu; ++l) acc = fmaf(Qt[(nx + m) * nc + nx + l], Kt[l * nc + j], acc);
-        Rt[m * nc + j] = acc;
-      }
-    }
-    __syncthreads();
-    if (t > 0)
-      for (int e = tid; e < nx * nc; e += NT) {
-        const int i = e / nc, j = e % nc;
-        float acc = Qt[i * nc + j];
-        for (int m = 0; m < nu; ++m) acc = fmaf(Qt[i * nc + nx + m], Kt[m * nc + j], acc);
-        for (int m = 0; m < nu; ++m) acc = fmaf(Kt[m * nc + i], Rt[m * nc + j], acc);
-        Vt[e] = acc;
-      }
-    __syncthreads();
+    mpc_tiled_after_qp(a, nx, nu, b, t, m, v);
   }
   if (tid == 0) {
     a.n_qp_total[b] = n_total;

@@ -40,7 +40,7 @@ def pnqp_device(H, q, lower, upper, x_init, n_iter, info=None, batch_coupled=Fal
     iters = torch.empty((B,), dtype=torch.int32, device=dev)
     ws, need = None, 0
     if batch_coupled:
-        need = lib.dmpc_coupled_workspace_bytes(1, int(n_iter))
+        need = lib.dmpc_pnqp_workspace_bytes(B, n, int(n_iter), 1)     # (decision slots + the fixed-grid form's rows: any n, any B)
         ws = _workspace(need, dev)
     with _lib.guard(dev):
         rc = lib.dmpc_pnqp(B, n, _lib.ptr(H), _lib.ptr(q), _lib.ptr(lower), _lib.ptr(upper), _lib.ptr(x_init),

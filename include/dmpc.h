@@ -31,7 +31,7 @@ extern "C" {
  * 400 (round 4): covers the round-3 changes that were made under 202 (dmpc_lqr_solve_saving + Vv_out, dmpc_lqr_kkt_grad_saved
  * + Vv, dmpc_pendulum_rollout_linearize + clamp_grad_closed, dmpc_mpc_step_backward + 5 arguments, dmpc_box_ddp dyn_params[6],
  * larger dmpc_lqr_workspace_bytes) and this round's additions. */
-#define DMPC_VERSION 410
+#define DMPC_VERSION 411
 
 #define DMPC_E_BADARG (-1)      /* NULL / non-positive size */
 #define DMPC_E_UNSUPPORTED (-2) /* dimensions outside what the kernels cover */
@@ -189,12 +189,16 @@ int dmpc_batch_lu_solve(int B, int n, int k, const float *LU, const int32_t *piv
  *   batch_coupled = 0: per-row termination (= the reference called with a batch of one per row; what shards
  *   across GPUs).  batch_coupled = 1: the reference's own batch semantics - the convergence test and the Armijo
  *   loop are reduced over the WHOLE batch (pnqp.py:139-144,172,187), so a row's answer depends on its batch-mates;
- *   needs `ws` of dmpc_coupled_workspace_bytes(1, n_iter) bytes and a batch that is resident in one cooperative
- *   launch (DMPC_E_UNSUPPORTED otherwise).
+ *   needs `ws` of dmpc_pnqp_workspace_bytes(B, n, n_iter, 1) bytes.  Any n, any B (round 5): n <= 8 with the whole batch
+ *   resident runs in registers (one lane per row, grid barriers at the decisions); a batch that is not, and every n > 8, runs
+ *   on a fixed resident grid whose workgroups walk their rows piece by piece, the rows' vectors in `ws` (mpc_coupled.hpp;
+ *   DMPC_NO_COOP_REGISTER=1 forces that form).  (With only dmpc_coupled_workspace_bytes(1, n_iter) bytes - the decision
+ *   slots, what rounds 1-4 asked for - the register form still runs; DMPC_E_WORKSPACE when it is the other form's turn.)
  *   outputs: x [B,n]; fac [B,n,n] = LU of the last free-set Hessian (n == 1: H_f [B,1,1]);
  *   piv [B,n] int32 1-based; index_f [B,n] float {0,1}; n_iter_out [B] int32 (the reference's `i`; one value
  *   for the whole batch when coupled). */
 size_t dmpc_coupled_workspace_bytes(int T, int n_qp_iter_max);
+size_t dmpc_pnqp_workspace_bytes(int B, int n, int n_iter, int batch_coupled);   /* 0 when not coupled */
 int dmpc_pnqp(int B, int n, const float *H, const float *q, const float *lower, const float *upper,
               const float *x_init, int n_iter, int batch_coupled, float *x, float *fac, int32_t *piv,
               float *index_f, int32_t *n_iter_out, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
@@ -233,8 +237,9 @@ int dmpc_mpc_step_status(int B, const int32_t *info, const int32_t *n_qp_iter, c
 
 /* The two halves of forward(), separately callable like the reference's methods:
  * backward_rec (mpc_step.py:70-173): c_hat must already be re-centred when need_expand applies;
- *   batch_coupled as in dmpc_pnqp (one PNQP per timestep; `ws` of dmpc_coupled_workspace_bytes(T, n_qp_iter_max)
- *   bytes, NULL when not coupled; dmpc_mpc_step_forward / dmpc_box_ddp carve it out of their own workspace);
+ *   batch_coupled as in dmpc_pnqp (one PNQP per timestep; `ws` of dmpc_mpc_backward_rec_workspace_bytes(..., 1) bytes;
+ *   dmpc_mpc_step_forward / dmpc_box_ddp carve it out of their own workspace).  Any shape, any batch: the register kernels
+ *   when the whole batch is resident in one launch of theirs, else mpc_coupled.hpp's fixed grid (slow, same decisions);
  * forward_rec (mpc_step.py:175-286): gains in, line-searched trajectory out.  Its loop condition is batch-global in
  *   the reference too (:196), but there a trajectory's result does not depend on its batch-mates (a trajectory that
  *   is no longer worse keeps its step size and re-computes the same rollout), so it has no coupled mode. */
@@ -242,9 +247,10 @@ int dmpc_mpc_backward_rec(int T, int B, int nx, int nu, const float *C_hat, cons
                           const float *F_hat, const float *f_hat, const float *controls, const float *u_lower,
                           const float *u_upper, int n_qp_iter_max, int batch_coupled, float *Ks_out, float *ks_out,
                           int32_t *n_qp_iter, void *ws, size_t ws_bytes, int32_t *info, dmpc_stream_t stream);
-/* what dmpc_mpc_backward_rec wants in `ws`: the decision slots of the batch-coupled termination, or - shapes with more than 8
- * controls or more than 64 columns, which run on the tiled kernels (a workgroup per trajectory, matrices in the workspace;
- * per-trajectory termination only) - every trajectory's matrices; 0 otherwise (ws may then be NULL). */
+/* what dmpc_mpc_backward_rec wants in `ws`: batch-coupled, the decision slots and every trajectory's matrices and QP vectors
+ * (the fixed-grid form's state); per-trajectory termination, shapes with more than 8 controls or more than 64 columns (the
+ * tiled kernels: a workgroup per trajectory, matrices in the workspace): every trajectory's matrices; 0 otherwise (ws may
+ * then be NULL). */
 size_t dmpc_mpc_backward_rec_workspace_bytes(int T, int B, int nx, int nu, int n_qp_iter_max, int batch_coupled);
 int dmpc_mpc_forward_rec(int T, int B, int nx, int nu, const float *Ks, const float *ks, const float *controls,
                          const float *states, const float *u_lower, const float *u_upper, const float *C_true,

@@ -66,6 +66,18 @@ int main() {
   EXPECT(dmpc_lqr_solve(0, 1, 1, 1, p, p, p, p, p, nullptr, nullptr, nullptr, p, p, nullptr, 0, nullptr, nullptr) == DMPC_E_BADARG);
   EXPECT(dmpc_pnqp(0, 2, p, p, p, p, nullptr, 20, 0, p, p, pi, p, pi, nullptr, 0, pi, nullptr) == DMPC_E_BADARG);
   EXPECT(dmpc_pnqp(4, 2, p, p, p, p, nullptr, 20, 1, p, p, pi, p, pi, nullptr, 0, pi, nullptr) == DMPC_E_WORKSPACE);
+  // batch-coupled workspaces (round 5: the fixed-grid form's rows behind the decision slots)
+  EXPECT(dmpc_pnqp_workspace_bytes(4, 2, 20, 0) == 0);
+  EXPECT(dmpc_pnqp_workspace_bytes(0, 2, 20, 1) == 0);
+  for (int n : {1, 2, 8, 9, 40})
+    for (int B : {1, 256, 16384})
+      EXPECT(dmpc_pnqp_workspace_bytes(B, n, 20, 1) >= dmpc_coupled_workspace_bytes(1, 20) + (size_t)B * 12 * n * sizeof(float));
+  for (int nx : {3, 8, 60})
+    for (int nu : {1, 2, 9})
+      EXPECT(dmpc_mpc_backward_rec_workspace_bytes(10, 64, nx, nu, 20, 1) >
+             dmpc_coupled_workspace_bytes(10, 20) + (size_t)64 * (nx + nu) * (nx + nu + 1) * sizeof(float));
+  EXPECT(dmpc_mpc_backward_rec(10, 64, 8, 2, p, p, p, p, p, p, p, 20, 1, p, p, pi, p, dmpc_coupled_workspace_bytes(10, 20), pi, nullptr) ==
+         DMPC_E_WORKSPACE);
   EXPECT(dmpc_batch_lu_factor(0, 2, p, p, pi, nullptr, nullptr) == DMPC_E_BADARG);
   char name[64];
   (void)dmpc_last_kernel_name(name, sizeof(name));

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "libdmpc_hip.so lacks %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert lib.dmpc_version() == _lib.ABI_VERSION == 410
+    assert lib.dmpc_version() == _lib.ABI_VERSION == 411
 
 
 def test_library_belongs_to_the_sources_in_the_tree():
@@ -48,12 +48,12 @@ def test_binding_refuses_a_library_of_another_abi_or_of_other_sources(monkeypatc
     monkeypatch.setattr(_lib, "ABI_VERSION", 409)
     with pytest.raises(_lib.DmpcError, match="C-ABI version"):
         _lib.load(_lib.LIB_PATH)
-    monkeypatch.setattr(_lib, "ABI_VERSION", 410)
+    monkeypatch.setattr(_lib, "ABI_VERSION", 411)
     lib = _lib.load(_lib.LIB_PATH)                       # explicit path: version checked, hash not
 
     class Fake:
         def dmpc_version(self):
-            return 410
+            return 411
 
         def dmpc_source_hash(self):
             return b"0" * 32
@@ -63,7 +63,7 @@ def test_binding_refuses_a_library_of_another_abi_or_of_other_sources(monkeypatc
         _lib._check_identity(Fake(), "x.so", explicit=False)
     monkeypatch.setenv("DMPC_SKIP_HASH_CHECK", "1")
     _lib._check_identity(Fake(), "x.so", explicit=False)
-    assert lib.dmpc_version() == 410
+    assert lib.dmpc_version() == 411
 
 
 def test_identity_check_names_what_differs(tmp_path, monkeypatch):

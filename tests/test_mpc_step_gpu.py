@@ -265,9 +265,9 @@ def test_shapes_beyond_8_controls_or_64_columns_against_the_oracle(shape):
     """VERDICT r03 "any shape": `MPCstep` with more than 8 controls, or more than 64 columns, used to be refused; the
     reference has no limit (mpc/mpc_step.py:70-286, mpc/pnqp.py:37-201).  The tiled kernels (mpc_tiled.hpp: a workgroup
     per trajectory, the box QP with runtime dimensions) take them: forward (backward_rec with PNQP + line search) and the
-    analytic backward against the oracle at the contract's tolerances, per-trajectory termination; the batch-coupled parity
-    mode says it is not available there."""
-    from chainer_differentiable_mpc_amd import DmpcError, _lib
+    analytic backward against the oracle at the contract's tolerances, per-trajectory termination; and (round 5) the
+    batch-coupled mode on mpc_coupled.hpp's fixed grid."""
+    from chainer_differentiable_mpc_amd import _lib
     B, T, nx, nu, bound = shape
     p = synthetic.make_lqr_problem(B, T, nx, nu, seed=7, with_f=True)
     lo, hi = -bound * np.ones((T, B, nu)), bound * np.ones((T, B, nu))
@@ -310,8 +310,15 @@ def test_shapes_beyond_8_controls_or_64_columns_against_the_oracle(shape):
         assert_close(npy(got), want, TOL_PRIMAL if key in ("dC", "dc") else TOL_COSTATE, key)
     coupled = MPCstep(dev(u0), T, dev(hi), dev(lo), B, nx, nu, dev(x0), QuadCost(dev(p["C"]), dev(p["c"])),
                       LinDx(dev(p["F"]), dev(p["f"])), ls_decay=0.2, max_ls_iter=5, need_expand=True, batch_coupled=True)
-    with pytest.raises(DmpcError):       # loud, not wrong: the batch-coupled parity mode lives in the register kernels
-        coupled.forward((dev(x0[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+    # batch-coupled at these sizes: refused until round 5, now mpc_coupled.hpp's fixed grid - against the oracle's coupled run
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xc, uc = coupled.forward((dev(x0[0]), dev(p["C"]), dev(p["c"]), dev(p["F"]), dev(p["f"])))
+        xcr, ucr, boc, foc, _, _ = ompc.mpc_forward(p["C"], p["c"], p["F"], p["f"], u0, x0, lo, hi, ompc.QuadCost(p["C"], p["c"]),
+                                                   ompc.LinDx(p["F"], p["f"]), 0.2, 5, T, nx, nu, need_expand=True, batch_coupled=True)
+    assert_close(npy(uc), ucr, TOL, "u (batch-coupled)")
+    assert_close(npy(xc), xcr, TOL, "x (batch-coupled)")
+    assert coupled.back_out.n_total_qp_iter == boc.n_total_qp_iter
 
 
 def test_tiled_mpc_step_without_recentring_and_with_an_affine_model():
@@ -341,19 +348,19 @@ def test_tiled_mpc_step_without_recentring_and_with_an_affine_model():
     assert int(step.back_out.n_total_qp_iter) >= T
 
 
-def test_batch_coupled_needs_the_batch_resident_and_says_so():
-    """the grid-wide termination needs every workgroup resident (cooperative launch): a batch that cannot be is
-    refused with DMPC_E_UNSUPPORTED instead of deadlocking; per-trajectory termination takes any batch"""
-    from chainer_differentiable_mpc_amd import DmpcError, PNQP
-    B, n = 1 << 20, 2                       # 4096 workgroups of 256 QPs: more than 256 CUs can hold at once
+def test_batch_coupled_takes_a_batch_that_is_not_resident_in_one_launch():
+    """rounds 1-4 refused this with DMPC_E_UNSUPPORTED (the register kernels' grid-wide termination needs every workgroup
+    resident); mpc_coupled.hpp's fixed grid takes any batch - parity: tests/test_coupled_gpu.py"""
+    from chainer_differentiable_mpc_amd import PNQP, _lib
+    B, n = 1 << 19, 2                       # 2048 workgroups of 256 QPs: more than the register kernel's launch holds
     p = synthetic.make_box_qp(B, n, seed=5)
     args = (dev(p["H"]), dev(p["q"]), dev(p["lower"]), dev(p["upper"]))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         x, _, _, _ = PNQP(*args)
         assert bool(torch.isfinite(x).all())
-        with pytest.raises(DmpcError):
-            PNQP(*args, batch_coupled=True)
+        xc, _, _, i = PNQP(*args, batch_coupled=True)
+    assert bool(torch.isfinite(xc).all()) and bool((PNQP.last_info["iters"] == i).all())
 
 
 def test_box_ddp_device_loop_batch_coupled_matches_the_reference_trace():
