@@ -10,6 +10,7 @@ the batch (:200-209); stop tests, the final no-op MPCstep node that carries the 
 detach mask for unconverged samples (:263-289) follow the reference.
 """
 import ctypes
+import os
 import warnings
 
 import torch
@@ -39,7 +40,7 @@ class BoxDDP(torch.nn.Module):
     def __init__(self, T, u_lower, u_upper, n_batch, n_state, n_ctrl, u_init, eps=1e-5, not_improved_lim=5,
                  line_search_decay=0.2, max_line_search_iter=10, best_cost_eps=1e-4, max_iter=10,
                  detach_unconverged=True, exit_unconverged=True, verbose=False, ilqr_verbose=False,
-                 update_dynamics=True, quiet=False, device_loop=True, batch_coupled=False, lazy_status=False):
+                 update_dynamics=True, quiet=False, device_loop=True, batch_coupled=False, lazy_status=False, graph=True):
         super().__init__()
         self.T, self.n_batch, self.n_state, self.n_ctrl = T, n_batch, n_state, n_ctrl
         self.n_sc = n_state + n_ctrl
@@ -69,6 +70,10 @@ class BoxDDP(torch.nn.Module):
         # `info`, the asserts and the reference's non-convergence warning then happen on first access, and at the latest
         # when the next solve of any BoxDDP starts (errors surface one call late instead of never).
         self.lazy_status = lazy_status
+        # device loop only: a solve called again on the same buffers replays its chain of launches from a hipGraph (_device_loop)
+        self.graph = graph
+        self._graphs = {}
+        self._fast = None           # the last recorded call, as forward() recognises it (_replay)
         self._pending = None        # (state [8] int32 on the device, info [B]) of a solve not read back yet
         self._warn_unconverged = False
         self._status = None
@@ -127,7 +132,7 @@ class BoxDDP(torch.nn.Module):
         self._pending = None
         if self in _UNRESOLVED:
             _UNRESOLVED.remove(self)
-        st = state.cpu().tolist()
+        st = state if isinstance(state, list) else state.cpu().tolist()      # (a replayed chain brings its state along)
         self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
         assert not st[4]
         assert not st[5], " lower is larger than upper"
@@ -201,45 +206,157 @@ class BoxDDP(torch.nn.Module):
         # one float and one int32 allocation per solve; the input asserts of MPCstep (mpc_step.py:133-138) and the
         # reductions over info / full_du_norm come back in state[4:8] with the loop state (box_ddp_summary_kernel)
         n_x, n_u = T * B * nx, T * B * nu
-        out = torch.empty((n_x + n_u + 3 * B,), dtype=torch.float32, device=d)
+        need = lib.dmpc_box_ddp_workspace_bytes(T, B, nx, nu)
+        scalars = (float(self.eps), int(self.not_improved_lim), float(self.ls_decay), int(self.max_ls_iter),
+                   float(self.best_cost_eps), int(self.max_iter), 1 if self.batch_coupled else 0)
+
+        def buffers():
+            out = torch.empty((n_x + n_u + 3 * B,), dtype=torch.float32, device=d)
+            ints = torch.empty((B + 8,), dtype=torch.int32, device=d)   # flags and loop state: cleared by the chain's first launch
+            return out, ints
+
+        def launch(out, ints, ws):
+            bx, bu = out[:n_x], out[n_x:n_x + n_u]
+            tail = out[n_x + n_u:]
+            with _lib.guard(d):
+                return lib.dmpc_box_ddp(T, B, nx, nu, _lib.ptr(x0), _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), kind,
+                                        None if params is None else ctypes.cast(params, ctypes.c_void_p), _lib.ptr(u0),
+                                        _lib.ptr(lo_), _lib.ptr(hi_), scalars[0], scalars[1], scalars[2], scalars[3], scalars[4],
+                                        scalars[5], 20, 1, scalars[6], _lib.ptr(bx), _lib.ptr(bu),
+                                        _lib.ptr(tail[:B]), _lib.ptr(tail[B:2 * B]), _lib.ptr(tail[2 * B:]), _lib.ptr(ints[B:]),
+                                        _lib.ptr(ws), need, _lib.ptr(ints[:B]), _lib.stream_ptr(d))
+
+        # The chain of 22-23 launches as ONE hipGraph (round 5; verdict r04 item 2): a solve called again on the SAME buffers
+        # (an MPC loop that updates its state in place, a benchmark) replays the chain recorded at its second call - the ~40 us
+        # of host time in front of the chain's first launch go (0.28 -> 0.24 ms at B = 128,
+        # profiles/r05/box_ddp_graph_ab.txt).  The key is every pointer, shape and scalar the chain was recorded with; a
+        # call with other buffers runs the chain directly, as before.  The graph owns its outputs and workspace: what the
+        # caller gets is a copy (one more small launch).  `graph=False` / DMPC_NO_DDP_GRAPH=1: never.
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = None
+        if self.graph and not capturing and os.environ.get("DMPC_NO_DDP_GRAPH") != "1":
+            key = (d, _lib.stream_ptr(d), T, B, nx, nu, kind, None if params is None else tuple(params), scalars) + tuple(
+                None if t is None else (t.data_ptr(), tuple(t.shape)) for t in (x0, C, c, F, f, u0, lo_, hi_))
+        entry = self._graphs.get(key) if key is not None else None
+        rc = 0
+        host_state = None
+        if entry is not None and entry[0] is None:     # second call on these buffers: record the chain
+            g_out, g_ints = buffers()
+            g_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=d)
+            g_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                rc = launch(g_out, g_ints, g_ws)
+                g_host.copy_(g_ints[B:], non_blocking=True)        # the loop state travels to the host inside the graph
+            if rc == 0:
+                entry = (g, g_out, g_ints, g_ws, g_host, torch.cuda.Event())
+                self._graphs[key] = entry
+            else:
+                self._graphs.pop(key, None)
+                entry = None
+        if entry is not None and entry[0] is not None:
+            g, g_out, g_ints, _ws, g_host, ev = entry
+            g.replay()
+            if not self.lazy_status:
+                ev.record()
+            out, ints = g_out.clone(), g_ints.clone()             # the caller's own copies (the graph owns its buffers)
+            if not self.lazy_status:
+                while not ev.query():                              # the one synchronisation of the loop: the chain, not the
+                    pass                                           # copies (polled: a blocking wait wakes up ~20 us late)
+                host_state = g_host.tolist()
+        else:
+            if key is not None and rc == 0:
+                if len(self._graphs) >= 4:             # (a handful of buffer sets per solver; the oldest goes)
+                    self._graphs.pop(next(iter(self._graphs)))
+                self._graphs[key] = (None,)            # seen once: the next call on these buffers records
+            out, ints = buffers()
+            rc = launch(out, ints, _workspace(need, d))
         bx, bu = out[:n_x].view(T, B, nx), out[n_x:n_x + n_u].view(T, B, nu)
         bc, bn, ln = out[n_x + n_u:].view(3, B).unbind(0)
-        ints = torch.empty((B + 8,), dtype=torch.int32, device=d)   # flags and loop state: cleared by the chain's first launch
         info, state = ints[:B], ints[B:]
-        need = lib.dmpc_box_ddp_workspace_bytes(T, B, nx, nu)
-        ws = _workspace(need, d)
-        with _lib.guard(d):
-            rc = lib.dmpc_box_ddp(T, B, nx, nu, _lib.ptr(x0), _lib.ptr(C), _lib.ptr(c), _lib.ptr(F), _lib.ptr(f), kind,
-                                  None if params is None else ctypes.cast(params, ctypes.c_void_p), _lib.ptr(u0),
-                                  _lib.ptr(lo_), _lib.ptr(hi_), float(self.eps), int(self.not_improved_lim),
-                                  float(self.ls_decay), int(self.max_ls_iter), float(self.best_cost_eps),
-                                  int(self.max_iter), 20, 1, 1 if self.batch_coupled else 0, _lib.ptr(bx), _lib.ptr(bu),
-                                  _lib.ptr(bc), _lib.ptr(bn),
-                                  _lib.ptr(ln), _lib.ptr(state), _lib.ptr(ws), need, _lib.ptr(info),
-                                  _lib.stream_ptr(d))
         if rc == _lib.E_UNSUPPORTED:
             return None
         _lib.check(rc, "dmpc_box_ddp")
         self._loop_flag = state[7:8]              # device int: some trajectory's best full_du_norm is above eps (:263)
         self._warn_unconverged = False
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             # recorded into a hipGraph, not executed: `state` holds nothing until a replay, and a replay is not this call -
             # there is no read-back to defer (a captured solve reports through its outputs and device flags only)
             self._pending = None
             if self in _UNRESOLVED:
                 _UNRESOLVED.remove(self)
         else:
-            self._pending = (state, info)
+            self._pending = (state if host_state is None else host_state, info)
             if self not in _UNRESOLVED:
                 _UNRESOLVED.append(self)
             if not self.lazy_status:
                 self._resolve()                   # the one synchronisation of the loop
         dev, dt = x_init.device, x_init.dtype
+        self._fast = None
+        if entry is not None and entry[0] is not None and dt == torch.float32 and dev == d and x0 is not None and \
+                x0.data_ptr() == x_init.data_ptr() and C.data_ptr() == cost.C.data_ptr() and c.data_ptr() == cost.c.data_ptr():
+            # what forward() checks before it replays this recording without going through any of the above
+            self._fast = (entry, x_init, cost, cost.C, cost.c, dynamics, x0.data_ptr(), C.data_ptr(), c.data_ptr(),
+                          _lib.stream_ptr(d), scalars, None if params is None else tuple(params), d)
         best = {'x': bx.to(device=dev, dtype=dt), 'u': bu.to(device=dev, dtype=dt),
                 'costs': bc.to(device=dev, dtype=dt), 'full_du_norm': bn.to(device=dev, dtype=dt)}
         return best, ln.to(device=dev, dtype=dt)
 
+    def _replay(self, inputs):
+        """forward() for the call an MPC loop makes over and over: the SAME tensors (updated in place), nothing to
+        differentiate, the chain already recorded (`_device_loop`) - replay, copy out, read the loop state.  None: not that call."""
+        entry, x_init, cost, Cc, cc, dynamics, p_x, p_C, p_c, stream, scalars, params, d = self._fast
+        xi, co, dy = inputs
+        if xi is not x_init or co is not cost or dy is not dynamics or co.C is not Cc or co.c is not cc or self.u_init is not None:
+            return None
+        if xi.data_ptr() != p_x or Cc.data_ptr() != p_C or cc.data_ptr() != p_c or _lib.stream_ptr(d) != stream:
+            return None
+        if scalars != (float(self.eps), int(self.not_improved_lim), float(self.ls_decay), int(self.max_ls_iter),
+                       float(self.best_cost_eps), int(self.max_iter), 1 if self.batch_coupled else 0):
+            return None
+        if self.verbose or self.ilqr_verbose or not self.graph or not self.device_loop or torch.cuda.is_current_stream_capturing():
+            return None
+        if torch.is_grad_enabled() and (xi.requires_grad or Cc.requires_grad or cc.requires_grad or (
+                isinstance(dy, LinDx) and (dy.F.requires_grad or (dy.f is not None and dy.f.requires_grad)))):
+            return None
+        if params is not None:
+            g_, m_, l_ = dy.host_params()
+            if params != tuple((ctypes.c_float * 6)(g_, m_, l_, float(dy.dt), float(dy.max_torque), 1.0 if dy.clamp_grad_closed else 0.0)):
+                return None
+        for other in list(_UNRESOLVED):       # earlier solves whose read-back was deferred: their asserts come now
+            other._resolve()
+        T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
+        g, g_out, g_ints, _ws, g_host, ev = entry
+        g.replay()
+        lazy = self.lazy_status
+        if not lazy:
+            ev.record()
+        out, ints = g_out.clone(), g_ints.clone()
+        n_x, n_u = T * B * nx, T * B * nu
+        self._loop_flag = ints[B + 7:B + 8]
+        self._warn_unconverged = False
+        self._best_norm_max = None
+        if lazy:
+            self._pending = (ints[B:], ints[:B])
+        else:
+            while not ev.query():
+                pass
+            self._pending = (g_host.tolist(), ints[:B])
+        _UNRESOLVED.append(self)
+        if not lazy:
+            self._resolve()
+        if self.detach_unconverged:              # (nothing to detach without a graph; the reference's warning stays, :263-273)
+            if lazy:
+                self._warn_unconverged = True
+            elif self._best_norm_max:
+                self._warn()
+        return out[:n_x].view(T, B, nx), out[n_x:n_x + n_u].view(T, B, nu), out[n_x + n_u:n_x + n_u + B]
+
     def forward(self, inputs):
+        if self._fast is not None:
+            again = self._replay(inputs)
+            if again is not None:
+                return again
         x_init, cost, dynamics = inputs
         x_init = _as_tensor(x_init)
         T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
