@@ -9,7 +9,7 @@ import shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "r05"), os.path.join(ROOT, "profiles", "r05")
 KEEP = ["parity_margins.txt", "bench_line.json", "bench_headline_kernel_stats.csv", "bench_secondary_kernel_stats.csv",
-        "rows_kernel_stats.csv", "size_sweep_steady.txt", "f64_timing.txt", "pmc_summary.txt", "mpc_step_one_launch.txt", "kkt_shape_timing.txt", "mpc_shape_timing.txt", "tile16_shapes.txt", "cfg5_shard_timing.txt"]
+        "rows_kernel_stats.csv", "size_sweep_steady.txt", "f64_timing.txt", "pmc_summary.txt", "mpc_step_one_launch.txt", "kkt_shape_timing.txt", "mpc_shape_timing.txt", "tile16_shapes.txt", "cfg5_shard_timing.txt", "shape_floor.txt", "coupled_timing.txt"]
 os.makedirs(DST, exist_ok=True)
 for name in KEEP:
     p = os.path.join(SRC, name)

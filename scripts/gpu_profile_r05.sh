@@ -46,6 +46,7 @@ if [ "$PART" = "A" ]; then
   timeout -k 10 300 python3 scripts/mpc_shape_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/mpc_shape_timing.txt
   timeout -k 10 300 python3 scripts/tile16_shapes.py 4096 2>&1 | grep -v amdgpu.ids > $OUT/tile16_shapes.txt
   timeout -k 10 300 python3 scripts/wave_mfma_timing.py 8192 2>&1 | grep -v amdgpu.ids > $OUT/cfg5_shard_timing.txt
+  timeout -k 10 600 python3 scripts/coupled_timing.py 2>&1 | grep -v "Warning\|amdgpu.ids" > $OUT/coupled_timing.txt
   ls -la $OUT
 else
   rm -f $OUT/pmc_summary.txt
@@ -60,6 +61,15 @@ else
   pmc w328_write "lqr_tile16_kernel<32, 8, true>" "WRITE_SIZE" $W
   pmc w328_mix "lqr_tile16_kernel<32, 8, true>" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY" $W
   pmc w328_mix2 "lqr_tile16_kernel<32, 8, true>" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT" $W
+  # (8,4) and (4,4) at B = 4096, T = 50: executed instructions and wavefront cycles per step (verdict r04 item 7; scripts/shape_floor.py)
+  export SHAPES=8x4,4x4
+  S="python3 $REPO/scripts/size_sweep.py"
+  pmc s84_mix "lqr_kernel<8, 4, 16" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" $S
+  pmc s44_mix "lqr_asm_kernel<4, 4" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" $S
+  unset SHAPES
+  B="python3 $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
+  pmc s82_mix "lqr_asm_kernel<8, 2" "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" $B
+  python3 $REPO/scripts/shape_floor.py $OUT/pmc_summary.txt > $OUT/shape_floor.txt
   pmc difflqr_fetch dmpc "FETCH_SIZE" python3 $REPO/scripts/difflqr_loop.py
   pmc difflqr_write dmpc "WRITE_SIZE" python3 $REPO/scripts/difflqr_loop.py
   cat $OUT/pmc_summary.txt | tail -40
