@@ -59,6 +59,10 @@ struct DdpSelectArgs {
   int copy_here;
   const float *x_new, *u_new;
   float *best_x, *best_u;
+  // one-launch iterations (box_ddp_pendulum_iter_kernel): the flags this iteration's sweep and search left in a staging word
+  // per trajectory (they may have run ahead of the stop flag) are merged into `info` here, i.e. only if the iteration counts
+  const int32_t *info_stage = nullptr;
+  int32_t *info = nullptr;
 };
 
 constexpr int kDdpCopyHereMaxB = 2048;
@@ -95,6 +99,11 @@ __device__ __forceinline__ void box_ddp_select_body(const DdpSelectArgs &a, cons
     for (int b = rb + tid; b < re; b += kDdpSelectThreads) a.keep[b] = 0;
     return;
   }
+  if (a.info_stage != nullptr && a.info != nullptr)
+    for (int b = rb + tid; b < re; b += kDdpSelectThreads) {
+      const int v = a.info_stage[b];
+      if (v != 0) atomicOr(&a.info[b], v);
+    }
   const int row = a.T * a.nu;
   float vmax = -1.f;
   bool nan_seen = false;

@@ -595,7 +595,8 @@ static MpcWs mpc_layout(int T, int B, int nx, int nu) {
 
 // workspace of the device-driven box-DDP loop (dmpc_box_ddp)
 struct DdpWs {
-  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u1, costs, old, alphas, nqp, nls, keep, info_back, sel_sync, sync, tiled, total;
+  size_t xs, F, f, c_back, Ks, ks, x_new, u_a, u_b, u_c, u1, u1_b, costs, costs_b, old, alphas, nqp, nls, keep, info_back, stage_a,
+      stage_b, sel_sync, sync, tiled, total;
 };
 static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   const size_t ns = nx + nu, TB = (size_t)T * B, fl = sizeof(float);
@@ -615,14 +616,19 @@ static DdpWs ddp_layout(int T, int B, int nx, int nu) {
   w.x_new = take(TB * nx * fl);
   w.u_a = take(TB * nu * fl);
   w.u_b = take(TB * nu * fl);
+  w.u_c = take(TB * nu * fl);     // (third control buffer, second u1 / costs, staging flags: the one-launch iterations)
   w.u1 = take(TB * nu * fl);
+  w.u1_b = take(TB * nu * fl);
   w.costs = take((size_t)B * fl);
+  w.costs_b = take((size_t)B * fl);
   w.old = take((size_t)B * fl);
   w.alphas = take((size_t)B * fl);
   w.nqp = take((size_t)B * sizeof(int32_t));
   w.nls = take((size_t)B * sizeof(int32_t));
   w.keep = take((size_t)B * sizeof(int32_t));
   w.info_back = take((size_t)B * sizeof(int32_t));
+  w.stage_a = take((size_t)B * sizeof(int32_t));
+  w.stage_b = take((size_t)B * sizeof(int32_t));
   w.sel_sync = take(4 * sizeof(unsigned));
   w.sync = take(coupled_bytes(T, kSyncQpIterMax));
   w.tiled = take(coupled_traj_bytes(B, nx, nu));
@@ -911,9 +917,20 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   const bool copy_here = B <= kDdpCopyHereMaxB && rows * (size_t)(nx + nu) <= kDdpCopyHereMaxElems;
   bool fused_select = false;   // decided at the first sweep: the bookkeeping of iteration i rides in sweep i + 1's launch
   DdpSelectArgs sa{};
+  // One launch per iteration (box_ddp_pendulum_iter_kernel) when the fused chain runs and the search is the wavefront-per-
+  // trajectory one: the search then runs BESIDE the previous iteration's bookkeeping, so what that reads (the controls the
+  // step started from, the first pass's controls, the costs) must not be what this search writes - three control buffers in
+  // rotation, two of u_first / costs, and the iteration's flags through a staging word that the bookkeeping merges.
+  // DMPC_NO_DDP_ITER_FUSED=1 (read at every call): sweep and search as two launches (A/B timing; bit-identical results).
+  bool iter_fused = false;
+  float *u_buf3[3] = {fp(w.u_a), fp(w.u_b), fp(w.u_c)};
+  float *u1_2[2] = {u1, fp(w.u1_b)}, *costs_2[2] = {costs, fp(w.costs_b)};
+  int32_t *stage_2[2] = {ip(w.stage_a), ip(w.stage_b)};
   for (int it = 0; it < max_iter; ++it) {
-    const float *u_cur = it == 0 ? u_init : u_buf[it & 1];   // the first iteration reads the caller's controls in place
-    float *u_new = u_buf[(it & 1) ^ 1];
+    // (iteration 0 names the same buffers in both rotations: the choice is made inside it)
+    const float *u_cur = it == 0 ? u_init : (iter_fused ? u_buf3[it % 3] : u_buf[it & 1]);   // the first iteration reads the caller's controls in place
+    float *u_new = iter_fused ? u_buf3[(it + 1) % 3] : u_buf[(it & 1) ^ 1];
+    float *u1_it = iter_fused ? u1_2[it & 1] : u1, *costs_it = iter_fused ? costs_2[it & 1] : costs;
     float *xs_it = fuse_lin ? x_buf[it & 1] : xs;
     float *xn_it = fuse_lin ? x_buf[(it & 1) ^ 1] : x_new;
     // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
@@ -939,21 +956,43 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
       ba.info = ip(w.info_back);
       ba.info_store = 1;
     }
-    int rc = launch_mpc_back(nx, nu, ba, stream, fused_select && it > 0 ? &sa : nullptr,
-                             reinterpret_cast<unsigned *>(base + w.sel_sync));
-    if (rc != 0) return rc;
+    if (it == 0) {
+      const char *e = getenv("DMPC_NO_DDP_ITER_FUSED");
+      iter_fused = fused_select && T >= 2 && T <= kSpec4MaxT && !spec4_disabled() && !mpc_asm_disabled() && !(e && e[0] == '1');
+    }
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs_it, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
-                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1, costs,
+                  dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1_it, costs_it,
                   /*old_costs: nobody reads them here*/ nullptr,
                   alphas, nullptr, ip(w.nls), info, dyn_kind, pg, pm, pl, pdt, pmax, pclosed, done,
                   fuse_lin ? fp(w.F) : nullptr, fuse_lin ? fp(w.f) : nullptr, fuse_lin ? c_back : nullptr, 0,
                   fused_select && info != nullptr ? ip(w.info_back) : nullptr};
-    rc = launch_mpc_fwd(nx, nu, fa, stream);
-    if (rc != 0) return rc;
+    int rc;
+    if (iter_fused) {
+      if (info != nullptr) {     // the search may run ahead of `done` too: sweep + search flags to this iteration's staging word
+        fa.info = stage_2[it & 1];
+        fa.info_store = 1;
+      }
+      const int n_sel = it > 0 ? select_parts(B) : 0;
+      const size_t lds = std::max(mpc_asm_lds_bytes<3, 1>(), Spec4Layout::lds_bytes(T));
+      DMPC_LAUNCH_GGL(box_ddp_pendulum_iter_kernel, dim3(B / 4 + n_sel), dim3(256), lds, stream, ba, fa, sa, n_sel,
+                      reinterpret_cast<unsigned *>(base + w.sel_sync));
+      rc = (int)hipGetLastError();
+      if (rc != 0) return rc;
+    } else {
+      rc = launch_mpc_back(nx, nu, ba, stream, fused_select && it > 0 ? &sa : nullptr,
+                           reinterpret_cast<unsigned *>(base + w.sel_sync));
+      if (rc != 0) return rc;
+      rc = launch_mpc_fwd(nx, nu, fa, stream);
+      if (rc != 0) return rc;
+    }
     // best-so-far update and stop tests of this iteration                                   box_ddp.py:200-230
-    sa = DdpSelectArgs{it, T, B, nx, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1, costs,
+    sa = DdpSelectArgs{it, T, B, nx, nu, max_iter, not_improved_lim, scrambled_norm, eps, best_cost_eps, u_cur, u1_it, costs_it,
                        costs_best, du_norm_best, du_norm_last, ip(w.keep), state, copy_here ? 1 : 0, xn_it, u_new,
                        x_best, u_best};
+    if (iter_fused && info != nullptr) {
+      sa.info_stage = stage_2[it & 1];
+      sa.info = info;
+    }
     if (fused_select) continue;   // rides in the next sweep's launch (the last one: in the summary launch)
     if (nx == 3 && nu == 1)
       DMPC_LAUNCH_GGL((box_ddp_select_kernel<3, 1>), dim3(1), dim3(kDdpSelectThreads), 0, stream, sa);

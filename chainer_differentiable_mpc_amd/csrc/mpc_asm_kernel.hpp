@@ -22,24 +22,23 @@ constexpr size_t mpc_asm_lds_bytes() {
 }
 
 // EXPAND: a.states given - c is the ORIGINAL linear term and the sweep re-centres it (need_expand, mpc_step.py:305-317)
+// One wavefront: the sweep of the four trajectories b0 .. b0 + 3 with its ring in slot `slot` of the workgroup's LDS
 template <int NX, int NU, bool HAS_F, bool EXPAND>
-__device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, const int block) {
+__device__ __forceinline__ void mpc_backward_asm_wave(const MpcBackArgs &a, const int b0, const int slot) {
   using G = MpcAsm<NX, NU, EXPAND>;
   static_assert(G::kAvailable, "no generated instruction stream for this shape");
   constexpr int NS = NX + NU;
   if (a.done != nullptr && *a.done != 0) return;  // uniform: the iLQR loop has stopped
   const int T = a.T;
   const size_t B = (size_t)a.B;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane64 = threadIdx.x & 63;
   const int r = lane64 >> 4;  // trajectory within the wave
   const int lane = lane64 & 15;
-  const int b0 = __builtin_amdgcn_readfirstlane((block * 4 + wave) * 4);  // first trajectory of this wave
   if (b0 >= a.B) return;      // whole wavefront (B % 4 == 0); the stream has no workgroup barrier
   const int b = b0 + r;
 
   extern __shared__ float lds[];
-  const unsigned ring = lds_byte_address(lds) + (unsigned)wave * G::RING_BYTES;
+  const unsigned ring = lds_byte_address(lds) + (unsigned)slot * G::RING_BYTES;
 
   LqrAsmIn<NX, NU> in{};      // the forward sweep's operands stay zero: the stream stops after the backward sweep
   in.ring = __builtin_amdgcn_readfirstlane(ring);
@@ -90,6 +89,12 @@ __device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, cons
 }
 
 template <int NX, int NU, bool HAS_F, bool EXPAND>
+__device__ __forceinline__ void mpc_backward_asm_body(const MpcBackArgs &a, const int block) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  mpc_backward_asm_wave<NX, NU, HAS_F, EXPAND>(a, __builtin_amdgcn_readfirstlane((block * 4 + wave) * 4), wave);
+}
+
+template <int NX, int NU, bool HAS_F, bool EXPAND>
 __global__ __launch_bounds__(256) void mpc_backward_asm_kernel(const MpcBackArgs a) {
   mpc_backward_asm_body<NX, NU, HAS_F, EXPAND>(a, blockIdx.x);
 }
@@ -105,6 +110,30 @@ __global__ __launch_bounds__(256) void mpc_backward_asm_select_kernel(const MpcB
     return;
   }
   mpc_backward_asm_body<NX, NU, HAS_F, EXPAND>(a, blockIdx.x);
+}
+
+// ONE launch per box-DDP iteration of the built-in pendulum (configs 2 and 4; round 5): a workgroup owns four trajectories -
+// its first wavefront runs their backward sweep (the generated stream with the QP inside), a workgroup barrier, then each of
+// its four wavefronts runs one trajectory's speculative line search (mpc_forward_rec_pendulum_spec4_wave); the previous
+// iteration's batch-mixing bookkeeping (box_ddp.py:200-230) rides in the launch's last n_sel workgroups as before.  Gains,
+// flags and the QP counts pass from sweep to search through global memory inside the workgroup (workgroup-scope ordering: the
+// wavefront drains its stores and LDS-DMA before the barrier); the LDS ring of the sweep and the searches' slots share the
+// dynamic LDS one after the other.  Saves the launch boundary between sweep and search: ten of a solve's 22 launches.
+__global__ __launch_bounds__(256) void box_ddp_pendulum_iter_kernel(const MpcBackArgs ba, const MpcFwdArgs fa, const DdpSelectArgs s,
+                                                                    const int n_sel, unsigned *sel_sync) {
+  const int n_main = (int)gridDim.x - n_sel;
+  if ((int)blockIdx.x >= n_main) {
+    box_ddp_select_body<256, 3, 1>(s, (int)blockIdx.x - n_main, n_sel, sel_sync);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int b0 = (int)blockIdx.x * 4;
+  if (wave == 0) {
+    mpc_backward_asm_wave<3, 1, false, false>(ba, b0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  mpc_forward_rec_pendulum_spec4_wave(fa, b0 + wave, wave);
 }
 
 }  // namespace dmpc

@@ -404,6 +404,7 @@ struct MpcFwdArgs {
   int traj_in_lds;
   const int32_t *info_in;                // [B] flags to merge into info (the backward sweep's, when it ran ahead of `done`)
   int nx_log = 0, nu_log = 0;            // container launches (PAD): the problem's own dimensions
+  int info_store = 0;                    // != 0: info[b] = this search's flags (plain store; pendulum spec4 search only)
 };
 
 // chunks of one wave-step of the forward kernel's LDS-DMA ring (DMA variant):
@@ -1100,14 +1101,13 @@ struct Spec4Layout {  // floats of one timestep's inputs in LDS (one dword per D
   static constexpr size_t lds_bytes(int T) { return (size_t)4 * 2 * T * SLOT * 4; }   // inputs + trajectories, 4 wavefronts
 };
 
-__global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(const MpcFwdArgs a) {
+// one wavefront: the search of trajectory b, its inputs and candidates in slot `wave` of the workgroup's LDS
+__device__ __forceinline__ void mpc_forward_rec_pendulum_spec4_wave(const MpcFwdArgs &a, const int b, const int wave) {
   constexpr int NX = 3, NS = 4, NC = 16;
   using Lay = Spec4Layout;
   if (a.done != nullptr && *a.done != 0) return;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane64 = threadIdx.x & 63;
   const int cand = lane64 >> 2, sub = lane64 & 3;
-  const int b = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
   if (b >= a.B) return;   // whole wavefront; no workgroup barrier below
   const int T = a.T;
   const size_t B = (size_t)a.B;
@@ -1289,8 +1289,16 @@ __global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(con
     if (a.old_costs != nullptr) a.old_costs[b] = old_cost;
     a.alphas[b] = alpha_sel;
     a.n_ls[b] = n_pass;
-    if (a.info != nullptr && info_bits != 0) atomicOr(&a.info[b], info_bits);
+    if (a.info != nullptr) {
+      if (a.info_store) a.info[b] = info_bits;
+      else if (info_bits != 0) atomicOr(&a.info[b], info_bits);
+    }
   }
+}
+
+__global__ __launch_bounds__(256) void mpc_forward_rec_pendulum_spec4_kernel(const MpcFwdArgs a) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  mpc_forward_rec_pendulum_spec4_wave(a, __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave), wave);
 }
 
 // Pendulum rollout and analytic linearisation in one pass, one lane per trajectory: x_{t+1} = pendulum(x_t, u_t)

@@ -379,6 +379,53 @@ def test_device_loop_matches_host_loop_pendulum(max_iter):
     assert_close(dev_[2], host[2], 1e-5, "costs")
 
 
+@pytest.mark.parametrize("B,max_iter", [(128, 10), (1024, 10), (260, 4), (128, 1), (8, 3)])
+def test_one_launch_iterations_are_bit_identical_to_sweep_and_search_as_two_launches(B, max_iter, monkeypatch):
+    """round 5: an iteration of the pendulum chain is ONE launch (box_ddp_pendulum_iter_kernel: a workgroup sweeps its four
+    trajectories, then searches them, beside the previous iteration's bookkeeping) - the same kernels' bodies in the same order,
+    so every output, the status, the iteration count and the flags must be those of the two-launch chain
+    (DMPC_NO_DDP_ITER_FUSED=1), bit for bit; incl. a run that stops early (the search of the iteration after the stop runs ahead
+    of the flag and must leave no trace)"""
+    from chainer_differentiable_mpc_amd import _lib
+    T = 20
+    dx, x0, Q, pv = pendulum_problem(B, T, seed=11)
+    kw = dict(eps=dx.mpc_eps, line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter, max_iter=max_iter,
+              exit_unconverged=False, quiet=True, graph=False)
+    outs = {}
+    for mode in ("two", "one"):
+        if mode == "two":
+            monkeypatch.setenv("DMPC_NO_DDP_ITER_FUSED", "1")
+        else:
+            monkeypatch.delenv("DMPC_NO_DDP_ITER_FUSED")
+        solver = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, **kw)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, c = solver((dev(x0), QuadCost(dev(Q), dev(pv)), dx))
+        outs[mode] = (x, u, c, solver.status, solver.n_iter, solver.info.clone())
+    for a, b in zip(outs["two"][:3], outs["one"][:3]):
+        assert torch.equal(a, b)
+    assert outs["two"][3:5] == outs["one"][3:5], (outs["two"][3:5], outs["one"][3:5])
+    assert torch.equal(outs["two"][5], outs["one"][5])
+    # an early stop: a loose eps ends the loop after a few iterations in both forms, with the same iterate
+    kw2 = dict(kw, eps=0.5, max_iter=10)
+    res = {}
+    for mode in ("two", "one"):
+        if mode == "two":
+            monkeypatch.setenv("DMPC_NO_DDP_ITER_FUSED", "1")
+        else:
+            monkeypatch.delenv("DMPC_NO_DDP_ITER_FUSED")
+        solver = BoxDDP(T, dx.lower, dx.upper, B, 3, 1, None, **kw2)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, u, c = solver((dev(x0), QuadCost(dev(Q), dev(pv)), dx))
+        res[mode] = (x, u, c, solver.status, solver.n_iter, solver.info.clone())
+    for a, b in zip(res["two"][:3], res["one"][:3]):
+        assert torch.equal(a, b)
+    assert res["two"][3:5] == res["one"][3:5]
+    assert torch.equal(res["two"][5], res["one"][5])
+    print("B=%d: %s after %d iterations; early stop: %s after %d" % (B, outs["one"][3], outs["one"][4], res["one"][3], res["one"][4]))
+
+
 @pytest.mark.parametrize("B", [128, 1024])
 def test_a_solve_called_again_on_the_same_buffers_replays_its_chain_from_a_graph(B):
     """verdict r04 item 2, the minimum asked: the chain of 22-23 launches captured as a hipGraph INSIDE `BoxDDP` by default.
