@@ -438,23 +438,32 @@ def secondary_metrics(device, d_headline):
         Q = torch.diag(q).to(device)[None, None].expand(20, Bp, -1, -1).contiguous()
         pv = pp.to(device)[None, None].expand(20, Bp, -1).contiguous()
         x0 = torch.as_tensor(sample_xinit(Bp, seed=0), dtype=torch.float32, device=device)
-        solver = BoxDDP(20, dx.lower, dx.upper, Bp, 3, 1, None, eps=dx.mpc_eps, max_iter=10, exit_unconverged=False,
-                        line_search_decay=dx.linesearch_decay, max_line_search_iter=dx.max_linesearch_iter, quiet=True)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            with torch.no_grad():
-                for _ in range(3):
-                    solver((x0, QuadCost(Q, pv), dx))
-                torch.cuda.synchronize()
-                times = []          # every solve ends with its own host read-back (no other synchronisation here):
-                for _ in range(7):       # blocks of 5 solves, the median block reported - a mean over a few
-                    t0 = time.perf_counter()     # milliseconds is at the mercy of one host hiccup
-                    for _ in range(5):
+        kw_ddp = dict(eps=dx.mpc_eps, max_iter=10, exit_unconverged=False, line_search_decay=dx.linesearch_decay,
+                      max_line_search_iter=dx.max_linesearch_iter, quiet=True)
+        res = {}
+        for key, graph in (("ms_per_solve", True), ("ms_per_solve_launched", False)):
+            # graph=True (the default): from its second call on the same buffers on, BoxDDP replays the chain of launches it
+            # recorded (a hipGraph of its own); graph=False launches the chain every time, as rounds 1-4 did
+            solver = BoxDDP(20, dx.lower, dx.upper, Bp, 3, 1, None, graph=graph, **kw_ddp)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                with torch.no_grad():
+                    for _ in range(4):
                         solver((x0, QuadCost(Q, pv), dx))
-                    times.append((time.perf_counter() - t0) / 5)
-                t = float(np.median(times))
+                    torch.cuda.synchronize()
+                    times = []          # every solve ends with its own host read-back (no other synchronisation here):
+                    for _ in range(7):       # blocks of 5 solves, the median block reported - a mean over a few
+                        t0 = time.perf_counter()     # milliseconds is at the mercy of one host hiccup
+                        for _ in range(5):
+                            solver((x0, QuadCost(Q, pv), dx))
+                        times.append((time.perf_counter() - t0) / 5)
+                    res[key] = float(np.median(times))
+        t = res["ms_per_solve"]
         out[name] = {"what": "BoxDDP (pendulum, true cost, T=20, 10 iLQR iterations incl. the host synchronisation), "
-                             "B=%d; median of 7 blocks of 5 solves" % Bp, "ms_per_solve": t * 1e3, "ilqr_timestep_solves_per_s": Bp * 20 * solver.n_iter / t}
+                             "B=%d; median of 7 blocks of 5 solves on the same buffers: BoxDDP replays its chain of 12-13 launches "
+                             "from the hipGraph it recorded itself (ms_per_solve_launched: graph=False, the chain launched every "
+                             "time)" % Bp, "ms_per_solve": t * 1e3, "ms_per_solve_launched": res["ms_per_solve_launched"] * 1e3,
+                     "ilqr_timestep_solves_per_s": Bp * 20 * solver.n_iter / t}
     # (vi) config 4 as the TRAINING update it names (env_dx/il_env.py:104-158, il_exp.py:213-302), timed by
     # scripts/imitation_update_timing.py in a process of its own: one of its three figures replays the update from a
     # hipGraph, and a capture that goes wrong inside the HIP runtime must not take the benchmark line with it

@@ -307,7 +307,8 @@ class BoxDDP(torch.nn.Module):
         differentiate, the chain already recorded (`_device_loop`) - replay, copy out, read the loop state.  None: not that call."""
         entry, x_init, cost, Cc, cc, dynamics, p_x, p_C, p_c, stream, scalars, params, d = self._fast
         xi, co, dy = inputs
-        if xi is not x_init or co is not cost or dy is not dynamics or co.C is not Cc or co.c is not cc or self.u_init is not None:
+        if xi is not x_init or type(co) is not type(cost) or dy is not dynamics or co.C is not Cc or co.c is not cc or \
+                self.u_init is not None:      # (the cost OBJECT may be a new one around the same tensors: QuadCost(C, c) per call)
             return None
         if xi.data_ptr() != p_x or Cc.data_ptr() != p_C or cc.data_ptr() != p_c or _lib.stream_ptr(d) != stream:
             return None
