@@ -250,8 +250,11 @@ class ClockSampler:
         cap = self._read("power1_cap")
         return {"samples": len(self.samples), "sclk_mhz": stat(0, 1e-6), "mclk_mhz": stat(1, 1e-6), "power_w": stat(2, 1e-6),
                 "power_cap_w": None if cap is None else cap * 1e-6,
-                "what": "hwmon freq1_input / freq2_input / power1_input of this rank's GPU, sampled every ~2 ms during the timed "
-                        "blocks (sysfs reads up to ~10 % above the in-kernel clock: MI355X_MICROARCH.md, DVFS give-back item 6)"}
+                "what": "hwmon freq1_input / freq2_input / power1_input of this rank's GPU, sampled every ~2 ms by a host thread "
+                        "(`clocks`: during the timed blocks - ~1 ms of load each between synchronisations, which the sensors' "
+                        "refresh of a few milliseconds mostly misses; `clocks_run_up`: during the >= 60 ms run-up of the same "
+                        "launch back to back that ends right before them).  sysfs reads up to ~10 % above the in-kernel clock "
+                        "(MI355X_MICROARCH.md, DVFS give-back item 6)"}
 
 
 def settle(fn, min_ms=SETTLE_MS, max_ms=600.0, block=25, fixed_blocks=None):
@@ -714,8 +717,12 @@ def main():
         cold = (time.perf_counter() - c0) / args.steps
     # the device in the power state of a running job (every rank its own GPU), then the contract's W warm-up steps
     # (with --gather the step holds a collective: every rank runs the same, fixed number of blocks)
-    pre_calls, pre_ms, pre_times = (0, 0.0, [None, None]) if args.no_settle else settle(
-        step, fixed_blocks=(80 if B * T * (nx + nu) ** 2 < 1e8 else 4) if gx is not None else None)
+    # (the run-up is >= 60 ms of the same launch back to back: the sensors, which the SMU refreshes every few milliseconds, have
+    # time to show the state the timed blocks then run in - the blocks themselves are ~1 ms each)
+    with ClockSampler(device.index or 0) as run_up_clocks:
+        pre_calls, pre_ms, pre_times = (0, 0.0, [None, None]) if args.no_settle else settle(
+            step, fixed_blocks=(80 if B * T * (nx + nu) ** 2 < 1e8 else 4) if gx is not None else None)
+    run_up_clock_info = None if args.no_settle else run_up_clocks.summary()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -871,6 +878,7 @@ def main():
                                     "what": "value / ms_per_step / frac are the MEDIAN of n timed regions of exactly K steps each "
                                             "(barrier + synchronize on both sides, max over ranks)"},
                          "clocks": clock_info,
+                         "clocks_run_up": run_up_clock_info,
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_s * 1e3,
                          "kernel_ms_wall": elapsed / args.steps * 1e3,
                          "protocol": "value/frac are taken AFTER an untimed run-up of the same step to the device's steady "
