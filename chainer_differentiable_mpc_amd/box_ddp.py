@@ -234,7 +234,8 @@ class BoxDDP(torch.nn.Module):
         # caller gets is a copy (one more small launch).  `graph=False` / DMPC_NO_DDP_GRAPH=1: never.
         capturing = torch.cuda.is_current_stream_capturing()
         key = None
-        if self.graph and not capturing and os.environ.get("DMPC_NO_DDP_GRAPH") != "1":
+        if self.graph and not capturing and not self.batch_coupled and os.environ.get("DMPC_NO_DDP_GRAPH") != "1":
+            # (batch_coupled: its grid barriers need cooperative launches, which a stream capture does not take)
             key = (d, _lib.stream_ptr(d), T, B, nx, nu, kind, None if params is None else tuple(params), scalars) + tuple(
                 None if t is None else (t.data_ptr(), tuple(t.shape)) for t in (x0, C, c, F, f, u0, lo_, hi_))
         entry = self._graphs.get(key) if key is not None else None
@@ -245,15 +246,22 @@ class BoxDDP(torch.nn.Module):
             g_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=d)
             g_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                rc = launch(g_out, g_ints, g_ws)
-                g_host.copy_(g_ints[B:], non_blocking=True)        # the loop state travels to the host inside the graph
+            try:
+                with torch.cuda.graph(g):
+                    rc = launch(g_out, g_ints, g_ws)
+                    g_host.copy_(g_ints[B:], non_blocking=True)        # the loop state travels to the host inside the graph
+            except RuntimeError:      # a launch the capture does not take: this solver launches its chain from now on
+                rc = _lib.E_UNSUPPORTED
+                self.graph = False
+                self._graphs.clear()
             if rc == 0:
                 entry = (g, g_out, g_ints, g_ws, g_host, torch.cuda.Event())
                 self._graphs[key] = entry
             else:
                 self._graphs.pop(key, None)
                 entry = None
+                key = None
+                rc = 0
         if entry is not None and entry[0] is not None:
             g, g_out, g_ints, _ws, g_host, ev = entry
             g.replay()
