@@ -463,7 +463,7 @@ def secondary_metrics(device, d_headline):
                     res[key] = float(np.median(times))
         t = res["ms_per_solve"]
         out[name] = {"what": "BoxDDP (pendulum, true cost, T=20, 10 iLQR iterations incl. the host synchronisation), "
-                             "B=%d; median of 7 blocks of 5 solves on the same buffers: BoxDDP replays its chain of 12-13 launches "
+                             "B=%d; median of 7 blocks of 5 solves on the same buffers: BoxDDP replays its chain of 11-12 launches "
                              "from the hipGraph it recorded itself (ms_per_solve_launched: graph=False, the chain launched every "
                              "time)" % Bp, "ms_per_solve": t * 1e3, "ms_per_solve_launched": res["ms_per_solve_launched"] * 1e3,
                      "ilqr_timestep_solves_per_s": Bp * 20 * solver.n_iter / t}

@@ -921,8 +921,16 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   // trajectory one: the search then runs BESIDE the previous iteration's bookkeeping, so what that reads (the controls the
   // step started from, the first pass's controls, the costs) must not be what this search writes - three control buffers in
   // rotation, two of u_first / costs, and the iteration's flags through a staging word that the bookkeeping merges.
-  // DMPC_NO_DDP_ITER_FUSED=1 (read at every call): sweep and search as two launches (A/B timing; bit-identical results).
+  // The first of these launches also rolls out and linearises the nominal trajectory (the chain's first launch otherwise).
+  // DMPC_NO_DDP_ITER_FUSED=1 (read at every call): rollout, sweep and search as launches of their own (A/B timing; bit-identical).
   bool iter_fused = false;
+  if (fuse_lin && nx == 3 && nu == 1 && copy_here) {   // (decided before the first launch: the first iteration's launch also rolls out)
+    const MpcBackArgs ba0{T, B, C, c_back, F_hat, nullptr, u_init, u_lower, u_upper, n_qp_iter_max, Ks, ks, ip(w.nqp), info, done,
+                          batch_coupled ? reinterpret_cast<unsigned *>(base + w.sync) : nullptr, nullptr, 0};
+    const char *e = getenv("DMPC_NO_DDP_ITER_FUSED");
+    iter_fused = mpc_back_dma_ok(ba0) && T >= 2 && T <= kSpec4MaxT && !spec4_disabled() && !mpc_asm_disabled() &&
+                 aligned16(fp(w.F)) && !(e && e[0] == '1');
+  }
   float *u_buf3[3] = {fp(w.u_a), fp(w.u_b), fp(w.u_c)};
   float *u1_2[2] = {u1, fp(w.u1_b)}, *costs_2[2] = {costs, fp(w.costs_b)};
   int32_t *stage_2[2] = {ip(w.stage_a), ip(w.stage_b)};
@@ -934,11 +942,13 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
     float *xs_it = fuse_lin ? x_buf[it & 1] : xs;
     float *xn_it = fuse_lin ? x_buf[(it & 1) ^ 1] : x_new;
     // nominal trajectory and the Taylor models around it                                    box_ddp.py:123-171
+    PendulumArgs pa_first{};     // one-launch iterations: the first iteration's launch rolls out and linearises itself (pa_first.T > 0)
     if (dyn_kind == 1) {
       if (it == 0 || !fuse_lin) {
         PendulumArgs pa{T, B, x_init, u_cur, pg, pm, pl, pdt, pmax, pclosed, xs_it, fp(w.F), fp(w.f), it == 0 ? nullptr : done, C, c,
                         c_back, it == 0 ? clear : ChainClear{}};
-        launch_pendulum_rollout(pa, stream);
+        if (iter_fused) pa_first = pa;
+        else launch_pendulum_rollout(pa, stream);
       }
     } else {
       DMPC_LAUNCH_GGL(lin_rollout_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, T, B, nx, nu, x_init, u_cur, F,
@@ -956,10 +966,6 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
       ba.info = ip(w.info_back);
       ba.info_store = 1;
     }
-    if (it == 0) {
-      const char *e = getenv("DMPC_NO_DDP_ITER_FUSED");
-      iter_fused = fused_select && T >= 2 && T <= kSpec4MaxT && !spec4_disabled() && !mpc_asm_disabled() && !(e && e[0] == '1');
-    }
     MpcFwdArgs fa{T, B, Ks, ks, u_cur, xs_it, u_lower, u_upper, C, c, dyn_kind == 0 ? F : nullptr,
                   dyn_kind == 0 ? f : nullptr, ls_decay, max_ls_iter, /*ls_cap=*/64, xn_it, u_new, u1_it, costs_it,
                   /*old_costs: nobody reads them here*/ nullptr,
@@ -972,10 +978,11 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
         fa.info = stage_2[it & 1];
         fa.info_store = 1;
       }
+      if (it == 0) ba.done = fa.done = nullptr;   // (this launch clears the flag; nothing can have stopped the loop yet)
       const int n_sel = it > 0 ? select_parts(B) : 0;
       const size_t lds = std::max(mpc_asm_lds_bytes<3, 1>(), Spec4Layout::lds_bytes(T));
       DMPC_LAUNCH_GGL(box_ddp_pendulum_iter_kernel, dim3(B / 4 + n_sel), dim3(256), lds, stream, ba, fa, sa, n_sel,
-                      reinterpret_cast<unsigned *>(base + w.sel_sync));
+                      reinterpret_cast<unsigned *>(base + w.sel_sync), pa_first);
       rc = (int)hipGetLastError();
       if (rc != 0) return rc;
     } else {

@@ -119,8 +119,11 @@ __global__ __launch_bounds__(256) void mpc_backward_asm_select_kernel(const MpcB
 // flags and the QP counts pass from sweep to search through global memory inside the workgroup (workgroup-scope ordering: the
 // wavefront drains its stores and LDS-DMA before the barrier); the LDS ring of the sweep and the searches' slots share the
 // dynamic LDS one after the other.  Saves the launch boundary between sweep and search: ten of a solve's 22 launches.
+// pa.T > 0 (the solve's first iteration): the nominal trajectory, its linearisation and the re-centred cost first - the lanes
+// 0..15 of the first wavefront, four per trajectory (pendulum_rollout_linearize4_lane) - and the chain's words cleared; that
+// launch must not be given the stop flag (it clears it) nor accumulate into `info` (it clears that too).
 __global__ __launch_bounds__(256) void box_ddp_pendulum_iter_kernel(const MpcBackArgs ba, const MpcFwdArgs fa, const DdpSelectArgs s,
-                                                                    const int n_sel, unsigned *sel_sync) {
+                                                                    const int n_sel, unsigned *sel_sync, const PendulumArgs pa) {
   const int n_main = (int)gridDim.x - n_sel;
   if ((int)blockIdx.x >= n_main) {
     box_ddp_select_body<256, 3, 1>(s, (int)blockIdx.x - n_main, n_sel, sel_sync);
@@ -128,7 +131,12 @@ __global__ __launch_bounds__(256) void box_ddp_pendulum_iter_kernel(const MpcBac
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int b0 = (int)blockIdx.x * 4;
+  if (pa.T > 0) {
+    pa.clear.run((int)(blockIdx.x * blockDim.x + threadIdx.x));
+    if (threadIdx.x < 16) pendulum_rollout_linearize4_lane(pa, b0 + ((int)threadIdx.x >> 2), (int)threadIdx.x & 3);
+  }
   if (wave == 0) {
+    if (pa.T > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sweep's LDS-DMA reads what these lanes just stored
     mpc_backward_asm_wave<3, 1, false, false>(ba, b0, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   }

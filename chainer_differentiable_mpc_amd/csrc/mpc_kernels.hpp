@@ -1403,10 +1403,8 @@ __global__ __launch_bounds__(64) void pendulum_rollout_linearize_kernel(const Pe
 // B / 64 wavefronts, so its time is the instructions of a step - the four lanes repeat the state update and split
 // what has rows: lane `sub` stores x_t[sub], row `sub` of F_t (one 16-byte store) with f_t[sub], and row `sub` of the
 // re-centred cost.  Same values as pendulum_jacobian_store.
-__global__ __launch_bounds__(256) void pendulum_rollout_linearize4_kernel(const PendulumArgs a) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  a.clear.run(g);
-  const int b = g >> 2, sub = g & 3;
+// lane `sub` of trajectory b (the caller has run a.clear)
+__device__ __forceinline__ void pendulum_rollout_linearize4_lane(const PendulumArgs &a, const int b, const int sub) {
   if (b >= a.B) return;
   if (a.done != nullptr && *a.done != 0) return;
   const size_t B = (size_t)a.B;
@@ -1467,6 +1465,12 @@ __global__ __launch_bounds__(256) void pendulum_rollout_linearize4_kernel(const 
     s = sn;
     w = nw;
   }
+}
+
+__global__ __launch_bounds__(256) void pendulum_rollout_linearize4_kernel(const PendulumArgs a) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  a.clear.run(g);
+  pendulum_rollout_linearize4_lane(a, g >> 2, g & 3);
 }
 
 // c_back[t][b][i] = sum_j C[t][b][i][j] tau[t][b][j] + c[t][b][i]        (mpc_step.py:305-317), one lane per (t,b,i)
