@@ -885,7 +885,7 @@ int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float 
   if (dyn_kind == 0 && !F) return DMPC_E_BADARG;
   if (dyn_kind == 1 && (!dyn_params || nx != 3 || nu != 1)) return DMPC_E_BADARG;
   if (dyn_kind != 0 && dyn_kind != 1) return DMPC_E_UNSUPPORTED;
-  if (mpc_needs_tiles(nx, nu)) return DMPC_E_UNSUPPORTED;   // any-size shapes: the caller runs the loop over MPCstep objects (nothing launched)
+  // (round 5: shapes that run on the tiled kernels - more than 8 controls / 64 columns - too: their matrices live in w.tiled)
   if ((size_t)T * B * (nx + nu) >= ((size_t)1 << 31)) return DMPC_E_UNSUPPORTED;  // 32-bit indices in the bookkeeping
   if (!aligned16(C) || !aligned16(c) || !aligned16(F) || !aligned16(f) || !aligned16(ws)) return DMPC_E_BADARG;
   const DdpWs w = ddp_layout(T, B, nx, nu);
