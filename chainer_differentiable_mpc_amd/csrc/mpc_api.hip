@@ -359,8 +359,10 @@ static int launch_mpc_back(int nx, int nu, const MpcBackArgs &a_in, hipStream_t 
   // B = 4096, T = 50 it beats the runtime-dimension kernel where the latter's QP in lane 0 is widest - (24,8) 9.2 against
   // 12.5 ms - and lost below - (20,6) 7.8 against 5.4 ms, (10,5) 5.4 against 2.9 ms.
   // (Round 4, the padded instance fetching through its LDS-DMA slot: (20,6) 3.4 against 3.8 ms - six controls and more.)
+  // (Round 5, from 21 states on with three to five controls, from 24 with one or two: the runtime-dimension kernel's cost grows with nx^2 in one lane group -
+  // (32,4) 7.7 ms, (32,2) 6.4, (23,4) 4.2, (24,4) 3.9 - where the padded (32,8) instance stays at ~3 ms: (32,4) 3.1, (32,2) 2.8, (24,4) 3.0.)
   if (wave_ok && !small && nu >= 6 && nx <= 16 && nu <= 8) return wave_container(16, 8);
-  if (wave_ok && !small && nu >= 6 && nx <= 32 && nu <= 8) return wave_container(32, 8);
+  if (wave_ok && !small && (nu >= 6 || nx >= (nu >= 3 ? 21 : 24)) && nx <= 32 && nu <= 8) return wave_container(32, 8);
   // any other shape with nx + nu + 1 <= 64, nu <= 8: runtime-dimension kernel (mpc_generic.hpp)
   if (nx + nu + 1 <= 64 && nu <= kMpcGenericMaxNu) {
     void *args2[] = {&a, &nx};
