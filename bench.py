@@ -875,6 +875,8 @@ def main():
                                     "ms_per_step_median": elapsed / args.steps * 1e3,
                                     "ms_per_step_max": max(block_wall) / args.steps * 1e3,
                                     "kernel_ms_min": min(block_ev) * 1e3, "kernel_ms_max": max(block_ev) * 1e3,
+                                    "ms_per_step_in_order": [round(w / args.steps * 1e3, 5) for w in block_wall],
+                                    "kernel_ms_in_order": [round(e * 1e3, 5) for e in block_ev],
                                     "what": "value / ms_per_step / frac are the MEDIAN of n timed regions of exactly K steps each "
                                             "(barrier + synchronize on both sides, max over ranks)"},
                          "clocks": clock_info,
