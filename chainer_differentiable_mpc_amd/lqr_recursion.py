@@ -223,6 +223,9 @@ def saved_solve_device(c, F, Ks, Quu, Qxu, x_init, T, n_state, n_ctrl, info=None
     return x, u
 
 
+_SOLVE_GEOMETRY = {}     # (T, B, nx, nu) -> (workspace bytes, kernel family, wide row kernel?)
+
+
 def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False, info=None, out=None):
     """Raw fused solve on float32 device tensors (no copies): the unit the benchmark times.
     Returns (x, u, Ks|None, ks|None)."""
@@ -243,12 +246,16 @@ def solve_device(C, c, F, f, x_init, mask, T, n_state, n_ctrl, want_gains=False,
     ws = None
     ws_bytes = 0
     # gains stay in LDS unless the horizon is long or the shape runs on the generic kernel
-    need = lib.dmpc_lqr_workspace_bytes(T, B, nx, nu)
+    geo = _SOLVE_GEOMETRY.get((T, B, nx, nu))
+    if geo is None:       # (three library queries per problem size, not per call)
+        geo = _SOLVE_GEOMETRY[(T, B, nx, nu)] = (lib.dmpc_lqr_workspace_bytes(T, B, nx, nu), lib.dmpc_lqr_kernel_family(nx, nu),
+                                                 lib.dmpc_lqr_solve_path(T, B, nx, nu) == 9)
+        if len(_SOLVE_GEOMETRY) > 256:
+            _SOLVE_GEOMETRY.pop(next(iter(_SOLVE_GEOMETRY)))
+    need, family, wide = geo
     per_traj_lds = T * nu * (nx + 1) * 4
-    family = lib.dmpc_lqr_kernel_family(nx, nu)
     # (family 5 - beyond 64 columns - keeps every trajectory's matrices in the workspace, whoever receives the gains)
     # (... and the wide row kernel - solve path 9 - sends its gain rows through it on their way to the rollout)
-    wide = lib.dmpc_lqr_solve_path(T, B, nx, nu) == 9
     if family == 5 or wide or (not want_gains and (per_traj_lds * 16 > 60 * 1024 or family != 1)):
         ws = _workspace(need, dev)
         ws_bytes = need
