@@ -74,6 +74,7 @@ class BoxDDP(torch.nn.Module):
         self.graph = graph
         self._graphs = {}
         self._fast = None           # the last recorded call, as forward() recognises it (_replay)
+        self._host_state = None     # lazy_status, chain launched: (pinned int32[8], event) the loop state is copied to
         self._pending = None        # (state [8] int32 on the device, info [B]) of a solve not read back yet
         self._warn_unconverged = False
         self._status = None
@@ -132,7 +133,11 @@ class BoxDDP(torch.nn.Module):
         self._pending = None
         if self in _UNRESOLVED:
             _UNRESOLVED.remove(self)
-        st = state if isinstance(state, list) else state.cpu().tolist()      # (a replayed chain brings its state along)
+        if isinstance(state, tuple):       # (pinned words, event): copied out behind the chain, waited for on ITS event only -
+            state[1].synchronize()         # a `.cpu()` here would wait for everything enqueued since (the update's backward
+            st = state[0].tolist()         # pass, the optimiser step) and stall a loop that is meant to run ahead of the device
+        else:
+            st = state if isinstance(state, list) else state.cpu().tolist()      # (a replayed chain brings its state along)
         self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
         assert not st[4]
         assert not st[5], " lower is larger than upper"
@@ -265,13 +270,14 @@ class BoxDDP(torch.nn.Module):
         if entry is not None and entry[0] is not None:
             g, g_out, g_ints, _ws, g_host, ev = entry
             g.replay()
-            if not self.lazy_status:
-                ev.record()
+            ev.record()
             out, ints = g_out.clone(), g_ints.clone()             # the caller's own copies (the graph owns its buffers)
             if not self.lazy_status:
                 while not ev.query():                              # the one synchronisation of the loop: the chain, not the
                     pass                                           # copies (polled: a blocking wait wakes up ~20 us late)
                 host_state = g_host.tolist()
+            else:
+                host_state = (g_host, ev)                          # read when the status is asked for (before the next replay)
         else:
             if key is not None and rc == 0:
                 if len(self._graphs) >= 4:             # (a handful of buffer sets per solver; the oldest goes)
@@ -279,6 +285,12 @@ class BoxDDP(torch.nn.Module):
                 self._graphs[key] = (None,)            # seen once: the next call on these buffers records
             out, ints = buffers()
             rc = launch(out, ints, _workspace(need, d))
+            if rc == 0 and self.lazy_status and not capturing:    # the loop state to pinned memory behind the chain, with its event
+                if self._host_state is None:
+                    self._host_state = (torch.empty((8,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+                self._host_state[0].copy_(ints[B:], non_blocking=True)
+                self._host_state[1].record()
+                host_state = self._host_state
         bx, bu = out[:n_x].view(T, B, nx), out[n_x:n_x + n_u].view(T, B, nu)
         bc, bn, ln = out[n_x + n_u:].view(3, B).unbind(0)
         info, state = ints[:B], ints[B:]
@@ -338,15 +350,14 @@ class BoxDDP(torch.nn.Module):
         g, g_out, g_ints, _ws, g_host, ev = entry
         g.replay()
         lazy = self.lazy_status
-        if not lazy:
-            ev.record()
+        ev.record()
         out, ints = g_out.clone(), g_ints.clone()
         n_x, n_u = T * B * nx, T * B * nu
         self._loop_flag = ints[B + 7:B + 8]
         self._warn_unconverged = False
         self._best_norm_max = None
         if lazy:
-            self._pending = (ints[B:], ints[:B])
+            self._pending = ((g_host, ev), ints[:B])
         else:
             while not ev.query():
                 pass
