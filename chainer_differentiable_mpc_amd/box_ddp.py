@@ -91,8 +91,10 @@ class BoxDDP(torch.nn.Module):
         assert list(self.u_lower.shape) == [T, n_batch, n_ctrl], 'actual' + str(tuple(self.u_lower.shape))
         assert list(self.u_upper.shape) == [T, n_batch, n_ctrl]
 
+    # (BoxDDP is a torch.nn.Module: a plain `self.x = ...` goes through Module.__setattr__ - parameter / buffer / submodule checks,
+    # ~1.5 us each, fourteen of them per solve; the per-solve bookkeeping below writes the instance dictionary directly)
     def _say(self, msg):
-        self._status = msg.strip()
+        self.__dict__["_status"] = msg.strip()
         if not self.quiet:
             print(msg)
 
@@ -104,7 +106,7 @@ class BoxDDP(torch.nn.Module):
 
     @status.setter
     def status(self, v):
-        self._status = v
+        self.__dict__["_status"] = v
 
     @property
     def n_iter(self):
@@ -113,7 +115,7 @@ class BoxDDP(torch.nn.Module):
 
     @n_iter.setter
     def n_iter(self, v):
-        self._n_iter = v
+        self.__dict__["_n_iter"] = v
 
     @property
     def info(self):
@@ -122,7 +124,7 @@ class BoxDDP(torch.nn.Module):
 
     @info.setter
     def info(self, v):
-        self._info = v
+        self.__dict__["_info"] = v
 
     def _resolve(self):
         """the one synchronisation of the device loop: loop state, the input asserts of MPCstep (mpc_step.py:133-138), NaN
@@ -130,7 +132,7 @@ class BoxDDP(torch.nn.Module):
         if self._pending is None:
             return
         state, info = self._pending
-        self._pending = None
+        self.__dict__["_pending"] = None
         if self in _UNRESOLVED:
             _UNRESOLVED.remove(self)
         if isinstance(state, tuple):       # (pinned words, event): copied out behind the chain, waited for on ITS event only -
@@ -138,17 +140,17 @@ class BoxDDP(torch.nn.Module):
             st = state[0].tolist()         # pass, the optimiser step) and stall a loop that is meant to run ahead of the device
         else:
             st = state if isinstance(state, list) else state.cpu().tolist()      # (a replayed chain brings its state along)
-        self._best_norm_max = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
+        self.__dict__["_best_norm_max"] = bool(st[7])         # full_du_norm of the best iterate above eps somewhere (:263)
         assert not st[4]
         assert not st[5], " lower is larger than upper"
         if st[6]:                                 # the reference asserts on NaN inside every MPC step
             raise AssertionError("BoxDDP: NaN/Inf in the solution of %d trajectories" % st[6])
-        self._info = info
-        self._n_iter = st[1]
+        self.__dict__["_info"] = info
+        self.__dict__["_n_iter"] = st[1]
         if st[2] in self._STATUS:
             self._say(self._STATUS[st[2]])
         if self._warn_unconverged and self._best_norm_max:
-            self._warn_unconverged = False
+            self.__dict__["_warn_unconverged"] = False
             self._warn()
 
     def _warn(self):
@@ -287,7 +289,7 @@ class BoxDDP(torch.nn.Module):
             rc = launch(out, ints, _workspace(need, d))
             if rc == 0 and self.lazy_status and not capturing:    # the loop state to pinned memory behind the chain, with its event
                 if self._host_state is None:
-                    self._host_state = (torch.empty((8,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
+                    self.__dict__["_host_state"] = (torch.empty((8,), dtype=torch.int32, pin_memory=True), torch.cuda.Event())
                 self._host_state[0].copy_(ints[B:], non_blocking=True)
                 self._host_state[1].record()
                 host_state = self._host_state
@@ -297,26 +299,26 @@ class BoxDDP(torch.nn.Module):
         if rc == _lib.E_UNSUPPORTED:
             return None
         _lib.check(rc, "dmpc_box_ddp")
-        self._loop_flag = state[7:8]              # device int: some trajectory's best full_du_norm is above eps (:263)
-        self._warn_unconverged = False
+        self.__dict__["_loop_flag"] = state[7:8]              # device int: some trajectory's best full_du_norm is above eps (:263)
+        self.__dict__["_warn_unconverged"] = False
         if capturing:
             # recorded into a hipGraph, not executed: `state` holds nothing until a replay, and a replay is not this call -
             # there is no read-back to defer (a captured solve reports through its outputs and device flags only)
-            self._pending = None
+            self.__dict__["_pending"] = None
             if self in _UNRESOLVED:
                 _UNRESOLVED.remove(self)
         else:
-            self._pending = (state if host_state is None else host_state, info)
+            self.__dict__["_pending"] = (state if host_state is None else host_state, info)
             if self not in _UNRESOLVED:
                 _UNRESOLVED.append(self)
             if not self.lazy_status:
                 self._resolve()                   # the one synchronisation of the loop
         dev, dt = x_init.device, x_init.dtype
-        self._fast = None
+        self.__dict__["_fast"] = None
         if entry is not None and entry[0] is not None and dt == torch.float32 and dev == d and x0 is not None and \
                 x0.data_ptr() == x_init.data_ptr() and C.data_ptr() == cost.C.data_ptr() and c.data_ptr() == cost.c.data_ptr():
             # what forward() checks before it replays this recording without going through any of the above
-            self._fast = (entry, x_init, cost, cost.C, cost.c, dynamics, x0.data_ptr(), C.data_ptr(), c.data_ptr(),
+            self.__dict__["_fast"] = (entry, x_init, cost, cost.C, cost.c, dynamics, x0.data_ptr(), C.data_ptr(), c.data_ptr(),
                           _lib.stream_ptr(d), scalars, None if params is None else tuple(params), d)
         best = {'x': bx.to(device=dev, dtype=dt), 'u': bu.to(device=dev, dtype=dt),
                 'costs': bc.to(device=dev, dtype=dt), 'full_du_norm': bn.to(device=dev, dtype=dt)}
@@ -353,21 +355,21 @@ class BoxDDP(torch.nn.Module):
         ev.record()
         out, ints = g_out.clone(), g_ints.clone()
         n_x, n_u = T * B * nx, T * B * nu
-        self._loop_flag = ints[B + 7:B + 8]
-        self._warn_unconverged = False
-        self._best_norm_max = None
+        self.__dict__["_loop_flag"] = ints[B + 7:B + 8]
+        self.__dict__["_warn_unconverged"] = False
+        self.__dict__["_best_norm_max"] = None
         if lazy:
-            self._pending = ((g_host, ev), ints[:B])
+            self.__dict__["_pending"] = ((g_host, ev), ints[:B])
         else:
             while not ev.query():
                 pass
-            self._pending = (g_host.tolist(), ints[:B])
+            self.__dict__["_pending"] = (g_host.tolist(), ints[:B])
         _UNRESOLVED.append(self)
         if not lazy:
             self._resolve()
         if self.detach_unconverged:              # (nothing to detach without a graph; the reference's warning stays, :263-273)
             if lazy:
-                self._warn_unconverged = True
+                self.__dict__["_warn_unconverged"] = True
             elif self._best_norm_max:
                 self._warn()
         return out[:n_x].view(T, B, nx), out[n_x:n_x + n_u].view(T, B, nu), out[n_x + n_u:n_x + n_u + B]
@@ -426,7 +428,7 @@ class BoxDDP(torch.nn.Module):
         n_not_improved = 0
         for_out = None
         last_norm = None
-        self._best_norm_max = None
+        self.__dict__["_best_norm_max"] = None
         if self.device_loop and not self.verbose and not self.ilqr_verbose and isinstance(cost, QuadCost):
             looped = self._device_loop(x_init, cost, dynamics, u, lo, hi)
             if looped is not None:
@@ -498,7 +500,7 @@ class BoxDDP(torch.nn.Module):
                 isinstance(t, torch.Tensor) and t.requires_grad for t in leaves)):
             if self.detach_unconverged:
                 if deferred:
-                    self._warn_unconverged = True          # (the warning comes with the read-back)
+                    self.__dict__["_warn_unconverged"] = True          # (the warning comes with the read-back)
                 elif unconverged():
                     self._warn()
             return x, u, costs
@@ -527,7 +529,7 @@ class BoxDDP(torch.nn.Module):
             x, u = _MPCstepTiledFn.apply(x[0].detach(), cost.Q, cost.p, spec, retained, x, u)
             if self.detach_unconverged:
                 if deferred:
-                    self._warn_unconverged = True
+                    self.__dict__["_warn_unconverged"] = True
                 elif unconverged():
                     self._warn()
             return x, u, costs

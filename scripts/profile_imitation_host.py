@@ -34,4 +34,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(200): train_step()
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "cumulative")).print_stats(45); print(s.getvalue()[:9000])
