@@ -217,10 +217,13 @@ class BoxDDP(torch.nn.Module):
         scalars = (float(self.eps), int(self.not_improved_lim), float(self.ls_decay), int(self.max_ls_iter),
                    float(self.best_cost_eps), int(self.max_iter), 1 if self.batch_coupled else 0)
 
+        n_f = n_x + n_u + 3 * B
+
+        def split(both):      # ONE allocation: the float outputs, then (as int32) the flags and the loop state
+            return both[:n_f], both[n_f:].view(torch.int32)
+
         def buffers():
-            out = torch.empty((n_x + n_u + 3 * B,), dtype=torch.float32, device=d)
-            ints = torch.empty((B + 8,), dtype=torch.int32, device=d)   # flags and loop state: cleared by the chain's first launch
-            return out, ints
+            return split(torch.empty((n_f + B + 8,), dtype=torch.float32, device=d))   # (the ints: cleared by the chain's first launch)
 
         def launch(out, ints, ws):
             bx, bu = out[:n_x], out[n_x:n_x + n_u]
@@ -249,7 +252,8 @@ class BoxDDP(torch.nn.Module):
         rc = 0
         host_state = None
         if entry is not None and entry[0] is None:     # second call on these buffers: record the chain
-            g_out, g_ints = buffers()
+            g_both = torch.empty((n_f + B + 8,), dtype=torch.float32, device=d)
+            g_out, g_ints = split(g_both)
             g_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=d)
             g_host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
             g = torch.cuda.CUDAGraph()
@@ -262,7 +266,7 @@ class BoxDDP(torch.nn.Module):
                 self.graph = False
                 self._graphs.clear()
             if rc == 0:
-                entry = (g, g_out, g_ints, g_ws, g_host, torch.cuda.Event())
+                entry = (g, g_both, n_f, g_ws, g_host, torch.cuda.Event())
                 self._graphs[key] = entry
             else:
                 self._graphs.pop(key, None)
@@ -270,10 +274,10 @@ class BoxDDP(torch.nn.Module):
                 key = None
                 rc = 0
         if entry is not None and entry[0] is not None:
-            g, g_out, g_ints, _ws, g_host, ev = entry
+            g, g_both, _nf, _ws, g_host, ev = entry
             g.replay()
             ev.record()
-            out, ints = g_out.clone(), g_ints.clone()             # the caller's own copies (the graph owns its buffers)
+            out, ints = split(g_both.clone())                     # the caller's own copy (the graph owns its buffers)
             if not self.lazy_status:
                 while not ev.query():                              # the one synchronisation of the loop: the chain, not the
                     pass                                           # copies (polled: a blocking wait wakes up ~20 us late)
@@ -349,11 +353,12 @@ class BoxDDP(torch.nn.Module):
         for other in list(_UNRESOLVED):       # earlier solves whose read-back was deferred: their asserts come now
             other._resolve()
         T, B, nx, nu = self.T, self.n_batch, self.n_state, self.n_ctrl
-        g, g_out, g_ints, _ws, g_host, ev = entry
+        g, g_both, n_f, _ws, g_host, ev = entry
         g.replay()
         lazy = self.lazy_status
         ev.record()
-        out, ints = g_out.clone(), g_ints.clone()
+        both = g_both.clone()
+        out, ints = both[:n_f], both[n_f:].view(torch.int32)
         n_x, n_u = T * B * nx, T * B * nu
         self.__dict__["_loop_flag"] = ints[B + 7:B + 8]
         self.__dict__["_warn_unconverged"] = False
