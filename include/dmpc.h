@@ -301,7 +301,12 @@ int dmpc_lin_rollout(int T, int B, int nx, int nu, const float *x_init, const fl
  *   [6] trajectories whose info carries DMPC_INFO_NONFINITE (0 without info), [7] du_norm_best > eps somewhere;
  *   scrambled_norm != 0 reproduces the reference's reshape in full_du_norm (mpc_step.py:261-263);
  *   batch_coupled != 0: batch-global PNQP termination inside every step (as dmpc_mpc_backward_rec);
- *   info [B] (optional) is cleared by the call and receives the OR of the MPC step flags of every iteration.      */
+ *   info [B] (optional) is cleared by the call and receives the OR of the MPC step flags of every iteration.
+ *   Any shape since round 5 (shapes beyond 8 controls / 64 columns run their steps on the tiled kernels, matrices in `ws`);
+ *   DMPC_E_UNSUPPORTED only at T*B*(nx+nu) >= 2^31.  The pendulum at T <= 32, B % 4 == 0: ONE launch per iteration (a workgroup
+ *   sweeps its four trajectories, then searches them; the first launch also rolls out and linearises) - 11-12 launches a solve;
+ *   DMPC_NO_DDP_ITER_FUSED=1: 22-23, bit-identical.  The chain contains no host synchronisation and no allocation: it can be
+ *   recorded in a hipGraph (batch_coupled = 0) - BoxDDP (box_ddp.py) does so by itself for a solve called again on the same buffers. */
 size_t dmpc_box_ddp_workspace_bytes(int T, int B, int nx, int nu);
 int dmpc_box_ddp(int T, int B, int nx, int nu, const float *x_init, const float *C, const float *c, const float *F,
                  const float *f, int dyn_kind, const float *dyn_params, const float *u_init, const float *u_lower,
